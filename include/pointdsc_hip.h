@@ -1,0 +1,211 @@
+/*
+ * pointdsc_hip.h -- C ABI of libpointdsc_hip.so (gfx950 / MI355X).
+ *
+ * The reference (XuyangBai/PointDSC) has no FFI of its own: its hot path is the Python method
+ * PointDSC.forward(data) in testing mode (reference models/PointDSC.py:128-197) built from stock ATen
+ * calls.  This header is the boundary a maintainer binds with ctypes: one entry
+ * point per reference stage (so each stage can be parity-checked on its own) plus one whole-path call.
+ * Every entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HIP, fp32 unless stated), caller-owned, never retained;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it: no host
+ *     synchronisation, no allocation, no hidden global state (graph-capturable);
+ *   - tensors are dense row-major; `bs` = number of correspondence sets (pairs), `N` = correspondences
+ *     per pair, `C` = 128 channels, `S` = number of seeds, `k` = neighbours per seed;
+ *   - bs > 1 means bs independent pairs, i.e. the reference called once per pair (the reference's
+ *     testing mode asserts bs == 1, models/PointDSC.py:210,414);
+ *   - return value 0 = enqueued, < 0 = rejected (pdsc_last_error() tells why); nothing is enqueued
+ *     on rejection.
+ */
+#ifndef POINTDSC_HIP_H
+#define POINTDSC_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDSC_VERSION 1
+#define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
+#define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
+#define PDSC_MAX_POWER_ITERS 32
+
+enum pdsc_status {
+    PDSC_OK = 0,
+    PDSC_ERR_ARG = -1,           /* bad argument (null pointer, unsupported size) */
+    PDSC_ERR_WORKSPACE = -2,     /* workspace too small                           */
+    PDSC_ERR_LAUNCH = -3         /* HIP launch error                              */
+};
+
+/* Constructor arguments of reference PointDSC.__init__ (models/PointDSC.py:81-91) that the path uses. */
+typedef struct pdsc_config {
+    int in_dim;              /* 6                                              */
+    int num_layers;          /* 12 in the released snapshots                   */
+    int num_channels;        /* must be PDSC_CHANNELS                          */
+    int num_iterations;      /* power-iteration cap, 10                        */
+    int k;                   /* neighbours per seed, 40                        */
+    int refine_iters;        /* 20 (models/PointDSC.py:416-418)                */
+    float inlier_threshold;  /* hypothesis-scoring threshold (:328,:335)       */
+    float nms_radius;        /* NMS radius R (:174)                            */
+    float refine_threshold;  /* 0.10 if inlier_threshold == 0.10 else 1.2 (:415-418) */
+} pdsc_config;
+
+/* ---- packed weights --------------------------------------------------------------------------
+ * One flat fp32 buffer holding the model with BatchNorm (eval) folded into the preceding conv and
+ * log2(e)/sqrt(C) folded into the Q projection.  Offsets (in floats) come from pdsc_wpack_offset so
+ * that the host packer (pointdsc_amd/model.py) and the kernels cannot disagree.
+ * All matrices are [out][in] row-major exactly like Conv1d.weight[:, :, 0]. */
+enum pdsc_wsection {
+    PDSC_W_LAYER0_W = 0,  /* [C][8]   in_dim zero-padded to 8   (encoder.layer0)            */
+    PDSC_W_LAYER0_B,      /* [C]                                                             */
+    PDSC_W_PCN_W,         /* per layer [C][C]     PointCN conv + BN folded                   */
+    PDSC_W_PCN_B,         /* per layer [C]                                                   */
+    PDSC_W_QKV_W,         /* per layer [3C][C]    rows: q (pre-scaled), k, v                 */
+    PDSC_W_QKV_B,         /* per layer [3C]                                                  */
+    PDSC_W_FC1_W,         /* per layer [C/2][C]   fc_message.0 + BN .1 folded                */
+    PDSC_W_FC1_B,         /* per layer [C/2]                                                 */
+    PDSC_W_FC2_W,         /* per layer [C/2][C/2] fc_message.3 + BN .4 folded                */
+    PDSC_W_FC2_B,         /* per layer [C/2]                                                 */
+    PDSC_W_FC3_W,         /* per layer [C][C/2]   fc_message.6                               */
+    PDSC_W_FC3_B,         /* per layer [C]                                                   */
+    PDSC_W_CLS1_W,        /* [32][C]   classification.0                                      */
+    PDSC_W_CLS1_B,        /* [32]                                                            */
+    PDSC_W_CLS2_W,        /* [32][32]  classification.2                                      */
+    PDSC_W_CLS2_B,        /* [32]                                                            */
+    PDSC_W_CLS3_W,        /* [32]      classification.4                                      */
+    PDSC_W_CLS3_B,        /* [1]                                                             */
+    PDSC_W_SIGMA,         /* [1]  learned feature-compat sigma   (models/PointDSC.py:97)     */
+    PDSC_W_SIGMA_SPAT,    /* [1]  spatial sigma_d                (models/PointDSC.py:98)     */
+    PDSC_W_NUM_SECTIONS
+};
+
+int         pdsc_version(void);
+const char* pdsc_last_error(void);
+
+/* total floats of the packed buffer / offset of a section (layer ignored for per-model sections);
+ * returns -1 on bad arguments */
+long long pdsc_wpack_floats(const pdsc_config* cfg);
+long long pdsc_wpack_offset(const pdsc_config* cfg, int section, int layer);
+
+/* leading dimension (floats) the compat matrix rows must have for N correspondences */
+long long pdsc_compat_ld(int N);
+
+/* bytes of scratch pdsc_forward_testing needs (compat matrix included) */
+size_t pdsc_workspace_bytes(const pdsc_config* cfg, int bs, int N, int num_seeds);
+
+/* ---- a-1  spatial-consistency matrix -----------------------------------------------------------
+ * replaces models/PointDSC.py:150-153.
+ *   src_dist[i][j] = ||src_i - src_j||_2 ,  compat[i][j] = max(0, 1 - (src_dist - tgt_dist)^2 / sigma_spat^2)
+ * compat: [bs][N][ld] (ld >= N, multiple of 4; columns N..ld-1 are written as 0).
+ * src_dist: optional (may be NULL) [bs][N][ld]; the fused path never materialises it. */
+int pdsc_spatial_compat(const float* src_keypts, const float* tgt_keypts, const float* sigma_spat,
+                        float* compat, float* src_dist, long long ld, int bs, int N, void* stream);
+
+/* ---- a-2  point-wise layers --------------------------------------------------------------------
+ * replaces every Conv1d(kernel_size=1)[+BatchNorm1d(eval)][+ReLU] of models/PointDSC.py:12-23,54-61,107-113.
+ *   Y[m][n] = act( sum_k X[m][k] * W[n][k] + bias[n] ) (+ residual[m][n])
+ * X [M][ldx], W [Nout][K], Y [M][ldy]; K multiple of 8 and <= 128; ldx, ldy, ldr multiples of 4.
+ * bias / residual may be NULL.  relu applies before the residual add (fc_message has no final ReLU). */
+int pdsc_linear(const float* X, long long ldx, const float* W, const float* bias,
+                const float* residual, long long ldr, float* Y, long long ldy,
+                int M, int K, int Nout, int relu, void* stream);
+
+/* encoder.layer0 (models/PointDSC.py:54,73): feat[m][c] = sum_d corr_pos[m][d] * W0[c][d] + b0[c];
+ * corr_pos [M][in_dim] dense, W0 [C][8] (zero-padded), feat [M][C]. */
+int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat,
+                int M, void* stream);
+
+/* ---- a-3  spatial-consistency guided non-local attention ---------------------------------------
+ * replaces models/PointDSC.py:39-42 (both einsums and the softmax; N x N scores never materialised).
+ *   msg[o][:] = sum_i softmax_i( compat[o][i] * <Q_o, K_i> / sqrt(C) ) * V_i
+ * qkv [bs*N][3C] rows = (q | k | v) with q PRE-SCALED by log2(e)/sqrt(C) (see PDSC_W_QKV_W);
+ * compat [bs][N][ld]; msg [bs*N][C].  `scratch` holds split-key partials, size from
+ * pdsc_attention_scratch_bytes; nsplit <= 0 lets the library choose. */
+size_t pdsc_attention_scratch_bytes(int bs, int N, int nsplit);
+int    pdsc_attention_default_split(int bs, int N);
+int    pdsc_sc_attention(const float* qkv, const float* compat, long long ld, float* msg,
+                         void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream);
+
+/* ---- a-4  L2 normalisation + last classifier layer --------------------------------------------
+ * replaces F.normalize (models/PointDSC.py:156) and classification.4 (:112,171).
+ *   normed[m][:] = feat[m][:] / max(||feat[m]||_2, 1e-12);  conf[m] = <h2[m][0:32], w3> + b3 */
+int pdsc_normalize_confidence(const float* feat, const float* h2, const float* w3, const float* b3,
+                              float* normed, float* conf, int M, void* stream);
+
+/* ---- a-5  NMS seed selection -------------------------------------------------------------------
+ * replaces pick_seeds (models/PointDSC.py:199-217).
+ *   keys[i] = conf[i] * [ for all j: conf[i] >= conf[j]  or  ||src_i - src_j|| >= radius ]
+ *   seeds   = first num_seeds indices by descending key, equal keys by ascending index. */
+int pdsc_nms_keys(const float* src_keypts, const float* conf, float radius, float* keys,
+                  int bs, int N, void* stream);
+int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream);
+
+/* ---- a-6  feature-space kNN of the seeds -------------------------------------------------------
+ * replaces knn(..., ignore_self=True, normalized=True) + the seed gather
+ * (models/common.py:48-69, models/PointDSC.py:250-252); only the seed rows are computed.
+ *   dist[s][j] = 2 - 2 * <normed[seed_s], normed[j]>;  knn_idx[s][0:k] = ranks 1..k of ascending
+ *   (dist, index) order (rank 0 dropped exactly like `[:, :, 1:]`).
+ * dist_scratch: [bs][S][ldd] floats, ldd = pdsc_compat_ld(N).  knn_idx: [bs][S][k] int32. */
+int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx,
+                   int bs, int N, int S, int k, void* stream);
+
+/* ---- a-7/a-8  per-seed compatibility + power iteration ----------------------------------------
+ * replaces models/PointDSC.py:257-281 and cal_leading_eigenvector (:347-358).
+ * Every iterate is stored: eig_iters [bs][S][num_iterations][PDSC_MAX_K]; conv_mask[b] bit i is set iff
+ * every seed of pair b satisfied the allclose test at iteration i (the reference's early exit is global
+ * over the S seeds).  seed_M (optional, may be NULL): [bs][S][k][k]. */
+int pdsc_seed_power_iteration(const float* normed, const float* src_keypts, const float* tgt_keypts,
+                              const int* knn_idx, const float* sigma, const float* sigma_spat,
+                              float* eig_iters, unsigned int* conv_mask, float* seed_M,
+                              int bs, int N, int S, int k, int num_iterations, void* stream);
+
+/* ---- a-9  seed-wise weighted Procrustes --------------------------------------------------------
+ * replaces models/PointDSC.py:282-320 (weight normalisation + rigid_transform_3d on the k neighbours).
+ * Picks iterate `first set bit of conv_mask, else num_iterations-1`.  seed_trans [bs][S][16]. */
+int pdsc_seed_transforms(const float* src_keypts, const float* tgt_keypts, const int* knn_idx,
+                         const float* eig_iters, const unsigned int* conv_mask, float* seed_trans,
+                         float* seed_weights /* optional [bs][S][k] */,
+                         int bs, int N, int S, int k, int num_iterations, void* stream);
+
+/* rigid_transform_3d(A, B, weights, weight_threshold) (models/common.py:7-45 + utils/SE3.py:73-96):
+ * A,B [bs][n][3], weights [bs][n] or NULL (=1), T [bs][16] row-major 4x4 with p_B = R p_A + t.
+ * weights are NOT modified (the reference zeroes weights < threshold in place). */
+int pdsc_rigid_transform_3d(const float* A, const float* B, const float* weights, float weight_threshold,
+                            float* T, int bs, int n, void* stream);
+
+/* ---- a-10  hypothesis scoring ------------------------------------------------------------------
+ * replaces models/PointDSC.py:325-335.  counts[b][s] = #{n : ||R_s src_n + t_s - tgt_n|| < thr};
+ * best = first argmax; initial_trans = seed_trans[best]; labels[n] = residual_best[n] < thr (0/1 fp32). */
+int pdsc_score_hypotheses(const float* seed_trans, const float* src_keypts, const float* tgt_keypts,
+                          float inlier_threshold, int* counts, int bs, int N, int S, void* stream);
+int pdsc_select_best(const int* counts, const float* seed_trans, const float* src_keypts,
+                     const float* tgt_keypts, float inlier_threshold, int* best, float* initial_trans,
+                     float* labels, int bs, int N, int S, void* stream);
+
+/* ---- a-11  post refinement ---------------------------------------------------------------------
+ * replaces post_refinement (models/PointDSC.py:403-438) incl. transform (utils/SE3.py:43-57): the whole
+ * <=max_iters loop runs on the device.  solves (optional) [bs] = number of re-solves performed. */
+int pdsc_post_refinement(const float* initial_trans, const float* src_keypts, const float* tgt_keypts,
+                         float threshold, int max_iters, float* final_trans, int* solves,
+                         int bs, int N, void* stream);
+
+/* ---- whole path --------------------------------------------------------------------------------
+ * replaces PointDSC.forward(data) with 'testing' in data (models/PointDSC.py:128-197).
+ * corr_pos [bs][N][in_dim], src/tgt [bs][N][3]  ->  final_trans [bs][16], final_labels [bs][N] (0/1).
+ * num_seeds = int(N * ratio) computed by the caller in double precision like the reference (:174). */
+int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack,
+                         const float* corr_pos, const float* src_keypts, const float* tgt_keypts,
+                         int bs, int N, int num_seeds,
+                         float* final_trans, float* final_labels,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Named views into the workspace of the last layout computed for (cfg, bs, N, num_seeds): lets the
+ * parity tests read intermediates after pdsc_forward_testing.  Returns byte offset or -1. */
+long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTDSC_HIP_H */

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Pins the oracle against the reference implementation and writes the golden fixtures.
+
+Run in the BUILD container only (it imports the unmodified reference from /root/reference, which does not
+exist on the GPU box):
+
+    python oracle/check_against_reference.py            # check + (re)write tests/golden/*
+
+For every case it
+  1. builds seeded inputs and weights (pointdsc_amd/synthetic.py; numpy RandomState, platform independent),
+  2. runs the reference ``PointDSC.forward`` (testing mode, CPU) and, stage by stage, the reference's own
+     methods (encoder, pick_seeds, knn, cal_leading_eigenvector, rigid_transform_3d, post_refinement),
+  3. runs oracle/pointdsc_oracle.py on the same inputs and asserts agreement (bit-exact for distances,
+     compat, seeds, neighbour sets, inlier counts, best index and labels; tight tolerances for floating-point
+     stages whose op order differs),
+  4. stores the REFERENCE outputs as fixtures: tests/golden/<case>.npz, and the agreement summary in
+     tests/golden/PINNING.json.
+The fixtures are what the GPU parity tests compare the HIP path with on the GPU box.
+"""
+from __future__ import annotations
+
+import json
+import sys
+import warnings
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference")
+
+from oracle import pointdsc_oracle as O  # noqa: E402
+from pointdsc_amd import synthetic  # noqa: E402
+from pointdsc_amd.model import PointDSC as AmdPointDSC  # noqa: E402  (state_dict template only)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+# name, N, pair kwargs, weight seed, model kwargs, store N x N stages?
+CASES = [
+    dict(name="n257_s0", N=257, pair=dict(seed=0, inlier_ratio=0.3), wseed=0, model=dict(), full=True),
+    dict(name="n1000_s1", N=1000, pair=dict(seed=1, inlier_ratio=0.2), wseed=6, model=dict(), full=False),
+    # default-initialised BN + unshifted logits: every logit is negative, NMS keys tie at -0/0 and the
+    # reference's unstable argsort decides the seed ORDER (backend-defined) -> labels must still agree, the
+    # pose only to refinement accuracy
+    dict(name="n1000_s2_defaultbn", N=1000, pair=dict(seed=2, inlier_ratio=0.3), wseed=2, model=dict(),
+         full=False, randomize_bn=False, tie_case=True),
+    dict(name="n2053_s3", N=2053, pair=dict(seed=3, inlier_ratio=0.25), wseed=3, model=dict(), full=False),
+    dict(name="kitti_n1500_s4", N=1500, pair=dict(seed=4, inlier_ratio=0.3, scale=60.0, noise=0.1), wseed=4,
+         model=dict(inlier_threshold=0.6, sigma_d=1.2, nms_radius=0.6), full=False),
+    dict(name="n5000_s5", N=5000, pair=dict(seed=5, inlier_ratio=0.2), wseed=5, model=dict(), full=False),
+]
+BASE_MODEL = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
+                  inlier_threshold=0.10, sigma_d=0.10, k=40, nms_radius=0.10)
+
+
+def build_models(case):
+    sys.path.insert(0, str(REF))
+    from models.PointDSC import PointDSC as RefPointDSC  # the unmodified reference
+    kw = dict(BASE_MODEL, **case["model"])
+    tmpl = AmdPointDSC(**kw)
+    sd = synthetic.make_state_dict(tmpl.state_dict(), seed=case["wseed"], randomize_bn=case.get("randomize_bn", True))
+    ref = RefPointDSC(**kw)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    return ref, sd, kw
+
+
+def maxabs(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def run_case(case):
+    ref, sd, kw = build_models(case)
+    from models.common import knn as ref_knn
+    pair = synthetic.make_pair(case["N"], **case["pair"])
+    corr, src, tgt = pair["corr_pos"], pair["src_keypts"], pair["tgt_keypts"]
+    N = case["N"]
+    rep = {"N": N}
+    with torch.no_grad():
+        # ---- reference, whole path ----
+        res = ref({"corr_pos": corr, "src_keypts": src, "tgt_keypts": tgt, "testing": True})
+        # ---- reference, stage by stage (its own methods) ----
+        r_dist = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
+        r_compat = r_dist - torch.norm(tgt[:, :, None, :] - tgt[:, None, :, :], dim=-1)
+        r_compat = torch.clamp(1.0 - r_compat ** 2 / ref.sigma_spat ** 2, min=0)
+        r_feat = ref.encoder(corr.permute(0, 2, 1), r_compat).permute(0, 2, 1)
+        r_normed = torch.nn.functional.normalize(r_feat, p=2, dim=-1)
+        r_conf = ref.classification(r_feat.permute(0, 2, 1)).squeeze(1)
+        S = int(N * kw["ratio"])
+        r_seeds = ref.pick_seeds(r_dist, r_conf, R=kw["nms_radius"], max_num=S)
+        k = min(kw["k"], N - 1)
+        r_knn_all = ref_knn(r_normed, k=k, ignore_self=True, normalized=True)
+        r_knn = r_knn_all.gather(dim=1, index=r_seeds[:, :, None].expand(-1, -1, k))[0]
+        seed_trans_r, fitness_r, initial_r, labels_r = ref.cal_seed_trans(r_seeds, r_normed, src, tgt)
+        final_r = ref.post_refinement(initial_r, src, tgt)
+        assert torch.equal(final_r, res["final_trans"]) and torch.equal(labels_r, res["final_labels"])
+
+        # ---- oracle ----
+        ores = O.forward_testing(sd, corr, src, tgt, return_stages=True,
+                                 **{kk: kw[kk] for kk in ("num_layers", "num_channels", "num_iterations", "ratio",
+                                                         "inlier_threshold", "k", "nms_radius")})
+        st = ores["stages"][0]
+
+    # ---- agreement ----
+    rep["src_dist_bitexact"] = bool(torch.equal(st["src_dist"], r_dist[0]))
+    rep["compat_bitexact"] = bool(torch.equal(st["compat"], r_compat[0]))
+    rep["compat_maxabs"] = maxabs(st["compat"], r_compat[0])
+    rep["feat_maxabs"] = maxabs(st["feat"], r_feat[0])
+    rep["feat_scale"] = float(r_feat.abs().max())
+    rep["normed_maxabs"] = maxabs(st["normed"], r_normed[0])
+    rep["conf_maxabs"] = maxabs(st["confidence"], r_conf[0])
+    # seeds: the reference's argsort is unstable on ties; compare as ordered list, and as sets
+    r_keys = O.nms_keys(r_dist[0], r_conf[0], kw["nms_radius"])
+    rep["nms_keys_equal_given_ref_conf"] = bool(torch.equal(
+        torch.sort(r_keys, descending=True, stable=True).indices[:S], r_seeds[0])) if S else True
+    rep["seeds_equal"] = bool(torch.equal(st["seeds"], r_seeds[0]))
+    rep["seeds_set_equal"] = set(st["seeds"].tolist()) == set(r_seeds[0].tolist())
+    knn_sets_equal = sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(st["knn_idx"], r_knn))
+    rep["knn_sets_equal_frac"] = knn_sets_equal / max(S, 1) if rep["seeds_equal"] else None
+    rep["knn_ordered_equal"] = bool(torch.equal(st["knn_idx"], r_knn)) if rep["seeds_equal"] else None
+    rep["seed_trans_maxabs"] = maxabs(st["seed_trans"], seed_trans_r[0]) if rep["seeds_equal"] else None
+    r_counts = (fitness_r[0] * N).round().long()
+    rep["counts_equal"] = bool(torch.equal(st["counts"], r_counts)) if rep["seeds_equal"] else None
+    rep["best_equal"] = bool(st["best"] == int(fitness_r[0].argmax())) if rep["seeds_equal"] else None
+    rep["labels_equal"] = bool(torch.equal(st["final_labels"], res["final_labels"][0]))
+    rep["label_flips"] = int((st["final_labels"] != res["final_labels"][0]).sum())
+    rep["initial_trans_maxabs"] = maxabs(st["initial_trans"], initial_r[0])
+    rep["final_trans_maxabs"] = maxabs(st["final_trans"], res["final_trans"][0])
+    rep["num_inliers_pred"] = int(res["final_labels"].sum())
+    rep["num_inliers_gt"] = int(pair["gt_labels"].sum())
+    re, te = O.registration_errors(res["final_trans"][0], pair["gt_trans"][0])
+    rep["ref_RE_deg"], rep["ref_TE_cm"] = re, te
+    rep["power_iters_run"] = st["power_iters"]
+    rep["refine_solves"] = st["refine_solves"]
+
+    # ---- fixtures: REFERENCE outputs (+ inputs, so the GPU box needs nothing else) ----
+    fx = dict(
+        corr_pos=corr.numpy(), src_keypts=src.numpy(), tgt_keypts=tgt.numpy(),
+        gt_trans=pair["gt_trans"].numpy(), gt_labels=pair["gt_labels"].numpy(),
+        wseed=np.int64(case["wseed"]), randomize_bn=np.bool_(case.get("randomize_bn", True)),
+        model_json=np.array(json.dumps(kw)), tie_case=np.bool_(case.get("tie_case", False)),
+        weights_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
+        ref_final_trans=res["final_trans"].numpy(), ref_final_labels=res["final_labels"].numpy(),
+        ref_initial_trans=initial_r.numpy(), ref_conf=r_conf.numpy(), ref_seeds=r_seeds.numpy(),
+        ref_knn_idx=r_knn.numpy(), ref_seed_trans=seed_trans_r.numpy(), ref_counts=r_counts.numpy(),
+        ref_feat_sample=r_feat[0, :: max(N // 64, 1)].numpy(), ref_normed_sample=r_normed[0, :: max(N // 64, 1)].numpy(),
+    )
+    if case["full"]:
+        fx.update(ref_src_dist=r_dist.numpy(), ref_compat=r_compat.numpy(), ref_feat=r_feat.numpy(),
+                  ref_normed=r_normed.numpy())
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(GOLDEN / f"{case['name']}.npz", **fx)
+    return rep
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(8)
+    report = {}
+    ok = True
+    for case in CASES:
+        rep = run_case(case)
+        report[case["name"]] = rep
+        print(case["name"], json.dumps(rep))
+        # hard requirements of the pin
+        must = [rep["src_dist_bitexact"], rep["compat_bitexact"], rep["seeds_set_equal"], rep["labels_equal"],
+                rep["final_trans_maxabs"] < (1e-3 if case.get("tie_case") else 2e-5), rep["conf_maxabs"] < 1e-4 * max(rep["feat_scale"], 1.0),
+                rep["ref_RE_deg"] < 1.0 and rep["num_inliers_pred"] >= 0.9 * rep["num_inliers_gt"]]  # fixture is well-conditioned
+        if not all(must):
+            ok = False
+            print("  !! pin violated:", must)
+    (GOLDEN / "PINNING.json").write_text(json.dumps(report, indent=1))
+    print("oracle pinned against the reference" if ok else "ORACLE DISAGREES WITH THE REFERENCE")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,103 @@
+"""ctypes binding of include/pointdsc_hip.h.
+
+There is NO CPU fallback: if libpointdsc_hip.so is missing or does not export every declared symbol the
+import of the product path fails loudly (``PointDSCLibraryError``).  Loading the library needs only the HIP
+runtime, so it also works (for symbol checks) on a box without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("POINTDSC_HIP_LIB", PKG / "libpointdsc_hip.so"))
+
+
+class PointDSCLibraryError(RuntimeError):
+    pass
+
+
+class PdscConfig(C.Structure):
+    """struct pdsc_config (include/pointdsc_hip.h)."""
+    _fields_ = [
+        ("in_dim", C.c_int), ("num_layers", C.c_int), ("num_channels", C.c_int),
+        ("num_iterations", C.c_int), ("k", C.c_int), ("refine_iters", C.c_int),
+        ("inlier_threshold", C.c_float), ("nms_radius", C.c_float), ("refine_threshold", C.c_float),
+    ]
+
+
+# enum pdsc_wsection
+W_SECTIONS = [
+    "LAYER0_W", "LAYER0_B", "PCN_W", "PCN_B", "QKV_W", "QKV_B", "FC1_W", "FC1_B", "FC2_W", "FC2_B",
+    "FC3_W", "FC3_B", "CLS1_W", "CLS1_B", "CLS2_W", "CLS2_B", "CLS3_W", "CLS3_B", "SIGMA", "SIGMA_SPAT",
+]
+W = {name: i for i, name in enumerate(W_SECTIONS)}
+
+_vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+_cfgp = C.POINTER(PdscConfig)
+
+# name -> (restype, argtypes); must list every function include/pointdsc_hip.h declares
+SIGNATURES = {
+    "pdsc_version": (_i, []),
+    "pdsc_last_error": (C.c_char_p, []),
+    "pdsc_wpack_floats": (_ll, [_cfgp]),
+    "pdsc_wpack_offset": (_ll, [_cfgp, _i, _i]),
+    "pdsc_compat_ld": (_ll, [_i]),
+    "pdsc_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),
+    "pdsc_workspace_offset": (_ll, [_cfgp, _i, _i, _i, C.c_char_p]),
+    "pdsc_spatial_compat": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "pdsc_attention_scratch_bytes": (_sz, [_i, _i, _i]),
+    "pdsc_attention_default_split": (_i, [_i, _i]),
+    "pdsc_sc_attention": (_i, [_vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "pdsc_normalize_confidence": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pdsc_nms_keys": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
+    "pdsc_rank_select": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pdsc_knn_seeds": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pdsc_seed_power_iteration": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pdsc_seed_transforms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pdsc_rigid_transform_3d": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
+    "pdsc_score_hypotheses": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "pdsc_select_best": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pdsc_post_refinement": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp]),
+    "pdsc_forward_testing": (_i, [_cfgp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library; raise PointDSCLibraryError if unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PointDSCLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m pointdsc_amd.build` (needs hipcc, gfx950). "
+            "pointdsc_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # missing HIP runtime etc.
+        raise PointDSCLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PointDSCLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pdsc_version() != 1:
+        raise PointDSCLibraryError(f"unexpected library version {lib.pdsc_version()}")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().pdsc_last_error().decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (status {rc}): {last_error()}")

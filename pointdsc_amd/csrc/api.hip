@@ -1,0 +1,237 @@
+// Host side of libpointdsc_hip.so: error plumbing, packed-weight layout, workspace layout and the
+// whole-path orchestrator pdsc_forward_testing (reference PointDSC.forward in testing mode,
+// models/PointDSC.py:128-197).  Pure HIP runtime -- no torch types cross this boundary.  Every stage is
+// enqueued on the caller's stream with no host synchronisation, so one forward is hipGraph-capturable.
+#include <stdarg.h>
+#include <string.h>
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return PDSC_ERR_LAUNCH;
+    }
+    return PDSC_OK;
+}
+
+static bool config_ok(const pdsc_config* c) {
+    if (!c) { set_error("pdsc_config is null"); return false; }
+    if (c->num_channels != PDSC_CHANNELS) { set_error("num_channels=%d (only %d supported)", c->num_channels, PDSC_CHANNELS); return false; }
+    if (c->in_dim < 1 || c->in_dim > 8) { set_error("in_dim=%d must be in [1,8]", c->in_dim); return false; }
+    if (c->num_layers < 0 || c->num_layers > 64) { set_error("num_layers=%d", c->num_layers); return false; }
+    if (c->num_iterations < 0 || c->num_iterations > PDSC_MAX_POWER_ITERS) { set_error("num_iterations=%d", c->num_iterations); return false; }
+    if (c->k < 1 || c->k > PDSC_MAX_K) { set_error("k=%d must be in [1,%d]", c->k, PDSC_MAX_K); return false; }
+    if (c->refine_iters < 0) { set_error("refine_iters=%d", c->refine_iters); return false; }
+    return true;
+}
+
+static long long section_floats(int section) {
+    const long long C = PDSC_CHANNELS, H = C / 2;
+    switch (section) {
+        case PDSC_W_LAYER0_W: return C * 8;
+        case PDSC_W_LAYER0_B: return C;
+        case PDSC_W_PCN_W: return C * C;
+        case PDSC_W_PCN_B: return C;
+        case PDSC_W_QKV_W: return 3 * C * C;
+        case PDSC_W_QKV_B: return 3 * C;
+        case PDSC_W_FC1_W: return H * C;
+        case PDSC_W_FC1_B: return H;
+        case PDSC_W_FC2_W: return H * H;
+        case PDSC_W_FC2_B: return H;
+        case PDSC_W_FC3_W: return C * H;
+        case PDSC_W_FC3_B: return C;
+        case PDSC_W_CLS1_W: return 32 * C;
+        case PDSC_W_CLS1_B: return 32;
+        case PDSC_W_CLS2_W: return 32 * 32;
+        case PDSC_W_CLS2_B: return 32;
+        case PDSC_W_CLS3_W: return 32;
+        case PDSC_W_CLS3_B: return 4;   // 1 used, padded to keep every section 16-byte aligned
+        case PDSC_W_SIGMA: return 4;
+        case PDSC_W_SIGMA_SPAT: return 4;
+    }
+    return -1;
+}
+static bool per_layer(int section) { return section >= PDSC_W_PCN_W && section <= PDSC_W_FC3_B; }
+
+static long long layer_block_floats() {
+    long long n = 0;
+    for (int s = PDSC_W_PCN_W; s <= PDSC_W_FC3_B; ++s) n += section_floats(s);
+    return n;
+}
+
+static long long wpack_offset(const pdsc_config* c, int section, int layer) {
+    if (section < 0 || section >= PDSC_W_NUM_SECTIONS) return -1;
+    long long off = 0;
+    if (section <= PDSC_W_LAYER0_B) {
+        for (int s = 0; s < section; ++s) off += section_floats(s);
+        return off;
+    }
+    off = section_floats(PDSC_W_LAYER0_W) + section_floats(PDSC_W_LAYER0_B);
+    if (per_layer(section)) {
+        if (layer < 0 || layer >= c->num_layers) return -1;
+        off += (long long)layer * layer_block_floats();
+        for (int s = PDSC_W_PCN_W; s < section; ++s) off += section_floats(s);
+        return off;
+    }
+    off += (long long)c->num_layers * layer_block_floats();
+    for (int s = PDSC_W_CLS1_W; s < section; ++s) off += section_floats(s);
+    return off;
+}
+
+// ---- workspace layout --------------------------------------------------------------------------
+struct WsEntry { const char* name; size_t bytes; size_t offset; };
+struct WsLayout {
+    WsEntry e[32];
+    int n = 0;
+    size_t total = 0;
+    void add(const char* name, size_t bytes) {
+        e[n].name = name; e[n].bytes = bytes; e[n].offset = total;
+        total += (size_t)round_up((long long)bytes, 256);
+        ++n;
+    }
+    long long find(const char* name) const {
+        for (int i = 0; i < n; ++i) if (strcmp(e[i].name, name) == 0) return (long long)e[i].offset;
+        return -1;
+    }
+};
+
+static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
+    WsLayout L;
+    const size_t M = (size_t)bs * N, C = PDSC_CHANNELS, f = sizeof(float);
+    const size_t ld = (size_t)pdsc_compat_ld(N);
+    const int k = c->k < N - 1 ? c->k : N - 1;
+    const int iters = c->num_iterations > 0 ? c->num_iterations : 1;
+    L.add("compat", (size_t)bs * N * ld * f);
+    L.add("featA", M * C * f);
+    L.add("featB", M * C * f);
+    L.add("qkv", M * 3 * C * f);
+    L.add("msg", M * C * f);
+    L.add("t64a", M * (C / 2) * f);
+    L.add("t64b", M * (C / 2) * f);
+    L.add("att_scratch", pdsc_attention_scratch_bytes(bs, N, 0));
+    L.add("normed", M * C * f);
+    L.add("h1", M * 32 * f);
+    L.add("h2", M * 32 * f);
+    L.add("conf", M * f);
+    L.add("keys", M * f);
+    L.add("seeds", (size_t)bs * S * sizeof(int));
+    L.add("knn_dist", (size_t)bs * S * ld * f);
+    L.add("knn_idx", (size_t)bs * S * (k > 0 ? k : 1) * sizeof(int));
+    L.add("eig_iters", (size_t)bs * S * iters * PDSC_MAX_K * f);
+    L.add("conv_mask", (size_t)bs * sizeof(unsigned int));
+    L.add("seed_trans", (size_t)bs * S * 16 * f);
+    L.add("seed_w", (size_t)bs * S * (k > 0 ? k : 1) * f);
+    L.add("counts", (size_t)bs * S * sizeof(int));
+    L.add("best", (size_t)bs * sizeof(int));
+    L.add("initial_trans", (size_t)bs * 16 * f);
+    L.add("solves", (size_t)bs * sizeof(int));
+    return L;
+}
+
+}  // namespace pdsc
+
+using namespace pdsc;
+
+extern "C" int pdsc_version(void) { return PDSC_VERSION; }
+extern "C" const char* pdsc_last_error(void) { return g_err; }
+
+extern "C" long long pdsc_wpack_floats(const pdsc_config* cfg) {
+    if (!config_ok(cfg)) return -1;
+    return wpack_offset(cfg, PDSC_W_SIGMA_SPAT, 0) + section_floats(PDSC_W_SIGMA_SPAT);
+}
+extern "C" long long pdsc_wpack_offset(const pdsc_config* cfg, int section, int layer) {
+    if (!config_ok(cfg)) return -1;
+    return wpack_offset(cfg, section, layer);
+}
+
+extern "C" size_t pdsc_workspace_bytes(const pdsc_config* cfg, int bs, int N, int num_seeds) {
+    if (!config_ok(cfg) || bs <= 0 || N <= 1 || num_seeds <= 0) return 0;
+    return make_layout(cfg, bs, N, num_seeds).total;
+}
+extern "C" long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name) {
+    if (!config_ok(cfg) || bs <= 0 || N <= 1 || num_seeds <= 0 || !name) return -1;
+    return make_layout(cfg, bs, N, num_seeds).find(name);
+}
+
+#define PDSC_TRY(call)                 \
+    do {                               \
+        const int rc__ = (call);       \
+        if (rc__ != PDSC_OK) return rc__; \
+    } while (0)
+
+extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const float* corr_pos,
+                                    const float* src, const float* tgt, int bs, int N, int num_seeds,
+                                    float* final_trans, float* final_labels, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    if (!config_ok(cfg)) return PDSC_ERR_ARG;
+    PDSC_REQUIRE(wpack && corr_pos && src && tgt && final_trans && final_labels && workspace,
+                 "pdsc_forward_testing: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 1, "pdsc_forward_testing: bs=%d N=%d", bs, N);
+    PDSC_REQUIRE(num_seeds >= 1 && num_seeds <= N,
+                 "pdsc_forward_testing: num_seeds=%d (int(N*ratio) must be >= 1; the reference fails on an empty seed set)",
+                 num_seeds);
+    const WsLayout L = make_layout(cfg, bs, N, num_seeds);
+    if (workspace_bytes < L.total) {
+        set_error("pdsc_forward_testing: workspace %zu < %zu bytes", workspace_bytes, L.total);
+        return PDSC_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    auto F = [&](const char* n) { return (float*)(ws + L.find(n)); };
+    auto I = [&](const char* n) { return (int*)(ws + L.find(n)); };
+    auto W = [&](int section, int layer) { return wpack + wpack_offset(cfg, section, layer); };
+
+    const int C = PDSC_CHANNELS, M = bs * N, S = num_seeds;
+    const int k = cfg->k < N - 1 ? cfg->k : N - 1;
+    const long long ld = pdsc_compat_ld(N);
+    float *compat = F("compat"), *featA = F("featA"), *featB = F("featB"), *qkv = F("qkv"), *msg = F("msg");
+    float *t64a = F("t64a"), *t64b = F("t64b"), *normed = F("normed"), *h1 = F("h1"), *h2 = F("h2");
+    float *conf = F("conf"), *keys = F("keys"), *knn_dist = F("knn_dist"), *eig = F("eig_iters");
+    float *seed_trans = F("seed_trans"), *seed_w = F("seed_w"), *initial = F("initial_trans");
+    int *seeds = I("seeds"), *knn_idx = I("knn_idx"), *counts = I("counts"), *best = I("best"), *solves = I("solves");
+    unsigned int* conv_mask = (unsigned int*)(ws + L.find("conv_mask"));
+    void* att_scratch = ws + L.find("att_scratch");
+    const size_t att_bytes = pdsc_attention_scratch_bytes(bs, N, 0);
+
+    // Step 1 (models/PointDSC.py:150-155): compat, then the SCNonlocal encoder
+    PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
+    PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
+    for (int i = 0; i < cfg->num_layers; ++i) {
+        PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_PCN_W, i), W(PDSC_W_PCN_B, i), nullptr, 0, featB, C, M, C, C, 1, stream));
+        PDSC_TRY(pdsc_linear(featB, C, W(PDSC_W_QKV_W, i), W(PDSC_W_QKV_B, i), nullptr, 0, qkv, 3 * C, M, C, 3 * C, 0, stream));
+        PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+        PDSC_TRY(pdsc_linear(msg, C, W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), nullptr, 0, t64a, C / 2, M, C, C / 2, 1, stream));
+        PDSC_TRY(pdsc_linear(t64a, C / 2, W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i), nullptr, 0, t64b, C / 2, M, C / 2, C / 2, 1, stream));
+        PDSC_TRY(pdsc_linear(t64b, C / 2, W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i), featB, C, featA, C, M, C / 2, C, 0, stream));
+    }
+    // Step 2.1 (:156,:171,:174): normalise, confidence head, NMS seeds
+    PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), nullptr, 0, h1, 32, M, C, 32, 1, stream));
+    PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
+    PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
+    PDSC_TRY(pdsc_nms_keys(src, conf, cfg->nms_radius, keys, bs, N, stream));
+    PDSC_TRY(pdsc_rank_select(keys, seeds, bs, N, S, stream));
+    // Step 3 & 4 (:182 -> :234-336): per-seed hypotheses, scoring, best
+    PDSC_TRY(pdsc_knn_seeds(normed, seeds, knn_dist, knn_idx, bs, N, S, k, stream));
+    PDSC_TRY(pdsc_seed_power_iteration(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig,
+                                       conv_mask, nullptr, bs, N, S, k, cfg->num_iterations, stream));
+    PDSC_TRY(pdsc_seed_transforms(src, tgt, knn_idx, eig, conv_mask, seed_trans, seed_w, bs, N, S, k,
+                                  cfg->num_iterations, stream));
+    PDSC_TRY(pdsc_score_hypotheses(seed_trans, src, tgt, cfg->inlier_threshold, counts, bs, N, S, stream));
+    PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S,
+                              stream));
+    // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
+    PDSC_TRY(pdsc_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N,
+                                  stream));
+    return PDSC_OK;
+}

@@ -1,0 +1,86 @@
+// a-1: N x N spatial-consistency matrix build (reference models/PointDSC.py:150-153).
+//
+// HBM-write bound: 4*N*ld bytes out, 24*N bytes in.  One workgroup produces a 64-row x 256-column tile;
+// every lane owns 4 consecutive columns (their 8 keypoints live in registers for the whole tile) and walks
+// 16 rows whose keypoints are broadcast from LDS, so each store instruction is one fully coalesced 1 KiB
+// row segment (float4 per lane).  Arithmetic is the reference's, bit for bit: the fma-chained norm of
+// torch.norm, an IEEE division by sigma^2 and the clamp.
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+constexpr int CT_ROWS = 64;    // rows per workgroup tile
+constexpr int CT_COLS = 256;   // columns per workgroup tile (64 lanes x float4)
+
+template <bool WRITE_DIST>
+__global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                     const float* __restrict__ sigma_spat,
+                                                     float* __restrict__ compat, float* __restrict__ src_dist,
+                                                     long long ld, int N) {
+    __shared__ float rows_s[CT_ROWS][8];   // sx sy sz - tx ty tz -
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * CT_ROWS;
+    const int j0 = blockIdx.x * CT_COLS;
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    const int t = threadIdx.x;
+    if (t < CT_ROWS) {
+        const int i = min(i0 + t, N - 1);
+        rows_s[t][0] = srcb[i * 3 + 0]; rows_s[t][1] = srcb[i * 3 + 1]; rows_s[t][2] = srcb[i * 3 + 2];
+        rows_s[t][4] = tgtb[i * 3 + 0]; rows_s[t][5] = tgtb[i * 3 + 1]; rows_s[t][6] = tgtb[i * 3 + 2];
+    }
+    const int lane = t & 63, wave = t >> 6;
+    const int jc = j0 + lane * 4;
+    float sx[4], sy[4], sz[4], tx[4], ty[4], tz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = min(jc + c, N - 1);
+        sx[c] = srcb[j * 3 + 0]; sy[c] = srcb[j * 3 + 1]; sz[c] = srcb[j * 3 + 2];
+        tx[c] = tgtb[j * 3 + 0]; ty[c] = tgtb[j * 3 + 1]; tz[c] = tgtb[j * 3 + 2];
+    }
+    const float sg = sigma_spat[0];
+    const float s2 = sg * sg;                        // `self.sigma_spat ** 2` in fp32
+    __syncthreads();
+    if (jc >= ld) return;
+    float* outb = compat + (size_t)b * N * ld;
+    float* distb = WRITE_DIST ? src_dist + (size_t)b * N * ld : nullptr;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int il = wave * 16 + r;
+        const int i = i0 + il;
+        if (i >= N) break;
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(&rows_s[il][0]);
+        const f32x4 pt = *reinterpret_cast<const f32x4*>(&rows_s[il][4]);
+        f32x4 o, dd;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ds = norm3(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
+            const float dt = norm3(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
+            const float df = ds - dt;
+            const float v = fmaxf(1.0f - (df * df) / s2, 0.0f);
+            const bool valid = (jc + c) < N;
+            o[c] = valid ? v : 0.0f;
+            dd[c] = valid ? ds : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(outb + (size_t)i * ld + jc) = o;
+        if (WRITE_DIST) *reinterpret_cast<f32x4*>(distb + (size_t)i * ld + jc) = dd;
+    }
+}
+
+}  // namespace pdsc
+
+extern "C" long long pdsc_compat_ld(int N) { return N <= 0 ? -1 : pdsc::round_up(N, 64); }
+
+extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const float* sigma_spat, float* compat,
+                                   float* src_dist, long long ld, int bs, int N, void* stream) {
+    PDSC_REQUIRE(src && tgt && sigma_spat && compat, "pdsc_spatial_compat: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_spatial_compat: bs=%d N=%d", bs, N);
+    PDSC_REQUIRE(ld >= N && ld % 4 == 0, "pdsc_spatial_compat: ld=%lld must be >= N and a multiple of 4", ld);
+    dim3 grid(pdsc::ceil_div((int)ld, pdsc::CT_COLS), pdsc::ceil_div(N, pdsc::CT_ROWS), bs);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dist)
+        hipLaunchKernelGGL(pdsc::compat_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, src_dist, ld, N);
+    else
+        hipLaunchKernelGGL(pdsc::compat_kernel<false>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+    return pdsc::check_launch("pdsc_spatial_compat");
+}

@@ -1,0 +1,182 @@
+// a-2: point-wise layers = NT GEMMs  Y[M][Nout] = act(X[M][K] . W[Nout][K]^T + b) (+R), exact fp32 on
+// v_mfma_f32_32x32x2_f32 (reference: every Conv1d(k=1)[+BN][+ReLU], models/PointDSC.py:12-23,54-61,107-113).
+// The same kernel (MODE 1, gathered rows) produces the seed rows of the kNN distance matrix
+// 2 - 2 <x_s, x_j> (reference models/common.py:58-60).
+//
+// Workgroup = 4 waves, tile 64 rows x (64*NT) columns, whole K (<=128) staged once in LDS with a +4-float
+// row pad (16 distinct 16-B bank slots for the 16 rows of a ds_read_b128 lane group).  MFMA operand
+// convention used throughout this library: k-slot (step t = 4q+e, half h = lane>>5) <-> channel 8q+4h+e,
+// so one ds_read_b128 per lane feeds 4 MFMA steps for both A and B.
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+constexpr int LIN_BM = 64;
+
+struct LinearArgs {
+    const float* X; long long ldx; long long x_batch;       // X rows, batch stride (floats)
+    const int* row_idx; long long idx_batch;                 // optional gather of X rows
+    const float* W; long long w_batch;                       // [Nout][K]
+    const float* bias;
+    const float* R; long long ldr;
+    float* Y; long long ldy; long long y_batch;
+    int M, K, Nout, relu;
+};
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = a.K, KP = K + 4, K4 = K >> 2;
+    float* Xs = lds;                       // [64][KP]
+    float* Ws = lds + LIN_BM * KP;         // [64*NT][KP]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * LIN_BM;
+    const int n0 = blockIdx.x * (64 * NT);
+    const float* X = a.X + (size_t)b * a.x_batch;
+    const float* W = a.W + (size_t)b * a.w_batch;
+    const int* ridx = a.row_idx ? a.row_idx + (size_t)b * a.idx_batch : nullptr;
+
+    for (int idx = t; idx < LIN_BM * K4; idx += 256) {
+        const int row = idx / K4, c = idx - row * K4;
+        int m = m0 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < a.M) {
+            if (ridx) m = ridx[m];
+            v = *reinterpret_cast<const f32x4*>(X + (size_t)m * a.ldx + c * 4);
+        }
+        *reinterpret_cast<f32x4*>(Xs + row * KP + c * 4) = v;
+    }
+    for (int idx = t; idx < 64 * NT * K4; idx += 256) {
+        const int row = idx / K4, c = idx - row * K4;
+        const int n = n0 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < a.Nout) v = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + c * 4);
+        *reinterpret_cast<f32x4*>(Ws + row * KP + c * 4) = v;
+    }
+    __syncthreads();
+
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    const float* xa = Xs + (wm * 32 + l31) * KP + 4 * h;
+    const float* wb = Ws + ((wn * NT) * 32 + l31) * KP + 4 * h;
+    const int nq = K >> 3;
+    for (int q = 0; q < nq; ++q) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(xa + 8 * q);
+        f32x4 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(wb + nt * 32 * KP + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[nt][e], acc[nt], 0, 0, 0);
+    }
+
+    float* Y = a.Y + (size_t)b * a.y_batch;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + l31;
+        if (n >= a.Nout) continue;
+        const float bval = (MODE == 0 && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * 32 + i;
+            if (m >= a.M) continue;
+            float v = acc[nt][r];
+            if (MODE == 0) {
+                v = v + bval;
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.R) v = a.R[(size_t)m * a.ldr + n] + v;
+            } else {
+                v = 2.0f - 2.0f * v;       // == reference `2 - 2*matmul` (one rounding)
+            }
+            Y[(size_t)m * a.ldy + n] = v;
+        }
+    }
+}
+
+// encoder.layer0: in_dim (<=8) inputs -> C channels, pure VALU (K=6 is too thin for MFMA).
+__global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ corr, int in_dim,
+                                                     const float* __restrict__ W0, const float* __restrict__ b0,
+                                                     float* __restrict__ feat, int M) {
+    // thread -> (row, 4 consecutive channels); 32 threads per row
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid >> 5;
+    const int c4 = (int)(gid & 31) * 4;
+    if (row >= M) return;
+    float x[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) x[d] = d < in_dim ? corr[row * in_dim + d] : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* w = W0 + (c4 + c) * 8;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s = fmaf(x[d], w[d], s);
+        o[c] = s + b0[c4 + c];
+    }
+    *reinterpret_cast<f32x4*>(feat + row * PDSC_CHANNELS + c4) = o;
+}
+
+static size_t linear_lds_bytes(int NT, int K) { return (size_t)(LIN_BM + 64 * NT) * (K + 4) * sizeof(float); }
+
+template <int NT, int MODE>
+static int launch_linear(const LinearArgs& a, int batches, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<NT, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)linear_lds_bytes(NT, 128));
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(a.Nout, 64 * NT), ceil_div(a.M, LIN_BM), batches);
+    hipLaunchKernelGGL((linear_kernel<NT, MODE>), grid, dim3(256), linear_lds_bytes(NT, a.K), st, a);
+    return check_launch("pdsc_linear");
+}
+
+int knn_dist_rows(const float* normed, const int* seeds, float* dist, long long ldd, int bs, int N, int S,
+                  hipStream_t st) {
+    LinearArgs a{};
+    a.X = normed; a.ldx = PDSC_CHANNELS; a.x_batch = (long long)N * PDSC_CHANNELS;
+    a.row_idx = seeds; a.idx_batch = S;
+    a.W = normed; a.w_batch = (long long)N * PDSC_CHANNELS;
+    a.Y = dist; a.ldy = ldd; a.y_batch = (long long)S * ldd;
+    a.M = S; a.K = PDSC_CHANNELS; a.Nout = N; a.relu = 0;
+    return launch_linear<2, 1>(a, bs, st);
+}
+
+}  // namespace pdsc
+
+extern "C" int pdsc_linear(const float* X, long long ldx, const float* W, const float* bias, const float* residual,
+                           long long ldr, float* Y, long long ldy, int M, int K, int Nout, int relu, void* stream) {
+    PDSC_REQUIRE(X && W && Y, "pdsc_linear: null pointer");
+    PDSC_REQUIRE(M > 0 && Nout > 0, "pdsc_linear: M=%d Nout=%d", M, Nout);
+    PDSC_REQUIRE(K >= 8 && K <= 128 && K % 8 == 0, "pdsc_linear: K=%d must be a multiple of 8 in [8,128]", K);
+    PDSC_REQUIRE(ldx >= K && ldx % 4 == 0, "pdsc_linear: ldx=%lld", ldx);
+    PDSC_REQUIRE(ldy >= Nout, "pdsc_linear: ldy=%lld < Nout", ldy);
+    PDSC_REQUIRE(!residual || ldr >= Nout, "pdsc_linear: ldr=%lld < Nout", ldr);
+    pdsc::LinearArgs a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.bias = bias; a.R = residual; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    a.M = M; a.K = K; a.Nout = Nout; a.relu = relu;
+    hipStream_t st = (hipStream_t)stream;
+    if (Nout > 64) return pdsc::launch_linear<2, 0>(a, 1, st);
+    return pdsc::launch_linear<1, 0>(a, 1, st);
+}
+
+extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat, int M,
+                           void* stream) {
+    PDSC_REQUIRE(corr_pos && W0 && b0 && feat, "pdsc_layer0: null pointer");
+    PDSC_REQUIRE(in_dim >= 1 && in_dim <= 8 && M > 0, "pdsc_layer0: in_dim=%d M=%d", in_dim, M);
+    const long long threads = (long long)M * 32;
+    hipLaunchKernelGGL(pdsc::layer0_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       corr_pos, in_dim, W0, b0, feat, M);
+    return pdsc::check_launch("pdsc_layer0");
+}

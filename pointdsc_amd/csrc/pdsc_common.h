@@ -1,0 +1,188 @@
+// Shared host/device helpers for libpointdsc_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/pointdsc_hip.h"
+
+#define PDSC_WAVE 64
+
+namespace pdsc {
+
+// ---- host-side error plumbing ---------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PDSC_REQUIRE(cond, ...)                       \
+    do {                                              \
+        if (!(cond)) {                                \
+            pdsc::set_error(__VA_ARGS__);             \
+            return PDSC_ERR_ARG;                      \
+        }                                             \
+    } while (0)
+
+static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers ----------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Euclidean norm of a 3-vector with torch's CPU/GPU reduction order: sqrt(fma(z,z,fma(y,y,x*x))).
+// (oracle/pointdsc_oracle.py:pairwise_dist documents the measurement.)  sqrtf is IEEE-correct
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Block-wide sum of NV floats per thread; result valid in every thread.  `red` needs NV*nwaves floats.
+template <int NV, int NWAVES>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();  // protect `red` from the previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) s += red[w * NV + i];
+        v[i] = s;
+    }
+}
+
+// ---- Kabsch from a 3x3 weighted covariance -----------------------------------------------------
+// reference models/common.py:35-42: U,S,V = svd(H); R = V diag(1,1,det(V U^T)) U^T; t = cB - R cA.
+// Computed as: eigen-decomposition of H^T H (cyclic Jacobi, fp64) -> V, sigma; u_i = H v_i / sigma_i for the
+// two leading directions, u_3 = u_1 x u_2 (so det U = +1), which yields the same R whenever rank(H) >= 2
+// (DESIGN.md "3x3 SVD").  Input H row-major fp32, centroids fp32; output row-major 4x4 fp32.
+__device__ inline void kabsch_from_covariance(const float* H32, const float* cA, const float* cB, float* T) {
+    double H[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) H[i][j] = (double)H32[i * 3 + j];
+    // A = H^T H (symmetric)
+    double A[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][j] = H[0][i] * H[0][j] + H[1][i] * H[1][j] + H[2][i] * H[2][j];
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-17 * diag) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = (pq == 2) ? 1 : 0;
+            const int q = (pq == 0) ? 1 : 2;
+            const double apq = A[p][q];
+            if (fabs(apq) < 1e-300) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {  // A <- A J
+                const double arp = A[r][p], arq = A[r][q];
+                A[r][p] = c * arp - s * arq;
+                A[r][q] = s * arp + c * arq;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {  // A <- J^T A
+                const double apr = A[p][r], aqr = A[q][r];
+                A[p][r] = c * apr - s * aqr;
+                A[q][r] = s * apr + c * aqr;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {  // V <- V J
+                const double vrp = V[r][p], vrq = V[r][q];
+                V[r][p] = c * vrp - s * vrq;
+                V[r][q] = s * vrp + c * vrq;
+            }
+        }
+    }
+    // order eigenvalues descending: i0 >= i1 >= i2
+    int i0 = 0, i1 = 1, i2 = 2;
+    double e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
+    if (e0 < e1) { double t = e0; e0 = e1; e1 = t; int ti = i0; i0 = i1; i1 = ti; }
+    if (e0 < e2) { double t = e0; e0 = e2; e2 = t; int ti = i0; i0 = i2; i2 = ti; }
+    if (e1 < e2) { double t = e1; e1 = e2; e2 = t; int ti = i1; i1 = i2; i2 = ti; }
+    (void)i2;
+    // select columns with compares (runtime-indexed local arrays would go to scratch memory)
+#define PDSC_SEL3(r, i) ((i) == 0 ? V[r][0] : ((i) == 1 ? V[r][1] : V[r][2]))
+    double v1[3] = {PDSC_SEL3(0, i0), PDSC_SEL3(1, i0), PDSC_SEL3(2, i0)};
+    double v2[3] = {PDSC_SEL3(0, i1), PDSC_SEL3(1, i1), PDSC_SEL3(2, i1)};
+#undef PDSC_SEL3
+    // v3 = v1 x v2 makes (v1,v2,v3) right-handed; the sign of v3 is irrelevant below because it enters
+    // R only through d * v3 u3^T with d = det(V) det(U) and u3 = u1 x u2 (det U = +1).
+    double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    // u1 = H v1 / |H v1|
+    double u1[3], u2[3], u3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u1[i] = H[i][0] * v1[0] + H[i][1] * v1[1] + H[i][2] * v1[2];
+    double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (n1 > 1e-150) { u1[0] /= n1; u1[1] /= n1; u1[2] /= n1; }
+    else { u1[0] = 1; u1[1] = 0; u1[2] = 0; }              // H == 0: any basis (R not defined by H)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u2[i] = H[i][0] * v2[0] + H[i][1] * v2[1] + H[i][2] * v2[2];
+    double dp = u2[0] * u1[0] + u2[1] * u1[1] + u2[2] * u1[2];
+    u2[0] -= dp * u1[0]; u2[1] -= dp * u1[1]; u2[2] -= dp * u1[2];
+    double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    if (n2 > 1e-12 * (n1 > 1e-150 ? n1 : 1.0) && n2 > 1e-150) { u2[0] /= n2; u2[1] /= n2; u2[2] /= n2; }
+    else {  // rank <= 1: pick any unit vector orthogonal to u1
+        int m = (fabs(u1[0]) <= fabs(u1[1]) && fabs(u1[0]) <= fabs(u1[2])) ? 0 : (fabs(u1[1]) <= fabs(u1[2]) ? 1 : 2);
+        const double e[3] = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
+        double d2 = e[0] * u1[0] + e[1] * u1[1] + e[2] * u1[2];
+        u2[0] = e[0] - d2 * u1[0]; u2[1] = e[1] - d2 * u1[1]; u2[2] = e[2] - d2 * u1[2];
+        n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+        u2[0] /= n2; u2[1] /= n2; u2[2] /= n2;
+    }
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+    u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+    u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    // with v3 = v1 x v2 and u3 = u1 x u2 both bases are right-handed: det(V) det(U) = +1, so
+    // R = v1 u1^T + v2 u2^T + v3 u3^T is the proper rotation the reference's det-correction selects.
+    double R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = v1[i] * u1[j] + v2[i] * u2[j] + v3[i] * u3[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double ti = (double)cB[i] - (R[i][0] * (double)cA[0] + R[i][1] * (double)cA[1] + R[i][2] * (double)cA[2]);
+        T[i * 4 + 0] = (float)R[i][0];
+        T[i * 4 + 1] = (float)R[i][1];
+        T[i * 4 + 2] = (float)R[i][2];
+        T[i * 4 + 3] = (float)ti;
+    }
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+}  // namespace pdsc

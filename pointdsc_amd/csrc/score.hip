@@ -1,0 +1,187 @@
+// a-10, a-11: hypothesis scoring / selection and the on-device post-refinement loop.
+//   reference: models/PointDSC.py:325-335 (score S hypotheses on N correspondences, argmax, labels)
+//              models/PointDSC.py:403-438 (post_refinement), utils/SE3.py:43-57 (transform)
+// The reference materialises [S,N,3] predictions and [S,N] residuals; here every (seed, point) residual is
+// formed in registers and only S integer counts leave the chip.  Bound: VALU/latency (30*S*N flop, 24*N+64*S
+// bytes); reported as time only.
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+constexpr int SC_SEEDS = 8;       // hypotheses per workgroup
+constexpr int SC_POINTS = 2048;   // points per workgroup (8 per thread)
+
+// residual of one correspondence under one transform, in the reference's rounding order:
+// pred = R p + t as a length-3 dot (fma chain) plus t, then torch.norm's fma chain.
+__device__ __forceinline__ float residual(const float* __restrict__ T, float px, float py, float pz, float qx, float qy,
+                                          float qz) {
+    const float x = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
+    const float y = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
+    const float z = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
+    return norm3(x - qx, y - qy, z - qz);
+}
+
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ seed_trans, const float* __restrict__ src,
+                                                    const float* __restrict__ tgt, float thr, int* __restrict__ counts,
+                                                    int N, int S) {
+    __shared__ float Ts[SC_SEEDS][12];
+    const int t = threadIdx.x, lane = t & 63;
+    const int s0 = blockIdx.x * SC_SEEDS, p0 = blockIdx.y * SC_POINTS, b = blockIdx.z;
+    if (t < SC_SEEDS * 12) {
+        const int sl = t / 12, e = t % 12;
+        const int s = min(s0 + sl, S - 1);
+        Ts[sl][e] = seed_trans[((size_t)b * S + s) * 16 + e];
+    }
+    __syncthreads();
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    int cnt[SC_SEEDS];
+#pragma unroll
+    for (int s = 0; s < SC_SEEDS; ++s) cnt[s] = 0;
+    for (int i = p0 + t; i < min(p0 + SC_POINTS, N); i += 256) {
+        const float px = srcb[i * 3], py = srcb[i * 3 + 1], pz = srcb[i * 3 + 2];
+        const float qx = tgtb[i * 3], qy = tgtb[i * 3 + 1], qz = tgtb[i * 3 + 2];
+#pragma unroll
+        for (int s = 0; s < SC_SEEDS; ++s) cnt[s] += residual(Ts[s], px, py, pz, qx, qy, qz) < thr;
+    }
+#pragma unroll
+    for (int s = 0; s < SC_SEEDS; ++s) {
+        const int c = wave_sum(cnt[s]);
+        if (lane == 0 && c > 0 && s0 + s < S) atomicAdd(counts + (size_t)b * S + s0 + s, c);
+    }
+}
+
+// first argmax over the S counts, emit the winning transform and its inlier labels
+__global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict__ counts, const float* __restrict__ seed_trans,
+                                                           const float* __restrict__ src, const float* __restrict__ tgt,
+                                                           float thr, int* __restrict__ best_out,
+                                                           float* __restrict__ initial_trans, float* __restrict__ labels,
+                                                           int N, int S) {
+    __shared__ unsigned long long wbest[16];
+    __shared__ float Tb[16];
+    __shared__ int best_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+    // key = count << 32 | (0xFFFFFFFF - index): max key == highest count, lowest index among equals
+    unsigned long long key = 0;
+    for (int s = t; s < S; s += 1024) {
+        const unsigned long long kk = ((unsigned long long)(unsigned)counts[(size_t)b * S + s] << 32) | (0xFFFFFFFFu - (unsigned)s);
+        key = kk > key ? kk : key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+    }
+    if (lane == 0) wbest[wave] = key;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long k = wbest[0];
+        for (int w = 1; w < 16; ++w) k = wbest[w] > k ? wbest[w] : k;
+        best_s = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));
+        if (best_out) best_out[b] = best_s;
+    }
+    __syncthreads();
+    if (t < 16) {
+        const float v = seed_trans[((size_t)b * S + best_s) * 16 + t];
+        Tb[t] = v;
+        initial_trans[(size_t)b * 16 + t] = v;
+    }
+    __syncthreads();
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    for (int i = t; i < N; i += 1024) {
+        const float r = residual(Tb, srcb[i * 3], srcb[i * 3 + 1], srcb[i * 3 + 2], tgtb[i * 3], tgtb[i * 3 + 1], tgtb[i * 3 + 2]);
+        labels[(size_t)b * N + i] = r < thr ? 1.0f : 0.0f;
+    }
+}
+
+// post_refinement: one persistent 512-thread workgroup per pair runs the whole <=max_iters loop.
+__global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ initial_trans, const float* __restrict__ src,
+                                                      const float* __restrict__ tgt, float thr, int max_iters,
+                                                      float* __restrict__ final_trans, int* __restrict__ solves, int N) {
+    __shared__ float red[8 * 9];
+    __shared__ float Tc[16];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    if (t < 16) Tc[t] = initial_trans[(size_t)b * 16 + t];
+    __syncthreads();
+    int prev = 0, solved = 0;
+    for (int it = 0; it < max_iters; ++it) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // count, sum w, sum w*a (3), sum w*b (3)
+        for (int i = t; i < N; i += 512) {
+            const float px = srcb[i * 3], py = srcb[i * 3 + 1], pz = srcb[i * 3 + 2];
+            const float qx = tgtb[i * 3], qy = tgtb[i * 3 + 1], qz = tgtb[i * 3 + 2];
+            const float r = residual(Tc, px, py, pz, qx, qy, qz);
+            if (r < thr) {
+                const float q = r / thr;
+                const float w = 1.0f / (1.0f + q * q);             // models/PointDSC.py:435
+                acc[0] += 1.0f;
+                acc[1] += w;
+                acc[2] = fmaf(px, w, acc[2]); acc[3] = fmaf(py, w, acc[3]); acc[4] = fmaf(pz, w, acc[4]);
+                acc[5] = fmaf(qx, w, acc[5]); acc[6] = fmaf(qy, w, acc[6]); acc[7] = fmaf(qz, w, acc[7]);
+            }
+        }
+        block_sum<8, 8>(acc, red);
+        const int n_inl = (int)acc[0];                              // exact: counts < 2^24
+        if (n_inl == prev) break;                                   // abs(int(inlier_num - previous)) < 1
+        prev = n_inl;
+        const float den = acc[1] + 1e-6f;
+        const float cA[3] = {acc[2] / den, acc[3] / den, acc[4] / den};
+        const float cB[3] = {acc[5] / den, acc[6] / den, acc[7] / den};
+        float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = t; i < N; i += 512) {
+            const float px = srcb[i * 3], py = srcb[i * 3 + 1], pz = srcb[i * 3 + 2];
+            const float qx = tgtb[i * 3], qy = tgtb[i * 3 + 1], qz = tgtb[i * 3 + 2];
+            const float r = residual(Tc, px, py, pz, qx, qy, qz);
+            if (r < thr) {
+                const float q = r / thr;
+                const float w = 1.0f / (1.0f + q * q);
+                const float am[3] = {px - cA[0], py - cA[1], pz - cA[2]};
+                const float bm[3] = {qx - cB[0], qy - cB[1], qz - cB[2]};
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) H[rr * 3 + c] = fmaf(am[rr] * w, bm[c], H[rr * 3 + c]);
+            }
+        }
+        block_sum<9, 8>(H, red);
+        __syncthreads();                     // everyone has finished reading Tc for this iteration
+        if (t == 0) kabsch_from_covariance(H, cA, cB, Tc);
+        ++solved;
+        __syncthreads();
+    }
+    if (t < 16) final_trans[(size_t)b * 16 + t] = Tc[t];
+    if (t == 0 && solves) solves[b] = solved;
+}
+
+}  // namespace pdsc
+
+extern "C" int pdsc_score_hypotheses(const float* seed_trans, const float* src, const float* tgt, float thr, int* counts,
+                                     int bs, int N, int S, void* stream) {
+    PDSC_REQUIRE(seed_trans && src && tgt && counts, "pdsc_score_hypotheses: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_score_hypotheses: bs=%d N=%d S=%d", bs, N, S);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)bs * S, st) != hipSuccess) return pdsc::check_launch("memset");
+    dim3 grid(pdsc::ceil_div(S, pdsc::SC_SEEDS), pdsc::ceil_div(N, pdsc::SC_POINTS), bs);
+    hipLaunchKernelGGL(pdsc::score_kernel, grid, dim3(256), 0, st, seed_trans, src, tgt, thr, counts, N, S);
+    return pdsc::check_launch("pdsc_score_hypotheses");
+}
+
+extern "C" int pdsc_select_best(const int* counts, const float* seed_trans, const float* src, const float* tgt, float thr,
+                                int* best, float* initial_trans, float* labels, int bs, int N, int S, void* stream) {
+    PDSC_REQUIRE(counts && seed_trans && src && tgt && initial_trans && labels, "pdsc_select_best: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_select_best: bs=%d N=%d S=%d", bs, N, S);
+    hipLaunchKernelGGL(pdsc::select_best_kernel, dim3(bs), dim3(1024), 0, (hipStream_t)stream, counts, seed_trans, src, tgt,
+                       thr, best, initial_trans, labels, N, S);
+    return pdsc::check_launch("pdsc_select_best");
+}
+
+extern "C" int pdsc_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold,
+                                    int max_iters, float* final_trans, int* solves, int bs, int N, void* stream) {
+    PDSC_REQUIRE(initial_trans && src && tgt && final_trans, "pdsc_post_refinement: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && max_iters >= 0, "pdsc_post_refinement: bs=%d N=%d iters=%d", bs, N, max_iters);
+    hipLaunchKernelGGL(pdsc::refine_kernel, dim3(bs), dim3(512), 0, (hipStream_t)stream, initial_trans, src, tgt, threshold,
+                       max_iters, final_trans, solves, N);
+    return pdsc::check_launch("pdsc_post_refinement");
+}

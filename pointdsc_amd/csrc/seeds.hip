@@ -1,0 +1,196 @@
+// a-4 (tail), a-5, a-6: per-correspondence head, NMS seed selection, feature-space kNN of the seeds.
+//   reference: F.normalize + classification.4 (models/PointDSC.py:156,112,171)
+//              pick_seeds                     (models/PointDSC.py:199-217)
+//              knn + seed gather              (models/common.py:48-69, models/PointDSC.py:250-252)
+// All three are row-parallel N x N predicate / selection problems with no data reuse worth an LDS tile:
+// one wavefront per row, lanes stride the columns (coalesced), wave shuffles/ballots do the reductions.
+// Ordering rules (ties): equal NMS keys -> ascending index; equal kNN distances -> ascending index
+// (DESIGN.md "tie semantics"; torch.argsort / torch.topk leave both unspecified).
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+int knn_dist_rows(const float* normed, const int* seeds, float* dist, long long ldd, int bs, int N, int S,
+                  hipStream_t st);
+
+// ---- normalise + final classifier layer: one wave per row ----------------------------------------
+__global__ __launch_bounds__(256) void normalize_conf_kernel(const float* __restrict__ feat, const float* __restrict__ h2,
+                                                             const float* __restrict__ w3, const float* __restrict__ b3,
+                                                             float* __restrict__ normed, float* __restrict__ conf, int M) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float2 v = *reinterpret_cast<const float2*>(feat + row * PDSC_CHANNELS + lane * 2);
+    const float ss = wave_sum(fmaf(v.y, v.y, v.x * v.x));
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float2 o;
+    o.x = v.x / nrm;
+    o.y = v.y / nrm;
+    *reinterpret_cast<float2*>(normed + row * PDSC_CHANNELS + lane * 2) = o;
+    float p = lane < 32 ? h2[row * 32 + lane] * w3[lane] : 0.f;
+    p = wave_sum(p);
+    if (lane == 0) conf[row] = p + b3[0];
+}
+
+// ---- NMS keys: key[i] = conf[i] * all_j( conf[i] >= conf[j] || dist(i,j) >= R ) ---------------------
+__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ src, const float* __restrict__ conf,
+                                                       float radius, float* __restrict__ keys, int N) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float* s = src + (size_t)b * N * 3;
+    const float* c = conf + (size_t)b * N;
+    const float ci = c[i];
+    const float xi = s[i * 3], yi = s[i * 3 + 1], zi = s[i * 3 + 2];
+    bool ok = true;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < N) {
+            const float d = norm3(xi - s[j * 3], yi - s[j * 3 + 1], zi - s[j * 3 + 2]);
+            ok = ok && ((ci >= c[j]) || (d >= radius));
+        }
+        if (__any(!ok)) break;
+    }
+    const bool is_max = !__any(!ok);
+    if (lane == 0) keys[(size_t)b * N + i] = ci * (is_max ? 1.0f : 0.0f);   // -0.0 for suppressed negatives, like torch
+}
+
+// ---- stable descending rank by counting; seeds[rank] = index for rank < num_seeds -------------------
+__global__ __launch_bounds__(256) void rank_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds,
+                                                          int N, int num_seeds) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float* k = keys + (size_t)b * N;
+    const float ki = k[i];
+    int cnt = 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < N) {
+            const float kj = k[j];
+            cnt += (kj > ki) || (kj == ki && j < i);
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0 && cnt < num_seeds) seeds[(size_t)b * num_seeds + cnt] = i;
+}
+
+// ---- kNN selection: one workgroup per seed row, radix descent on (monotone(dist) << IDX_BITS | index) ---
+__device__ __forceinline__ unsigned int float_order_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending float order == ascending unsigned order
+}
+
+constexpr int KNN_THREADS = 256;
+
+__global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __restrict__ dist, long long ldd,
+                                                                 int* __restrict__ knn_idx, int N, int S, int k,
+                                                                 int idx_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds_u[];
+    unsigned int* keys = lds_u;                     // [N] monotone distance bits
+    __shared__ int wave_cnt[KNN_THREADS / 64];
+    __shared__ unsigned long long cand[PDSC_MAX_K + 1];
+    __shared__ int cand_n;
+    const int s = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const float* row = dist + ((size_t)b * S + s) * ldd;
+    for (int j = t; j < N; j += KNN_THREADS) keys[j] = float_order_bits(row[j]);
+    if (t == 0) cand_n = 0;
+    __syncthreads();
+
+    // find the (k+1)-th smallest composite value, most significant bit first
+    const int want = k + 1;
+    int remaining = want;
+    unsigned long long prefix = 0;
+    const int total_bits = 32 + idx_bits;
+    for (int bit = total_bits - 1; bit >= 0; --bit) {
+        const unsigned long long hi_mask = ~((2ULL << bit) - 1ULL);          // bits above `bit`
+        int c = 0;
+        for (int j = t; j < N; j += KNN_THREADS) {
+            const unsigned long long v = ((unsigned long long)keys[j] << idx_bits) | (unsigned)j;
+            c += ((v & hi_mask) == prefix) && (((v >> bit) & 1ULL) == 0ULL);
+        }
+        c = wave_sum(c);
+        __syncthreads();
+        if ((t & 63) == 0) wave_cnt[t >> 6] = c;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < KNN_THREADS / 64; ++w) tot += wave_cnt[w];
+        if (tot >= remaining) {
+            // target has a 0 here: keep prefix
+        } else {
+            remaining -= tot;
+            prefix |= (1ULL << bit);
+        }
+    }
+    // prefix == the (k+1)-th smallest composite; collect everything <= prefix (exactly k+1 values)
+    for (int j = t; j < N; j += KNN_THREADS) {
+        const unsigned long long v = ((unsigned long long)keys[j] << idx_bits) | (unsigned)j;
+        if (v <= prefix) {
+            const int slot = atomicAdd(&cand_n, 1);
+            if (slot <= PDSC_MAX_K) cand[slot] = v;
+        }
+    }
+    __syncthreads();
+    // rank the candidates (ascending) and drop rank 0 (the reference's `[:, :, 1:]`)
+    if (t < want) {
+        const unsigned long long mine = cand[t];
+        int rank = 0;
+        for (int u = 0; u < want; ++u) rank += cand[u] < mine;
+        if (rank >= 1) knn_idx[((size_t)b * S + s) * k + (rank - 1)] = (int)(mine & ((1ULL << idx_bits) - 1ULL));
+    }
+}
+
+}  // namespace pdsc
+
+extern "C" int pdsc_normalize_confidence(const float* feat, const float* h2, const float* w3, const float* b3,
+                                         float* normed, float* conf, int M, void* stream) {
+    PDSC_REQUIRE(feat && h2 && w3 && b3 && normed && conf, "pdsc_normalize_confidence: null pointer");
+    PDSC_REQUIRE(M > 0, "pdsc_normalize_confidence: M=%d", M);
+    hipLaunchKernelGGL(pdsc::normalize_conf_kernel, dim3(pdsc::ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream, feat, h2,
+                       w3, b3, normed, conf, M);
+    return pdsc::check_launch("pdsc_normalize_confidence");
+}
+
+extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, float* keys, int bs, int N, void* stream) {
+    PDSC_REQUIRE(src && conf && keys, "pdsc_nms_keys: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_nms_keys: bs=%d N=%d", bs, N);
+    hipLaunchKernelGGL(pdsc::nms_keys_kernel, dim3(pdsc::ceil_div(N, 4), bs), dim3(256), 0, (hipStream_t)stream, src, conf,
+                       radius, keys, N);
+    return pdsc::check_launch("pdsc_nms_keys");
+}
+
+extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream) {
+    PDSC_REQUIRE(keys && seeds, "pdsc_rank_select: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && num_seeds >= 0 && num_seeds <= N, "pdsc_rank_select: bs=%d N=%d S=%d", bs, N, num_seeds);
+    if (num_seeds == 0) return PDSC_OK;
+    hipLaunchKernelGGL(pdsc::rank_select_kernel, dim3(pdsc::ceil_div(N, 4), bs), dim3(256), 0, (hipStream_t)stream, keys,
+                       seeds, N, num_seeds);
+    return pdsc::check_launch("pdsc_rank_select");
+}
+
+extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
+                              int S, int k, void* stream) {
+    PDSC_REQUIRE(normed && seeds && dist_scratch && knn_idx, "pdsc_knn_seeds: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 1 && S > 0, "pdsc_knn_seeds: bs=%d N=%d S=%d", bs, N, S);
+    PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K && k <= N - 1, "pdsc_knn_seeds: k=%d (N=%d, max %d)", k, N, PDSC_MAX_K);
+    PDSC_REQUIRE((size_t)N * 4 <= 150 * 1024, "pdsc_knn_seeds: N=%d exceeds the single-workgroup LDS row (38400)", N);
+    hipStream_t st = (hipStream_t)stream;
+    const long long ldd = pdsc_compat_ld(N);
+    int rc = pdsc::knn_dist_rows(normed, seeds, dist_scratch, ldd, bs, N, S, st);
+    if (rc != PDSC_OK) return rc;
+    int idx_bits = 1;
+    while ((1 << idx_bits) < N) ++idx_bits;
+    const size_t lds_bytes = (size_t)N * sizeof(unsigned int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::knn_select_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(pdsc::knn_select_kernel, dim3(S, bs), dim3(pdsc::KNN_THREADS), lds_bytes, st, dist_scratch, ldd,
+                       knn_idx, N, S, k, idx_bits);
+    return pdsc::check_launch("pdsc_knn_seeds");
+}

@@ -1,0 +1,233 @@
+"""``PointDSC`` -- the reference's module boundary over the HIP hot path.
+
+Mirrors reference ``models/PointDSC.py``:
+  * constructor signature and defaults                               (:81-91)
+  * parameter / buffer tree, hence the 358-entry ``state_dict`` of the released snapshots
+    (``load_state_dict(torch.load(...), strict=False)`` works unchanged, evaluation/test_3DMatch.py:225)
+  * ``forward(data: dict) -> {'final_trans', 'final_labels', 'M'}``   (:128-197) in testing mode
+so the reference's callers (evaluation/test_3DMatch.py:53, demo_registration.py:117) only swap the import.
+
+The sub-modules below are weight containers only; the arithmetic runs in libpointdsc_hip.so through
+``pdsc_forward_testing`` (include/pointdsc_hip.h).  There is no CPU or eager-PyTorch fallback: inputs
+must be CUDA(ROCm) tensors and the library must be built, otherwise forward raises.
+
+Extension over the reference: testing mode accepts bs >= 1 (the reference asserts bs == 1,
+:210/:414); a batch is processed as bs independent pairs in the same kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_NUM_CHANNELS = 128
+
+
+def _conv(cin: int, cout: int) -> nn.Conv1d:
+    return nn.Conv1d(cin, cout, kernel_size=1, bias=True)
+
+
+class _NonLocalParams(nn.Module):
+    """Weights of one SCNonlocal block (reference NonLocalBlock, models/PointDSC.py:9-25)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        h = c // 2
+        self.fc_message = nn.Sequential(_conv(c, h), nn.BatchNorm1d(h), nn.ReLU(inplace=True),
+                                        _conv(h, h), nn.BatchNorm1d(h), nn.ReLU(inplace=True), _conv(h, c))
+        self.projection_q = _conv(c, c)
+        self.projection_k = _conv(c, c)
+        self.projection_v = _conv(c, c)
+
+
+class _EncoderParams(nn.Module):
+    """Weights of the 12-layer encoder (reference NonLocalNet, models/PointDSC.py:48-63)."""
+
+    def __init__(self, in_dim: int, num_layers: int, c: int):
+        super().__init__()
+        self.num_layers = num_layers
+        self.blocks = nn.ModuleDict()
+        self.layer0 = _conv(in_dim, c)
+        for i in range(num_layers):
+            self.blocks[f"PointCN_layer_{i}"] = nn.Sequential(_conv(c, c), nn.BatchNorm1d(c), nn.ReLU(inplace=True))
+            self.blocks[f"NonLocal_layer_{i}"] = _NonLocalParams(c)
+
+
+def _fold_bn(conv: nn.Conv1d, bn: Optional[nn.BatchNorm1d]):
+    """Conv1d(k=1) followed by eval-mode BatchNorm1d as one affine map, folded in fp64."""
+    w = conv.weight.detach()[:, :, 0].double()
+    b = conv.bias.detach().double()
+    if bn is not None:
+        scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = w * scale[:, None]
+        b = (b - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+    return w, b
+
+
+class PointDSC(nn.Module):
+    def __init__(self, in_dim=6, num_layers=6, num_channels=128, num_iterations=10, ratio=0.1,
+                 inlier_threshold=0.10, sigma_d=0.10, k=40, nms_radius=0.10):
+        super().__init__()
+        if num_channels != _NUM_CHANNELS:
+            raise ValueError(f"pointdsc_amd supports num_channels={_NUM_CHANNELS} (the released models); got {num_channels}")
+        self.in_dim = in_dim
+        self.num_layers = num_layers
+        self.num_iterations = num_iterations
+        self.ratio = ratio
+        self.num_channels = num_channels
+        self.inlier_threshold = inlier_threshold
+        self.sigma = nn.Parameter(torch.tensor([1.0], dtype=torch.float32), requires_grad=True)
+        self.sigma_spat = nn.Parameter(torch.tensor([sigma_d], dtype=torch.float32), requires_grad=False)
+        self.k = k
+        self.nms_radius = nms_radius
+        self.encoder = _EncoderParams(in_dim, num_layers, num_channels)
+        self.classification = nn.Sequential(_conv(num_channels, 32), nn.ReLU(inplace=True), _conv(32, 32),
+                                            nn.ReLU(inplace=True), _conv(32, 1))
+        for m in self.modules():  # same initialiser family as the reference (:116-121)
+            if isinstance(m, nn.Conv1d):
+                nn.init.xavier_normal_(m.weight, gain=1)
+            elif isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._wpack: Optional[torch.Tensor] = None
+        self._wpack_key = None
+        self._workspace: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------------------------------
+    def _config(self) -> _lib.PdscConfig:
+        # reference post_refinement picks its threshold by exact equality with 0.10 (:415-418)
+        refine_thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
+        return _lib.PdscConfig(self.in_dim, self.num_layers, self.num_channels, self.num_iterations, self.k, 20,
+                               float(self.inlier_threshold), float(self.nms_radius), float(refine_thr))
+
+    # The packed buffer is rebuilt after anything that can change weights through the nn.Module API
+    # (load_state_dict, .to()/.cuda()/.float(), train()); after editing parameters in place call
+    # invalidate_packed_weights() yourself.
+    def invalidate_packed_weights(self) -> None:
+        self._wpack = None
+        self._wpack_key = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed_weights()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_packed_weights()
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed_weights()
+        return super().train(mode)
+
+    def packed_weights(self, device=None) -> torch.Tensor:
+        """The flat fp32 buffer of include/pointdsc_hip.h (``enum pdsc_wsection``): BatchNorm folded,
+        q pre-scaled, sigma / sigma_spat appended (read from the Parameters, so a checkpoint overrides
+        the constructor's sigma_d exactly like in the reference)."""
+        lib = _lib.load()
+        device = device or self.sigma.device
+        key = (str(device), self.sigma.data_ptr())
+        if self._wpack is not None and self._wpack_key == key:
+            return self._wpack
+        cfg = self._config()
+        total = int(lib.pdsc_wpack_floats(C.byref(cfg)))
+        if total <= 0:
+            raise RuntimeError("pdsc_wpack_floats: " + _lib.last_error())
+        pack = torch.zeros(total, dtype=torch.float32, device=device)
+
+        def put(section: str, layer: int, value: torch.Tensor):
+            off = int(lib.pdsc_wpack_offset(C.byref(cfg), _lib.W[section], layer))
+            if off < 0:
+                raise RuntimeError(f"pdsc_wpack_offset({section},{layer}): " + _lib.last_error())
+            flat = value.reshape(-1).to(device=device, dtype=torch.float32)
+            pack[off:off + flat.numel()] = flat
+
+        c = self.num_channels
+        w0, b0 = _fold_bn(self.encoder.layer0, None)
+        w0p = torch.zeros(c, 8, dtype=torch.float64, device=w0.device)
+        w0p[:, :self.in_dim] = w0
+        put("LAYER0_W", 0, w0p)
+        put("LAYER0_B", 0, b0)
+        qscale = math.log2(math.e) / math.sqrt(c)      # softmax runs in the log2 domain on pre-scaled q
+        for i in range(self.num_layers):
+            pcn = self.encoder.blocks[f"PointCN_layer_{i}"]
+            nl = self.encoder.blocks[f"NonLocal_layer_{i}"]
+            w, b = _fold_bn(pcn[0], pcn[1])
+            put("PCN_W", i, w); put("PCN_B", i, b)
+            wq, bq = _fold_bn(nl.projection_q, None)
+            wk, bk = _fold_bn(nl.projection_k, None)
+            wv, bv = _fold_bn(nl.projection_v, None)
+            put("QKV_W", i, torch.cat([wq * qscale, wk, wv], 0)); put("QKV_B", i, torch.cat([bq * qscale, bk, bv], 0))
+            w, b = _fold_bn(nl.fc_message[0], nl.fc_message[1])
+            put("FC1_W", i, w); put("FC1_B", i, b)
+            w, b = _fold_bn(nl.fc_message[3], nl.fc_message[4])
+            put("FC2_W", i, w); put("FC2_B", i, b)
+            w, b = _fold_bn(nl.fc_message[6], None)
+            put("FC3_W", i, w); put("FC3_B", i, b)
+        for sec, j in (("CLS1", 0), ("CLS2", 2), ("CLS3", 4)):
+            w, b = _fold_bn(self.classification[j], None)
+            put(sec + "_W", 0, w); put(sec + "_B", 0, b)
+        put("SIGMA", 0, self.sigma.detach())
+        put("SIGMA_SPAT", 0, self.sigma_spat.detach())
+        self._wpack, self._wpack_key = pack, key
+        return pack
+
+    def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, Optional[torch.Tensor]]:
+        """data: corr_pos [bs,N,in_dim], src_keypts [bs,N,3], tgt_keypts [bs,N,3], key 'testing' present.
+        Returns final_trans [bs,4,4], final_labels [bs,N] (0/1 float), M None."""
+        corr_pos, src_keypts, tgt_keypts = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
+        if "testing" not in data.keys():
+            raise NotImplementedError(
+                "pointdsc_amd implements the test-time hot path (data['testing'] present); the training-mode "
+                "forward (M matrix + logits, reference models/PointDSC.py:158-163,176,190-191) is out of scope "
+                "(SURVEY.md section 8 f-1).")
+        if self.training:
+            raise RuntimeError("call .eval() first: BatchNorm is folded with its running statistics")
+        lib = _lib.load()
+        if not corr_pos.is_cuda:
+            raise RuntimeError("pointdsc_amd has no CPU path: move the model and data to the GPU (model.cuda())")
+        dev = corr_pos.device
+        corr_pos = corr_pos.detach().to(torch.float32).contiguous()
+        src_keypts = src_keypts.detach().to(device=dev, dtype=torch.float32).contiguous()
+        tgt_keypts = tgt_keypts.detach().to(device=dev, dtype=torch.float32).contiguous()
+        bs, n = corr_pos.shape[0], corr_pos.shape[1]
+        if corr_pos.shape[2] != self.in_dim or src_keypts.shape != (bs, n, 3) or tgt_keypts.shape != (bs, n, 3):
+            raise ValueError("bad input shapes for PointDSC.forward")
+        num_seeds = int(n * self.ratio)                       # python double arithmetic, as the reference (:174)
+        cfg = self._config()
+        with torch.cuda.device(dev):
+            wpack = self.packed_weights(dev)
+            nbytes = int(lib.pdsc_workspace_bytes(C.byref(cfg), bs, n, num_seeds))
+            if nbytes == 0:
+                raise RuntimeError(f"unsupported problem size bs={bs} N={n} seeds={num_seeds}: " + _lib.last_error())
+            ws = self._get_workspace(nbytes, dev)
+            final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
+            final_labels = torch.empty(bs, n, device=dev, dtype=torch.float32)
+            rc = lib.pdsc_forward_testing(C.byref(cfg), C.c_void_p(wpack.data_ptr()), C.c_void_p(corr_pos.data_ptr()),
+                                          C.c_void_p(src_keypts.data_ptr()), C.c_void_p(tgt_keypts.data_ptr()),
+                                          bs, n, num_seeds, C.c_void_p(final_trans.data_ptr()),
+                                          C.c_void_p(final_labels.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
+                                          torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pdsc_forward_testing")
+        return {"final_trans": final_trans, "final_labels": final_labels, "M": None}
+
+    def workspace_view(self, name: str, bs: int, n: int, dtype=torch.float32) -> torch.Tensor:
+        """Intermediate of the LAST forward (parity tests): flat view into the workspace from `name` on."""
+        lib = _lib.load()
+        cfg = self._config()
+        off = int(lib.pdsc_workspace_offset(C.byref(cfg), bs, n, int(n * self.ratio), name.encode()))
+        if off < 0 or self._workspace is None:
+            raise KeyError(name)
+        return self._workspace[off:].view(torch.uint8)[: (self._workspace.numel() - off) // 4 * 4].view(dtype)

@@ -1,0 +1,203 @@
+"""Stage-level tensor wrappers over the C-ABI (one per entry point of include/pointdsc_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic happens in
+libpointdsc_hip.so.  Every wrapper validates device/dtype/contiguity, allocates outputs with torch and
+enqueues on ``torch.cuda.current_stream()``.  Names and argument meaning follow the reference functions
+they stand in for (``rigid_transform_3d``, ``knn`` ... in /root/reference/models/common.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (pointdsc_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def compat_ld(n: int) -> int:
+    return int(_lib.load().pdsc_compat_ld(n))
+
+
+def spatial_compat(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spat: torch.Tensor,
+                   want_dist: bool = False):
+    """[bs,N,3] x2 -> compat [bs,N,ld] (view [..., :N] is the reference matrix), optional src_dist."""
+    lib = _lib.load()
+    src, tgt = _chk(src_keypts, "src_keypts"), _chk(tgt_keypts, "tgt_keypts")
+    sig = _chk(sigma_spat.reshape(-1), "sigma_spat")
+    bs, n = src.shape[0], src.shape[1]
+    ld = compat_ld(n)
+    compat = torch.empty(bs, n, ld, device=src.device, dtype=torch.float32)
+    dist = torch.empty_like(compat) if want_dist else None
+    _lib.check(lib.pdsc_spatial_compat(_p(src), _p(tgt), _p(sig), _p(compat), _p(dist), ld, bs, n, _stream()),
+               "pdsc_spatial_compat")
+    return (compat, dist) if want_dist else compat
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M,K] @ weight[Nout,K]^T (+bias)(relu)(+residual) -> [M,Nout]."""
+    lib = _lib.load()
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    m, k = x.shape
+    nout = weight.shape[0]
+    y = torch.empty(m, nout, device=x.device, dtype=torch.float32)
+    b = _chk(bias, "bias") if bias is not None else None
+    r = _chk(residual, "residual") if residual is not None else None
+    _lib.check(lib.pdsc_linear(_p(x), k, _p(weight), _p(b), _p(r), nout, _p(y), nout, m, k, nout, int(relu), _stream()),
+               "pdsc_linear")
+    return y
+
+
+def layer0(corr_pos: torch.Tensor, w0_padded: torch.Tensor, b0: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = _chk(corr_pos, "corr_pos").reshape(-1, corr_pos.shape[-1])
+    w, b = _chk(w0_padded, "w0"), _chk(b0, "b0")
+    y = torch.empty(x.shape[0], 128, device=x.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_layer0(_p(x), x.shape[1], _p(w), _p(b), _p(y), x.shape[0], _stream()), "pdsc_layer0")
+    return y
+
+
+def sc_attention(qkv: torch.Tensor, compat: torch.Tensor, bs: int, n: int, nsplit: int = 0) -> torch.Tensor:
+    """qkv [bs*N,384] (q pre-scaled by log2(e)/sqrt(128)), compat [bs,N,ld] -> msg [bs*N,128]."""
+    lib = _lib.load()
+    qkv, compat = _chk(qkv, "qkv"), _chk(compat, "compat")
+    ld = compat.shape[-1]
+    msg = torch.empty(bs * n, 128, device=qkv.device, dtype=torch.float32)
+    nb = int(lib.pdsc_attention_scratch_bytes(bs, n, nsplit))
+    scratch = torch.empty(max(nb, 16), device=qkv.device, dtype=torch.uint8)
+    _lib.check(lib.pdsc_sc_attention(_p(qkv), _p(compat), ld, _p(msg), _p(scratch), nb, bs, n, nsplit, _stream()),
+               "pdsc_sc_attention")
+    return msg
+
+
+def normalize_confidence(feat, h2, w3, b3) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    feat, h2, w3, b3 = _chk(feat, "feat"), _chk(h2, "h2"), _chk(w3.reshape(-1), "w3"), _chk(b3.reshape(-1), "b3")
+    m = feat.shape[0]
+    normed = torch.empty_like(feat)
+    conf = torch.empty(m, device=feat.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_normalize_confidence(_p(feat), _p(h2), _p(w3), _p(b3), _p(normed), _p(conf), m, _stream()),
+               "pdsc_normalize_confidence")
+    return normed, conf
+
+
+def nms_keys(src_keypts, conf, radius: float) -> torch.Tensor:
+    lib = _lib.load()
+    src, conf = _chk(src_keypts, "src_keypts"), _chk(conf, "conf")
+    bs, n = src.shape[0], src.shape[1]
+    keys = torch.empty(bs, n, device=src.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_nms_keys(_p(src), _p(conf), float(radius), _p(keys), bs, n, _stream()), "pdsc_nms_keys")
+    return keys
+
+
+def rank_select(keys, num_seeds: int) -> torch.Tensor:
+    lib = _lib.load()
+    keys = _chk(keys, "keys")
+    bs, n = keys.shape
+    seeds = torch.empty(bs, num_seeds, device=keys.device, dtype=torch.int32)
+    _lib.check(lib.pdsc_rank_select(_p(keys), _p(seeds), bs, n, num_seeds, _stream()), "pdsc_rank_select")
+    return seeds
+
+
+def pick_seeds(src_keypts, scores, R: float, max_num: int) -> torch.Tensor:
+    """reference PointDSC.pick_seeds (dists replaced by the keypoints they were computed from)."""
+    return rank_select(nms_keys(src_keypts, scores, R), max_num).long()
+
+
+def knn_seeds(normed, seeds, k: int, return_dist: bool = False):
+    """normed [bs,N,128], seeds [bs,S] int32 -> knn_idx [bs,S,k] int32."""
+    lib = _lib.load()
+    normed, seeds = _chk(normed, "normed"), _chk(seeds, "seeds", torch.int32)
+    bs, n = normed.shape[0], normed.shape[1]
+    s = seeds.shape[1]
+    ld = compat_ld(n)
+    dist = torch.empty(bs, s, ld, device=normed.device, dtype=torch.float32)
+    idx = torch.empty(bs, s, k, device=normed.device, dtype=torch.int32)
+    _lib.check(lib.pdsc_knn_seeds(_p(normed), _p(seeds), _p(dist), _p(idx), bs, n, s, k, _stream()), "pdsc_knn_seeds")
+    return (idx, dist[..., :n]) if return_dist else idx
+
+
+def seed_power_iteration(normed, src, tgt, knn_idx, sigma, sigma_spat, num_iterations: int, want_M: bool = False):
+    lib = _lib.load()
+    normed, src, tgt = _chk(normed, "normed"), _chk(src, "src"), _chk(tgt, "tgt")
+    knn_idx = _chk(knn_idx, "knn_idx", torch.int32)
+    sigma, sigma_spat = _chk(sigma.reshape(-1), "sigma"), _chk(sigma_spat.reshape(-1), "sigma_spat")
+    bs, n = src.shape[0], src.shape[1]
+    s, k = knn_idx.shape[1], knn_idx.shape[2]
+    iters = torch.zeros(bs, s, max(num_iterations, 1), 64, device=src.device, dtype=torch.float32)
+    mask = torch.empty(bs, device=src.device, dtype=torch.int32)
+    M = torch.empty(bs, s, k, k, device=src.device, dtype=torch.float32) if want_M else None
+    _lib.check(lib.pdsc_seed_power_iteration(_p(normed), _p(src), _p(tgt), _p(knn_idx), _p(sigma), _p(sigma_spat),
+                                             _p(iters), _p(mask), _p(M), bs, n, s, k, num_iterations, _stream()),
+               "pdsc_seed_power_iteration")
+    return iters, mask, M
+
+
+def seed_transforms(src, tgt, knn_idx, iters, mask, num_iterations: int):
+    lib = _lib.load()
+    src, tgt = _chk(src, "src"), _chk(tgt, "tgt")
+    knn_idx = _chk(knn_idx, "knn_idx", torch.int32)
+    bs, n = src.shape[0], src.shape[1]
+    s, k = knn_idx.shape[1], knn_idx.shape[2]
+    trans = torch.empty(bs, s, 4, 4, device=src.device, dtype=torch.float32)
+    w = torch.empty(bs, s, k, device=src.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_seed_transforms(_p(src), _p(tgt), _p(knn_idx), _p(iters), _p(mask), _p(trans), _p(w),
+                                        bs, n, s, k, num_iterations, _stream()), "pdsc_seed_transforms")
+    return trans, w
+
+
+def rigid_transform_3d(A: torch.Tensor, B: torch.Tensor, weights: Optional[torch.Tensor] = None,
+                       weight_threshold: float = 0) -> torch.Tensor:
+    """Drop-in for reference models/common.py:rigid_transform_3d: A,B [bs,n,3] -> [bs,4,4]."""
+    lib = _lib.load()
+    A, B = _chk(A, "A"), _chk(B, "B")
+    bs, n = A.shape[0], A.shape[1]
+    w = _chk(weights, "weights") if weights is not None else None
+    T = torch.empty(bs, 4, 4, device=A.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_rigid_transform_3d(_p(A), _p(B), _p(w), float(weight_threshold), _p(T), bs, n, _stream()),
+               "pdsc_rigid_transform_3d")
+    return T
+
+
+def score_hypotheses(seed_trans, src, tgt, inlier_threshold: float):
+    lib = _lib.load()
+    seed_trans, src, tgt = _chk(seed_trans, "seed_trans"), _chk(src, "src"), _chk(tgt, "tgt")
+    bs, n = src.shape[0], src.shape[1]
+    s = seed_trans.shape[1]
+    counts = torch.empty(bs, s, device=src.device, dtype=torch.int32)
+    _lib.check(lib.pdsc_score_hypotheses(_p(seed_trans), _p(src), _p(tgt), float(inlier_threshold), _p(counts),
+                                         bs, n, s, _stream()), "pdsc_score_hypotheses")
+    best = torch.empty(bs, device=src.device, dtype=torch.int32)
+    initial = torch.empty(bs, 4, 4, device=src.device, dtype=torch.float32)
+    labels = torch.empty(bs, n, device=src.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_select_best(_p(counts), _p(seed_trans), _p(src), _p(tgt), float(inlier_threshold), _p(best),
+                                    _p(initial), _p(labels), bs, n, s, _stream()), "pdsc_select_best")
+    return counts, best, initial, labels
+
+
+def post_refinement(initial_trans, src, tgt, threshold: float, max_iters: int = 20):
+    lib = _lib.load()
+    initial_trans, src, tgt = _chk(initial_trans, "initial_trans"), _chk(src, "src"), _chk(tgt, "tgt")
+    bs, n = src.shape[0], src.shape[1]
+    final = torch.empty(bs, 4, 4, device=src.device, dtype=torch.float32)
+    solves = torch.empty(bs, device=src.device, dtype=torch.int32)
+    _lib.check(lib.pdsc_post_refinement(_p(initial_trans), _p(src), _p(tgt), float(threshold), max_iters, _p(final),
+                                        _p(solves), bs, n, _stream()), "pdsc_post_refinement")
+    return final, solves
