@@ -62,6 +62,9 @@ SIGNATURES = {
     "pdsc_score_hypotheses": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "pdsc_select_best": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pdsc_post_refinement": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp]),
+    "pdsc_profile_enable": (_i, [_i]),
+    "pdsc_profile_reset": (_i, []),
+    "pdsc_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pdsc_forward_testing": (_i, [_cfgp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }
 

@@ -26,6 +26,24 @@ int check_launch(const char* what) {
     return PDSC_OK;
 }
 
+// ---- opt-in event timing -----------------------------------------------------------------------
+struct ProfKind { hipEvent_t* start = nullptr; hipEvent_t* stop = nullptr; int cap = 0, n = 0; bool open = false; };
+static ProfKind g_prof[PDSC_PROF_NUM_KINDS];
+
+void profile_mark_begin(int kind, hipStream_t st) {
+    ProfKind& p = g_prof[kind];
+    if (p.cap == 0 || p.n >= p.cap) return;
+    (void)hipEventRecord(p.start[p.n], st);
+    p.open = true;
+}
+void profile_mark_end(int kind, hipStream_t st) {
+    ProfKind& p = g_prof[kind];
+    if (!p.open) return;
+    (void)hipEventRecord(p.stop[p.n], st);
+    p.open = false;
+    ++p.n;
+}
+
 static bool config_ok(const pdsc_config* c) {
     if (!c) { set_error("pdsc_config is null"); return false; }
     if (c->num_channels != PDSC_CHANNELS) { set_error("num_channels=%d (only %d supported)", c->num_channels, PDSC_CHANNELS); return false; }
@@ -163,6 +181,43 @@ extern "C" size_t pdsc_workspace_bytes(const pdsc_config* cfg, int bs, int N, in
 extern "C" long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name) {
     if (!config_ok(cfg) || bs <= 0 || N <= 1 || num_seeds <= 0 || !name) return -1;
     return make_layout(cfg, bs, N, num_seeds).find(name);
+}
+
+extern "C" int pdsc_profile_enable(int max_records) {
+    for (int k = 0; k < PDSC_PROF_NUM_KINDS; ++k) {
+        ProfKind& p = g_prof[k];
+        for (int i = 0; i < p.cap; ++i) { (void)hipEventDestroy(p.start[i]); (void)hipEventDestroy(p.stop[i]); }
+        delete[] p.start; delete[] p.stop;
+        p = ProfKind();
+        if (max_records > 0) {
+            p.start = new hipEvent_t[max_records];
+            p.stop = new hipEvent_t[max_records];
+            for (int i = 0; i < max_records; ++i) {
+                if (hipEventCreate(&p.start[i]) != hipSuccess || hipEventCreate(&p.stop[i]) != hipSuccess)
+                    return check_launch("pdsc_profile_enable");
+            }
+            p.cap = max_records;
+        }
+    }
+    return PDSC_OK;
+}
+extern "C" int pdsc_profile_reset(void) {
+    for (int k = 0; k < PDSC_PROF_NUM_KINDS; ++k) { g_prof[k].n = 0; g_prof[k].open = false; }
+    return PDSC_OK;
+}
+extern "C" int pdsc_profile_read(int kind, double* total_ms, int* launches) {
+    PDSC_REQUIRE(kind >= 0 && kind < PDSC_PROF_NUM_KINDS && total_ms && launches, "pdsc_profile_read: bad argument");
+    ProfKind& p = g_prof[kind];
+    double tot = 0.0;
+    for (int i = 0; i < p.n; ++i) {
+        if (hipEventSynchronize(p.stop[i]) != hipSuccess) return check_launch("pdsc_profile_read");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start[i], p.stop[i]) != hipSuccess) return check_launch("pdsc_profile_read");
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = p.n;
+    return PDSC_OK;
 }
 
 #define PDSC_TRY(call)                 \

@@ -282,7 +282,9 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
         attr_done = true;
     }
     dim3 grid(pdsc::ceil_div(N, pdsc::ATT_BQ), nsplit, bs);
+    pdsc::profile_mark_begin(PDSC_PROF_ATTENTION, st);
     hipLaunchKernelGGL(pdsc::sc_attention_kernel, grid, dim3(256), lds_bytes, st, a);
+    pdsc::profile_mark_end(PDSC_PROF_ATTENTION, st);
     int rc = pdsc::check_launch("pdsc_sc_attention");
     if (rc != PDSC_OK) return rc;
     if (nsplit > 1) {

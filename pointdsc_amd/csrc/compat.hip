@@ -78,9 +78,11 @@ extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const flo
     PDSC_REQUIRE(ld >= N && ld % 4 == 0, "pdsc_spatial_compat: ld=%lld must be >= N and a multiple of 4", ld);
     dim3 grid(pdsc::ceil_div((int)ld, pdsc::CT_COLS), pdsc::ceil_div(N, pdsc::CT_ROWS), bs);
     hipStream_t st = (hipStream_t)stream;
+    pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
     if (src_dist)
         hipLaunchKernelGGL(pdsc::compat_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, src_dist, ld, N);
     else
         hipLaunchKernelGGL(pdsc::compat_kernel<false>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+    pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
     return pdsc::check_launch("pdsc_spatial_compat");
 }

@@ -21,6 +21,10 @@ int check_launch(const char* what);
         }                                             \
     } while (0)
 
+// opt-in event timing of the roofline kernels (api.hip); no-ops unless pdsc_profile_enable() was called
+void profile_mark_begin(int kind, hipStream_t st);
+void profile_mark_end(int kind, hipStream_t st);
+
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

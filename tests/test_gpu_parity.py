@@ -1,0 +1,485 @@
+"""GPU parity tests (-m gpu): every stage of the HIP path, called through the C-ABI, against the CPU oracle
+on identical seeded inputs, then the whole path against the committed golden fixtures (outputs of the
+unmodified reference).  Each stage test feeds ORACLE inputs to ONE stage so failures do not cascade.
+
+Bars: bit-exact for integer/index/mask work (compat bits, NMS keys, seeds, inlier counts, best index, labels);
+floating-point stages within the tolerance written next to each assert; R/t within 1e-4 (BASELINE.json).
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointdsc_oracle as O
+from pointdsc_amd import PointDSC, ops, synthetic
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLDEN = ROOT / "tests" / "golden"
+DEV = "cuda:0"
+KW = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
+          sigma_d=0.10, k=40, nms_radius=0.10)
+ORACLE_KEYS = ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")
+QSCALE = float(np.log2(np.e) / np.sqrt(128.0))
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+_CASES = {}
+
+
+def case(n, pair_seed=21, wseed=6, inlier_ratio=0.3, kw=None):
+    """Oracle stages for one seeded pair (cached per session)."""
+    key = (n, pair_seed, wseed, inlier_ratio, json.dumps(kw or {}, sort_keys=True))
+    if key not in _CASES:
+        mk = dict(KW, **(kw or {}))
+        model = PointDSC(**mk)
+        sd = synthetic.make_state_dict(model.state_dict(), seed=wseed)
+        model.load_state_dict(sd)
+        model = model.eval().to(DEV)
+        pair = synthetic.make_pair(n, inlier_ratio=inlier_ratio, seed=pair_seed)
+        res = O.forward_testing(sd, pair["corr_pos"], pair["src_keypts"], pair["tgt_keypts"], return_stages=True,
+                                **{k: mk[k] for k in ORACLE_KEYS})
+        _CASES[key] = dict(model=model, sd=sd, pair=pair, st=res["stages"][0], res=res, kw=mk)
+    return _CASES[key]
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-1 compat
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [257, 1000, 2053])
+def test_spatial_compat_bit_exact(n):
+    c = case(n)
+    src, tgt = g(c["pair"]["src_keypts"]), g(c["pair"]["tgt_keypts"])
+    compat, dist = ops.spatial_compat(src, tgt, g(c["sd"]["sigma_spat"]), want_dist=True)
+    assert compat.shape[-1] == ops.compat_ld(n)
+    assert torch.equal(compat[0, :, :n].cpu(), c["st"]["compat"])            # bit-exact vs oracle == reference
+    assert torch.equal(dist[0, :, :n].cpu(), c["st"]["src_dist"])
+    assert float(compat[0, :, n:].abs().sum()) == 0.0                          # padding columns are zero
+    only = ops.spatial_compat(src, tgt, g(c["sd"]["sigma_spat"]))
+    assert torch.equal(only, compat)
+
+
+def test_spatial_compat_batched_and_kitti_scale():
+    b = synthetic.make_batch(3, 300, seed=50, scale=60.0, noise=0.1)
+    sig = torch.tensor([1.2])
+    compat = ops.spatial_compat(g(b["src_keypts"]), g(b["tgt_keypts"]), g(sig))
+    for i in range(3):
+        _, want = O.spatial_compat(b["src_keypts"][i], b["tgt_keypts"][i], sig)
+        assert torch.equal(compat[i, :, :300].cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-2 point-wise layers
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,k,nout", [(1, 8, 1), (63, 32, 32), (64, 64, 64), (65, 128, 128), (1000, 128, 384),
+                                      (257, 128, 100), (5000, 64, 128), (130, 128, 32)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (False, True)])
+def test_linear_matches_fp64(m, k, nout, relu, res):
+    gen = torch.Generator().manual_seed(m * 7 + k + nout)
+    x = torch.randn(m, k, generator=gen)
+    w = torch.randn(nout, k, generator=gen) / k ** 0.5
+    b = torch.randn(nout, generator=gen)
+    r = torch.randn(m, nout, generator=gen) if res else None
+    y = ops.linear(g(x), g(w), g(b), relu=relu, residual=g(r) if res else None).cpu()
+    want = x.double() @ w.double().T + b.double()
+    if relu:
+        want = want.clamp(min=0)
+    if res:
+        want = want + r.double()
+    assert (y.double() - want).abs().max() < 2e-6 * max(1.0, float(want.abs().max()))   # fp32 accumulate, K<=128
+
+
+def test_layer0_matches_oracle():
+    c = case(1000)
+    sd = c["sd"]
+    w0 = torch.zeros(128, 8)
+    w0[:, :6] = sd["encoder.layer0.weight"][:, :, 0]
+    y = ops.layer0(g(c["pair"]["corr_pos"]), g(w0), g(sd["encoder.layer0.bias"])).cpu()
+    want = (sd["encoder.layer0.weight"][:, :, 0] @ c["pair"]["corr_pos"][0].T + sd["encoder.layer0.bias"][:, None]).T
+    assert (y - want).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-3 attention
+# ------------------------------------------------------------------------------------------------------
+def _attention_ref(q, k, v, compat):
+    s = (q.double() @ k.double().T) / np.sqrt(128.0)
+    w = torch.softmax(compat.double() * s, dim=-1)
+    return w @ v.double()
+
+
+@pytest.mark.parametrize("n,bs", [(257, 1), (1000, 2), (2053, 1), (96, 3), (33, 1)])
+@pytest.mark.parametrize("nsplit", [1, 0, 3])
+def test_sc_attention_matches_fp64_softmax(n, bs, nsplit):
+    gen = torch.Generator().manual_seed(n + bs)
+    batch = synthetic.make_batch(bs, n, seed=70 + n)
+    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    q, k, v = (torch.randn(bs, n, 128, generator=gen) * s for s in (2.0, 2.0, 1.0))
+    qkv = torch.cat([q * QSCALE, k, v], dim=-1).reshape(bs * n, 384)
+    msg = ops.sc_attention(g(qkv), compat, bs, n, nsplit=nsplit).cpu().reshape(bs, n, 128)
+    for b in range(bs):
+        want = _attention_ref(q[b], k[b], v[b], compat[b, :, :n].cpu())
+        err = (msg[b].double() - want).abs().max()
+        assert err < 5e-6 * max(1.0, float(want.abs().max())), (b, float(err))   # fp32 MFMA + online softmax
+
+
+def test_sc_attention_online_softmax_rescale_branch():
+    """Force the running max to jump late (one key dominates one query in the LAST tile) and early."""
+    n = 320
+    gen = torch.Generator().manual_seed(5)
+    q, k, v = torch.randn(n, 128, generator=gen), torch.randn(n, 128, generator=gen), torch.randn(n, 128, generator=gen)
+    k[n - 3] = q[7] * 3.0            # spike in the last tile for query 7
+    k[2] = q[200] * 3.0              # spike in the first tile for query 200
+    compat = torch.ones(1, n, ops.compat_ld(n))
+    qkv = torch.cat([q * QSCALE, k, v], dim=-1)
+    for nsplit in (1, 2, 5):
+        msg = ops.sc_attention(g(qkv), g(compat), 1, n, nsplit=nsplit).cpu()
+        want = _attention_ref(q, k, v, compat[0, :, :n])
+        assert (msg.double() - want).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------
+# encoder end to end (a-2 + a-3 chained over 12 layers) and a-4
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [257, 1000])
+def test_encoder_and_head_match_oracle(n):
+    c = case(n)
+    data = {k: g(c["pair"][k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    data["testing"] = True
+    c["model"](data)
+    torch.cuda.synchronize()
+    feat = c["model"].workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu()
+    scale = float(c["st"]["feat"].abs().max())
+    assert (feat - c["st"]["feat"]).abs().max() < 3e-5 * max(scale, 1.0)          # 12 layers of fp32 roundoff
+    normed = c["model"].workspace_view("normed", 1, n)[: n * 128].reshape(n, 128).cpu()
+    assert (normed - c["st"]["normed"]).abs().max() < 2e-5
+    conf = c["model"].workspace_view("conf", 1, n)[:n].cpu()
+    assert (conf - c["st"]["confidence"]).abs().max() < 3e-5 * max(scale, 1.0)
+
+
+def test_normalize_confidence_stage():
+    c = case(1000)
+    sd, feat = c["sd"], c["st"]["feat"]
+    h1 = torch.relu(feat @ sd["classification.0.weight"][:, :, 0].T + sd["classification.0.bias"])
+    h2 = torch.relu(h1 @ sd["classification.2.weight"][:, :, 0].T + sd["classification.2.bias"])
+    normed, conf = ops.normalize_confidence(g(feat), g(h2), g(sd["classification.4.weight"]), g(sd["classification.4.bias"]))
+    assert (normed.cpu() - c["st"]["normed"]).abs().max() < 1e-6
+    assert (conf.cpu() - c["st"]["confidence"]).abs().max() < 1e-5
+    zero = torch.zeros(4, 128)                                                     # eps branch of F.normalize
+    nz, _ = ops.normalize_confidence(g(zero), g(torch.zeros(4, 32)), g(sd["classification.4.weight"]), g(sd["classification.4.bias"]))
+    assert float(nz.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-5 NMS seeds (fed with the oracle's confidence: result must be identical)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [257, 1000, 2053])
+def test_nms_keys_and_seeds_bit_exact(n):
+    c = case(n)
+    src, conf = g(c["pair"]["src_keypts"]), g(c["st"]["confidence"][None])
+    keys = ops.nms_keys(src, conf, KW["nms_radius"])
+    assert torch.equal(keys[0].cpu(), c["st"]["nms_keys"])
+    seeds = ops.rank_select(keys, int(n * KW["ratio"]))
+    assert torch.equal(seeds[0].cpu().long(), c["st"]["seeds"])
+
+
+def test_seed_ties_resolve_by_ascending_index():
+    n = 500
+    pair = synthetic.make_pair(n, seed=3)
+    conf = torch.full((1, n), -0.25)                 # all-negative, all-equal logits: keys tie at -0.25 / -0
+    conf[0, ::7] = -0.5
+    src_dist, _ = O.spatial_compat(pair["src_keypts"][0], pair["tgt_keypts"][0], torch.tensor([0.1]))
+    want = O.pick_seeds(src_dist, conf[0], 0.1, 50)
+    got = ops.pick_seeds(g(pair["src_keypts"]), g(conf), 0.1, 50)
+    assert torch.equal(got[0].cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-6 kNN (fed with the oracle's features and seeds)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [257, 1000, 2053])
+def test_knn_of_seeds(n):
+    c = case(n)
+    normed, seeds = c["st"]["normed"], c["st"]["seeds"]
+    k = min(KW["k"], n - 1)
+    idx, dist = ops.knn_seeds(g(normed[None]), g(seeds[None].int()), k, return_dist=True)
+    idx, dist = idx[0].cpu().long(), dist[0].cpu()
+    want_dist = O.knn_dist_rows(normed, seeds)
+    assert (dist - want_dist).abs().max() < 2e-6                                   # fp32 Gram rows
+    # the selection itself is exact on the GPU's own distances: ascending (dist, index), rank 0 dropped
+    order = torch.sort(dist, dim=-1, stable=True).indices[:, 1:k + 1]
+    assert torch.equal(idx, order)
+    # against the oracle's neighbour sets: only near-ties at the k-th boundary may differ
+    want = c["st"]["knn_idx"]
+    same = sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(idx, want))
+    assert same >= 0.9 * len(seeds)
+    for s in range(len(seeds)):
+        diff = set(idx[s].tolist()) ^ set(want[s].tolist())
+        if diff:
+            kth = torch.sort(want_dist[s]).values[k]
+            assert all(abs(float(want_dist[s, j] - kth)) < 5e-6 for j in diff)
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-7 / a-8 / a-9 seed solver (fed with the oracle's neighbour lists)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [257, 1000])
+def test_seed_matrices_power_iteration_and_transforms(n):
+    c = case(n)
+    st, sd = c["st"], c["sd"]
+    normed, src, tgt = g(st["normed"][None]), g(c["pair"]["src_keypts"]), g(c["pair"]["tgt_keypts"])
+    knn = g(st["knn_idx"][None].int())
+    iters, mask, M = ops.seed_power_iteration(normed, src, tgt, knn, g(sd["sigma"]), g(sd["sigma_spat"]), 10, want_M=True)
+    assert (M[0].cpu() - st["seed_M"]).abs().max() < 2e-5            # (ds-dt)^2/sigma^2 amplifies 1 ulp of distance
+    k = st["knn_idx"].shape[1]
+    ran = st["power_iters"]
+    m = int(mask[0].item()) & 0x3FF
+    chosen = (m & -m).bit_length() - 1 if m else 9
+    assert chosen == ran - 1 or (ran == 10 and m == 0)
+    vec = iters[0, :, chosen, :k].cpu()
+    assert (vec - st["eigvec"]).abs().max() < 2e-5
+    assert float(iters[0, :, :, k:].abs().sum()) == 0.0
+    trans, w = ops.seed_transforms(src, tgt, knn, iters, mask, 10)
+    assert (w[0].cpu() - st["seed_weights"]).abs().max() < 2e-6
+    d = (trans[0].cpu() - st["seed_trans"]).abs().amax(dim=(1, 2))
+    # hypotheses from near-degenerate neighbourhoods are ill-conditioned for ANY solver; the bulk must agree tightly
+    assert float((d < 1e-4).float().mean()) > 0.97, float((d < 1e-4).float().mean())
+    assert float(d.median()) < 5e-6
+
+
+def test_power_iteration_global_early_exit():
+    """Rigid pair + identical features: every k x k block is c*(J-I) and converges at the 2nd iterate."""
+    n, S, k = 200, 20, 40
+    pair = synthetic.make_pair(n, inlier_ratio=1.1, noise=0.0, seed=9)
+    feat = torch.ones(1, n, 128) / 128 ** 0.5
+    knn = torch.stack([torch.randperm(n, generator=torch.Generator().manual_seed(s))[:k] for s in range(S)])[None].int()
+    src, tgt = g(pair["src_keypts"]), g(pair["tgt_keypts"])
+    iters, mask, M = ops.seed_power_iteration(g(feat), src, tgt, g(knn), g(torch.tensor([1.0])), g(torch.tensor([0.1])), 10, want_M=True)
+    want_M = O.seed_matrices(feat[0], pair["src_keypts"][0], pair["tgt_keypts"][0], knn[0].long(), torch.tensor([1.0]), torch.tensor([0.1]))
+    assert (M[0].cpu() - want_M).abs().max() < 1e-3        # compat of an exactly rigid pair is 1 up to rounding of distances
+    vec, ran = O.power_iteration(M[0].cpu(), 10)
+    m = int(mask[0].item()) & 0x3FF
+    assert m != 0 and (m & -m).bit_length() == ran          # first converged iteration == oracle's break point
+    assert (iters[0, :, ran - 1, :k].cpu() - vec).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("bs,n", [(1, 3), (4, 40), (2, 1000), (3, 5000)])
+def test_rigid_transform_3d_matches_lapack_path(bs, n):
+    rs = np.random.RandomState(n + bs)
+    A = torch.from_numpy(rs.standard_normal((bs, n, 3)).astype(np.float32)) * 2
+    R = torch.from_numpy(np.stack([synthetic.random_rotation(rs) for _ in range(bs)]))
+    B = A @ R.transpose(1, 2) + torch.from_numpy(rs.standard_normal((bs, 1, 3)).astype(np.float32))
+    B = B + torch.from_numpy(rs.standard_normal((bs, n, 3)).astype(np.float32)) * 0.05
+    w = torch.from_numpy(rs.random_sample((bs, n)).astype(np.float32))
+    for weights, thr in ((None, 0.0), (w, 0.0), (w, 0.5)):
+        T = ops.rigid_transform_3d(g(A), g(B), g(weights) if weights is not None else None, thr).cpu()
+        want = O.rigid_transform_3d(A, B, weights, thr)
+        assert (T - want).abs().max() < 2e-5, (bs, n, thr)
+        Rg = T[:, :3, :3].double()
+        assert (Rg @ Rg.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-6
+        assert (torch.det(Rg) - 1).abs().max() < 1e-6
+    w_dev = g(w)
+    ops.rigid_transform_3d(g(A), g(B), w_dev, 0.5)
+    assert torch.equal(w_dev.cpu(), w)                      # unlike the reference, weights are not zeroed in place
+
+
+def test_rigid_transform_3d_degenerate_inputs():
+    rs = np.random.RandomState(0)
+    # coplanar points (rank-2 covariance): R is still unique and must match the LAPACK path
+    A = torch.from_numpy(rs.standard_normal((2, 60, 3)).astype(np.float32))
+    A[:, :, 2] = 0.0
+    R = torch.from_numpy(synthetic.random_rotation(rs))
+    B = A @ R.T + torch.tensor([0.1, 0.2, 0.3])
+    T = ops.rigid_transform_3d(g(A), g(B)).cpu()
+    assert (T - O.rigid_transform_3d(A, B)).abs().max() < 2e-5
+    # reflection case: the det correction must produce a proper rotation
+    Bm = B.clone()
+    Bm[:, :, 0] = -Bm[:, :, 0]
+    Tm = ops.rigid_transform_3d(g(A + torch.from_numpy(rs.standard_normal((2, 60, 3)).astype(np.float32)) * 0.3), g(Bm)).cpu()
+    assert (torch.det(Tm[:, :3, :3].double()) - 1).abs().max() < 1e-6
+    # collinear / empty / all-zero-weight inputs: R not defined by the data, result must still be a finite rotation
+    C = torch.zeros(1, 10, 3)
+    C[0, :, 0] = torch.arange(10.0)
+    for A_, B_, w_ in ((C, C * 2, None), (A[:1], B[:1], torch.zeros(1, 60)), (A[:1, :0], B[:1, :0], None)):
+        Td = ops.rigid_transform_3d(g(A_), g(B_), g(w_) if w_ is not None else None).cpu()
+        Rd = Td[:, :3, :3].double()
+        assert torch.isfinite(Td).all() and (Rd @ Rd.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------
+# a-10 / a-11 (fed with the oracle's hypotheses)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [257, 1000, 2053])
+def test_hypothesis_scoring_bit_exact(n):
+    c = case(n)
+    st = c["st"]
+    src, tgt = g(c["pair"]["src_keypts"]), g(c["pair"]["tgt_keypts"])
+    counts, best, initial, labels = ops.score_hypotheses(g(st["seed_trans"][None]), src, tgt, KW["inlier_threshold"])
+    assert torch.equal(counts[0].cpu().long(), st["counts"])
+    assert int(best[0]) == st["best"]
+    assert torch.equal(initial[0].cpu(), st["seed_trans"][st["best"]])
+    assert torch.equal(labels[0].cpu(), st["final_labels"])
+
+
+def test_argmax_takes_first_of_equal_counts():
+    n = 300
+    pair = synthetic.make_pair(n, seed=4)
+    T = torch.eye(4).repeat(1, 6, 1, 1)
+    T[0, 4, 0, 3] = 0.5                                # different transform, fewer inliers
+    counts, best, _, _ = ops.score_hypotheses(g(T), g(pair["src_keypts"]), g(pair["tgt_keypts"]), 0.1)
+    assert int(best[0]) == 0 and int(counts[0, 0]) == int(counts[0, 1])
+
+
+@pytest.mark.parametrize("n", [257, 1000, 2053])
+def test_post_refinement_matches_oracle(n):
+    c = case(n)
+    st = c["st"]
+    src, tgt = g(c["pair"]["src_keypts"]), g(c["pair"]["tgt_keypts"])
+    final, solves = ops.post_refinement(g(st["initial_trans"][None]), src, tgt, 0.10, 20)
+    assert int(solves[0]) == st["refine_solves"]
+    assert (final[0].cpu() - st["final_trans"]).abs().max() < 1e-5
+    # a perturbed start needs several re-solves: exercises the loop, must converge to the same pose
+    start = st["initial_trans"].clone()
+    start[:3, 3] += 0.03
+    want, want_solves = O.post_refinement(start, c["pair"]["src_keypts"][0], c["pair"]["tgt_keypts"][0], 0.10)
+    got, got_solves = ops.post_refinement(g(start[None]), src, tgt, 0.10, 20)
+    assert int(got_solves[0]) == want_solves and (got[0].cpu() - want).abs().max() < 2e-5
+    # no inliers at all: first iteration breaks, pose returned unchanged
+    far = torch.eye(4)[None].clone()
+    far[0, :3, 3] = 100.0
+    same, s0 = ops.post_refinement(g(far), src, tgt, 0.10, 20)
+    assert int(s0[0]) == 0 and torch.equal(same.cpu(), far)
+
+
+# ------------------------------------------------------------------------------------------------------
+# whole path: vs oracle, vs golden fixtures (= reference outputs), batching, edge sizes, errors
+# ------------------------------------------------------------------------------------------------------
+def _forward(model, pair_or_batch):
+    data = {k: g(pair_or_batch[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    data["testing"] = True
+    with torch.no_grad():
+        res = model(data)
+    torch.cuda.synchronize()
+    return res
+
+
+@pytest.mark.parametrize("n", [257, 1000, 2053])
+def test_forward_matches_oracle(n):
+    c = case(n)
+    res = _forward(c["model"], c["pair"])
+    assert res["M"] is None and res["final_trans"].shape == (1, 4, 4) and res["final_labels"].shape == (1, n)
+    assert torch.equal(res["final_labels"].cpu(), c["res"]["final_labels"])            # inlier mask bit-exact
+    assert (res["final_trans"].cpu() - c["res"]["final_trans"]).abs().max() < 1e-4      # R/t within 1e-4
+    re, te = O.registration_errors(res["final_trans"][0].cpu(), c["pair"]["gt_trans"][0])
+    assert re < 1.0 and te < 5.0
+
+
+@pytest.mark.parametrize("name", ["n257_s0", "n1000_s1", "n1000_s2_defaultbn", "n2053_s3", "kitti_n1500_s4", "n5000_s5"])
+def test_forward_matches_reference_golden(name):
+    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    kw = json.loads(str(fx["model_json"]))
+    model = PointDSC(**kw)
+    sd = synthetic.make_state_dict(model.state_dict(), seed=int(fx["wseed"]), randomize_bn=bool(fx["randomize_bn"]))
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    batch = {k: torch.from_numpy(fx[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    res = _forward(model, batch)
+    flips = int((res["final_labels"].cpu() != torch.from_numpy(fx["ref_final_labels"])).sum())
+    dT = float((res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().max())
+    assert flips == 0, f"{flips} label flips vs the reference"
+    assert dT < (1e-3 if bool(fx["tie_case"]) else 1e-4), dT
+
+
+def test_batched_forward_equals_per_pair_calls():
+    c = case(1000)
+    batch = synthetic.make_batch(3, 1000, seed=300, inlier_ratio=0.3)
+    res = _forward(c["model"], batch)
+    for i in range(3):
+        one = _forward(c["model"], {k: batch[k][i:i + 1] for k in batch})
+        assert torch.equal(res["final_labels"][i], one["final_labels"][0])
+        assert (res["final_trans"][i] - one["final_trans"][0]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("n", [11, 30, 64, 129])
+def test_small_and_ragged_sizes(n):
+    """N < k+1 (k = N-1, reference :250), S = int(N*0.1) as small as 1, tiles with ragged tails."""
+    c = case(n, pair_seed=31, inlier_ratio=0.6)
+    res = _forward(c["model"], c["pair"])
+    flips = int((res["final_labels"].cpu() != c["res"]["final_labels"]).sum())
+    assert flips == 0 and (res["final_trans"].cpu() - c["res"]["final_trans"]).abs().max() < 1e-4
+
+
+def test_kitti_thresholds_select_the_other_refinement_schedule():
+    c = case(1500, pair_seed=4, wseed=4, kw=dict(inlier_threshold=0.6, sigma_d=1.2, nms_radius=0.6))
+    pair = synthetic.make_pair(1500, seed=4, inlier_ratio=0.3, scale=60.0, noise=0.1)
+    sd = c["sd"]
+    want = O.forward_testing(sd, pair["corr_pos"], pair["src_keypts"], pair["tgt_keypts"],
+                             **{k: c["kw"][k] for k in ORACLE_KEYS})
+    res = _forward(c["model"], pair)
+    assert c["model"]._config().refine_threshold == pytest.approx(1.2)
+    assert torch.equal(res["final_labels"].cpu(), want["final_labels"])
+    assert (res["final_trans"].cpu() - want["final_trans"]).abs().max() < 1e-4
+
+
+def test_checkpoint_sigma_overrides_constructor():
+    model = PointDSC(**dict(KW, sigma_d=0.5))
+    sd = synthetic.make_state_dict(model.state_dict(), seed=6)
+    sd["sigma_spat"] = torch.tensor([0.1])                # the snapshot's value wins (reference note 3)
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    c = case(1000)
+    res = _forward(model, c["pair"])
+    assert torch.equal(res["final_labels"].cpu(), c["res"]["final_labels"])
+
+
+def test_inputs_are_not_mutated_and_errors_are_loud():
+    c = case(257)
+    data = {k: g(c["pair"][k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    keep = {k: v.clone() for k, v in data.items()}
+    data["testing"] = True
+    c["model"](data)
+    torch.cuda.synchronize()
+    assert all(torch.equal(data[k], keep[k]) for k in keep)
+    with pytest.raises(RuntimeError, match="unsupported problem size"):
+        c["model"]({"corr_pos": g(torch.zeros(1, 5, 6)), "src_keypts": g(torch.zeros(1, 5, 3)),
+                    "tgt_keypts": g(torch.zeros(1, 5, 3)), "testing": True})
+    with pytest.raises(RuntimeError, match="K="):
+        ops.linear(g(torch.zeros(4, 12)), g(torch.zeros(4, 12)))
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE.json size (N=5000, 4 pairs per GPU): size-independent properties
+# ------------------------------------------------------------------------------------------------------
+def test_full_size_batch_properties():
+    n, bs = 5000, 4
+    c = case(1000)
+    model = c["model"]
+    batch = synthetic.make_batch(bs, n, seed=1000, inlier_ratio=0.2)
+    res = _forward(model, batch)
+    T = res["final_trans"].cpu().double()
+    R = T[:, :3, :3]
+    assert (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5
+    assert (torch.det(R) - 1).abs().max() < 1e-5 and torch.equal(T[:, 3], torch.tensor([[0, 0, 0, 1.0]] * bs, dtype=torch.float64))
+    lab = res["final_labels"].cpu()
+    assert set(lab.unique().tolist()) <= {0.0, 1.0}
+    init = model.workspace_view("initial_trans", bs, n)[: bs * 16].reshape(bs, 4, 4).cpu()
+    for i in range(bs):
+        # labels are exactly the inliers of the pre-refinement best hypothesis (reference note 1)
+        L2 = O.residuals(init[i:i + 1], batch["src_keypts"][i], batch["tgt_keypts"][i])[0]
+        assert torch.equal(lab[i], (L2 < KW["inlier_threshold"]).float())
+        re, te = O.registration_errors(res["final_trans"][i].cpu(), batch["gt_trans"][i])
+        assert re < 1.0 and te < 5.0
+        tp = float((lab[i] * batch["gt_labels"][i]).sum())
+        assert tp / float(batch["gt_labels"][i].sum()) > 0.95 and tp / float(lab[i].sum()) > 0.95
+    # permutation equivariance: shuffling the correspondences permutes the labels and keeps the pose
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    shuf = {k: batch[k][:1, perm] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    res2 = _forward(model, shuf)
+    assert (res2["final_trans"][0].cpu() - res["final_trans"][0].cpu()).abs().max() < 2e-3
+    assert float((res2["final_labels"][0].cpu() != lab[0][perm]).float().mean()) < 0.01
