@@ -39,6 +39,33 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA p
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline_worker(num_corr: int, pairs: int, threads: int) -> None:
+    """Child process: time the CPU oracle on `pairs` pairs of the bench workload; prints one JSON line."""
+    from oracle import pointdsc_oracle as O
+    from pointdsc_amd import PointDSC, synthetic
+    torch.set_num_threads(threads)
+    model = PointDSC(**MODEL_KW)
+    sd = synthetic.make_state_dict(model.state_dict(), seed=6)
+    batch = synthetic.make_batch(pairs, num_corr, seed=1000, inlier_ratio=0.2)
+    okw = {k: MODEL_KW[k] for k in ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold",
+                                   "k", "nms_radius")}
+    with torch.no_grad():
+        first = O.forward_testing(sd, batch["corr_pos"][:1], batch["src_keypts"][:1], batch["tgt_keypts"][:1], **okw)
+        t1 = time.perf_counter()
+        for i in range(pairs):
+            O.forward_testing(sd, batch["corr_pos"][i:i + 1], batch["src_keypts"][i:i + 1], batch["tgt_keypts"][i:i + 1], **okw)
+        dt = time.perf_counter() - t1
+    print(json.dumps({"pairs_per_s": pairs / dt, "seconds": dt, "threads": threads,
+                      "first_trans": first["final_trans"][0].tolist()}), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,12 +75,18 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=4, help="batch per GPU per step (32 pairs / 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (bounded sample)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all host cores)")
+    ap.add_argument("--cpu-timeout", type=float, default=240.0, help="wall-clock cap for the CPU baseline leg")
     ap.add_argument("--check", action="store_true", help="also verify rank-0's first pair against the oracle")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.num_corr, args.cpu_pairs, args.cpu_threads or (os.cpu_count() or 1))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,9 +116,11 @@ def main():
             res = model(data)
         return sharding.gather_results(res["final_trans"], None, total_pairs)
 
+    log(f"rank {rank}: model + {B} pairs (N={N}) resident on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    log("warm-up done; timing")
 
     n_att = args.steps * MODEL_KW["num_layers"]
     _lib.check(lib.pdsc_profile_enable(n_att + 8), "pdsc_profile_enable")
@@ -100,6 +135,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,28 +195,32 @@ def main():
         except Exception:
             pass
 
-    # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N=1 only) ----
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N=1 only), in a child
+    #      process with a wall-clock cap so the bench always finishes ----
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import pointdsc_oracle as O
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        okw = {k: MODEL_KW[k] for k in ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold",
-                                       "k", "nms_radius")}
-        cpu_batch = {k: batch[k][:1] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
-        with torch.no_grad():
-            ref0 = O.forward_testing(sd, cpu_batch["corr_pos"], cpu_batch["src_keypts"], cpu_batch["tgt_keypts"], **okw)  # warm-up
-            n_cpu = max(1, min(args.cpu_pairs, B))
-            t1 = time.perf_counter()
-            for i in range(n_cpu):
-                O.forward_testing(sd, batch["corr_pos"][i:i + 1], batch["src_keypts"][i:i + 1],
-                                  batch["tgt_keypts"][i:i + 1], **okw)
-            cpu_s = time.perf_counter() - t1
-        line["cpu_baseline"] = {"value": round(n_cpu / cpu_s, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
-                                "sample": "%d pair(s) of the same N=%d workload after 1 warm-up, torch-CPU oracle "
-                                          "(oracle/pointdsc_oracle.py), %d intra-op threads" % (n_cpu, N, cores)}
-        if args.check:
-            dT = float((out["final_trans"][0].cpu() - ref0["final_trans"][0]).abs().max())
-            line["check"] = {"max_abs_dT_vs_oracle": dT}
+        import subprocess
+        cores = args.cpu_threads or (os.cpu_count() or 1)
+        n_cpu = max(1, min(args.cpu_pairs, B))
+        log(f"CPU baseline: oracle on {n_cpu} pair(s), {cores} threads (cap {args.cpu_timeout:.0f}s)")
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-worker", "--num-corr", str(N),
+               "--cpu-pairs", str(n_cpu), "--cpu-threads", str(cores)]
+        sample = ("%d pair(s) of the same N=%d workload after 1 warm-up, torch-CPU oracle "
+                  "(oracle/pointdsc_oracle.py), %d intra-op threads" % (n_cpu, N, cores))
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout)
+            cj = json.loads(r.stdout.strip().splitlines()[-1])
+            line["cpu_baseline"] = {"value": round(cj["pairs_per_s"], 4), "unit": "pairs/s", "cores": cores,
+                                    "kind": "port", "sample": sample}
+            if args.check:
+                dT = float((out["final_trans"][0].cpu() - torch.tensor(cj["first_trans"])).abs().max())
+                line["check"] = {"max_abs_dT_vs_oracle": dT}
+        except subprocess.TimeoutExpired:
+            line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                    "sample": sample + " -- did not finish within %.0fs" % args.cpu_timeout}
+        except Exception as e:  # noqa: BLE001
+            line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                    "sample": sample + " -- failed: %r" % (e,)}
+        log("CPU baseline done")
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -213,7 +213,7 @@ extern "C" int pdsc_seed_transforms(const float* src, const float* tgt, const in
 
 extern "C" int pdsc_rigid_transform_3d(const float* A, const float* B, const float* weights, float weight_threshold,
                                        float* T, int bs, int n, void* stream) {
-    PDSC_REQUIRE(A && B && T, "pdsc_rigid_transform_3d: null pointer");
+    PDSC_REQUIRE(T && (n == 0 || (A && B)), "pdsc_rigid_transform_3d: null pointer");
     PDSC_REQUIRE(bs > 0 && n >= 0, "pdsc_rigid_transform_3d: bs=%d n=%d", bs, n);
     hipLaunchKernelGGL(pdsc::rigid_transform_kernel, dim3(bs), dim3(256), 0, (hipStream_t)stream, A, B, weights,
                        weight_threshold, T, n);
