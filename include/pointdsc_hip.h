@@ -117,6 +117,17 @@ int pdsc_linear(const float* X, long long ldx, const float* W, const float* bias
 int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat,
                 int M, void* stream);
 
+/* Fused point-wise chain between two attention calls (one launch instead of five pdsc_linear calls):
+ *   tail (msg != NULL):      feat = res + fc3(relu(fc2(relu(fc1(msg)))))            models/PointDSC.py:43-45
+ *   head (featB_out != NULL): featB = relu(pcn(feat)); qkv = Wqkv featB + bqkv       models/PointDSC.py:75,36-38
+ * tail only -> feat_out required; head only -> feat_in required.  All matrices [out][in], BN folded
+ * (sections PDSC_W_FC1..FC3 of layer i, PDSC_W_PCN/QKV of layer i+1).  Buffers must not alias. */
+int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, float* feat_out,
+                     float* featB_out, float* qkv_out,
+                     const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* w3, const float* b3, const float* wp, const float* bp,
+                     const float* wq, const float* bq, int M, void* stream);
+
 /* ---- a-3  spatial-consistency guided non-local attention ---------------------------------------
  * replaces models/PointDSC.py:39-42 (both einsums and the softmax; N x N scores never materialised).
  *   msg[o][:] = sum_i softmax_i( compat[o][i] * <Q_o, K_i> / sqrt(C) ) * V_i

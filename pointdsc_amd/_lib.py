@@ -49,6 +49,7 @@ SIGNATURES = {
     "pdsc_spatial_compat": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "pdsc_layer_fused": (_i, [_vp] * 16 + [_i, _vp]),
     "pdsc_attention_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_default_split": (_i, [_i, _i]),
     "pdsc_sc_attention": (_i, [_vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),

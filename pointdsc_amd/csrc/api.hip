@@ -3,6 +3,7 @@
 // models/PointDSC.py:128-197).  Pure HIP runtime -- no torch types cross this boundary.  Every stage is
 // enqueued on the caller's stream with no host synchronisation, so one forward is hipGraph-capturable.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include "pdsc_common.h"
 
@@ -134,6 +135,7 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("compat", (size_t)bs * N * ld * f);
     L.add("featA", M * C * f);
     L.add("featB", M * C * f);
+    L.add("featC", M * C * f);
     L.add("qkv", M * 3 * C * f);
     L.add("msg", M * C * f);
     L.add("t64a", M * (C / 2) * f);
@@ -250,7 +252,7 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     const int C = PDSC_CHANNELS, M = bs * N, S = num_seeds;
     const int k = cfg->k < N - 1 ? cfg->k : N - 1;
     const long long ld = pdsc_compat_ld(N);
-    float *compat = F("compat"), *featA = F("featA"), *featB = F("featB"), *qkv = F("qkv"), *msg = F("msg");
+    float *compat = F("compat"), *featA = F("featA"), *featB = F("featB"), *featC = F("featC"), *qkv = F("qkv"), *msg = F("msg");
     float *t64a = F("t64a"), *t64b = F("t64b"), *normed = F("normed"), *h1 = F("h1"), *h2 = F("h2");
     float *conf = F("conf"), *keys = F("keys"), *knn_dist = F("knn_dist"), *eig = F("eig_iters");
     float *seed_trans = F("seed_trans"), *seed_w = F("seed_w"), *initial = F("initial_trans");
@@ -262,6 +264,29 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     // Step 1 (models/PointDSC.py:150-155): compat, then the SCNonlocal encoder
     PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
     PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
+    static int fused = -1;
+    if (fused < 0) {
+        const char* env = getenv("PDSC_FUSED_LAYERS");          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
+        fused = env ? atoi(env) : 1;
+    }
+    if (fused && cfg->num_layers > 0) {
+        // head of layer 0, then per layer: attention + (tail of layer i fused with head of layer i+1)
+        PDSC_TRY(pdsc_layer_fused(nullptr, nullptr, featA, nullptr, featB, qkv, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0), W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), M,
+                                  stream));
+        float *cur = featB, *nxt = featC;
+        for (int i = 0; i < cfg->num_layers; ++i) {
+            PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            const bool last = i + 1 == cfg->num_layers;
+            PDSC_TRY(pdsc_layer_fused(msg, cur, nullptr, last ? featA : nullptr, last ? nullptr : nxt, last ? nullptr : qkv,
+                                      W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
+                                      W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
+                                      last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
+                                      last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1), M,
+                                      stream));
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+    } else
     for (int i = 0; i < cfg->num_layers; ++i) {
         PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_PCN_W, i), W(PDSC_W_PCN_B, i), nullptr, 0, featB, C, M, C, C, 1, stream));
         PDSC_TRY(pdsc_linear(featB, C, W(PDSC_W_QKV_W, i), W(PDSC_W_QKV_B, i), nullptr, 0, qkv, 3 * C, M, C, 3 * C, 0, stream));

@@ -21,10 +21,12 @@
 // image is XOR-swizzled through the SOURCE address (chunk ^= row&15) so the column-slice ds_read_b128 of
 // 16 different rows hits 16 different bank slots.  Q is pre-scaled by log2(e)/sqrt(C) in the packed weights,
 // so p = exp2(compat*s - m).
+#include <stdlib.h>
 #include "pdsc_common.h"
 
 namespace pdsc {
 
+#define PDSC_ATT_DEFAULT_VARIANT 1
 constexpr int ATT_BQ = 128;
 constexpr int ATT_BK = 32;
 constexpr int ATT_C = PDSC_CHANNELS;
@@ -60,6 +62,9 @@ __device__ __forceinline__ void issue_tile_loads(const float* __restrict__ kbase
     }
 }
 
+// PIPE = 0: operand fragments read right before use (compiler-scheduled);
+// PIPE = 1: K/V fragment reads run two ds_read_b128 ahead of the MFMAs that consume them (explicit ring).
+template <int PIPE>
 __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // K0 K1 V0 V1, 16 KiB each
     const int t = threadIdx.x, lane = t & 63;
@@ -105,16 +110,9 @@ __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
         // tile kt landed (own LDS-DMA pieces) + everyone finished reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        f32x4 cn[4];
-        if (kt + 1 < kt1) {
+        if (kt + 1 < kt1)
             issue_tile_loads(kbase, vbase, (kt + 1) * ATT_BK, N, lds + (buf ^ 1) * ATT_TILE_FLOATS,
                              lds + (2 + (buf ^ 1)) * ATT_TILE_FLOATS, wave, lane);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const f32x4*>(crow + (kt + 1) * ATT_BK + 8 * g);
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cn[g] = cc[g];
-        }
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------
         f32x16 s;
@@ -122,17 +120,38 @@ __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const float* krow_p = Kb + l31 * ATT_C;
         const int ksw = l31 & 15;
+        if (PIPE == 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(krow_p + (((2 * q + h) ^ ksw) << 2));
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(krow_p + (((2 * q + h) ^ ksw) << 2));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[q][e], s, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[q][e], s, 0, 0, 0);
+            }
+        } else {
+            f32x4 kr[4];
+            kr[0] = *reinterpret_cast<const f32x4*>(krow_p + (((0 + h) ^ ksw) << 2));
+            kr[1] = *reinterpret_cast<const f32x4*>(krow_p + (((2 + h) ^ ksw) << 2));
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                if (q + 2 < 16) {
+                    kr[(q + 2) & 3] = *reinterpret_cast<const f32x4*>(krow_p + (((2 * (q + 2) + h) ^ ksw) << 2));
+                    kr[(q + 3) & 3] = *reinterpret_cast<const f32x4*>(krow_p + (((2 * (q + 3) + h) ^ ksw) << 2));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[q & 3][e], qf[q][e], s, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[(q + 1) & 3][e], qf[q + 1][e], s, 0, 0, 0);
+            }
         }
 
         // ---- online softmax (log2 domain), lane-local: this lane = query l31, keys (r&3)+8(r>>2)+4h ----
         float x[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = cc[r >> 2][r & 3] * s[r];
+        if (kt + 1 < kt1) {   // compat of the NEXT tile into the registers just consumed: a whole PV + QK phase to land
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const f32x4*>(crow + (kt + 1) * ATT_BK + 8 * g);
+        }
         if ((kt + 1) * ATT_BK > N) {   // tail tile (wave-uniform branch)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -164,15 +183,31 @@ __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
 
         // ---- O^T += V^T P^T ----------------------------------------------------------------------
         const float* vcol = Vb + 4 * l31;
+        if (PIPE == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const f32x4 va = *reinterpret_cast<const f32x4*>(vcol + key * ATT_C);
+            for (int r = 0; r < 16; ++r) {
+                const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const f32x4 va = *reinterpret_cast<const f32x4*>(vcol + key * ATT_C);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c], x[r], o[c], 0, 0, 0);
+                for (int c = 0; c < 4; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c], x[r], o[c], 0, 0, 0);
+            }
+        } else {
+            const float* vh = vcol + 4 * h * ATT_C;
+            f32x4 vr[4];
+            vr[0] = *reinterpret_cast<const f32x4*>(vh + 0 * ATT_C);
+            vr[1] = *reinterpret_cast<const f32x4*>(vh + 1 * ATT_C);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                if (r + 2 < 16) {
+                    vr[(r + 2) & 3] = *reinterpret_cast<const f32x4*>(vh + (((r + 2) & 3) + 8 * ((r + 2) >> 2)) * ATT_C);
+                    vr[(r + 3) & 3] = *reinterpret_cast<const f32x4*>(vh + (((r + 3) & 3) + 8 * ((r + 3) >> 2)) * ATT_C);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[r & 3][c], x[r], o[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[(r + 1) & 3][c], x[r + 1], o[c], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cc[g] = cn[g];
     }
 
     // ---- epilogue: o[c][r] = O^T[channel 4*i+c][query l31], i = (r&3)+8(r>>2)+4h ------------------
@@ -275,15 +310,21 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * pdsc::ATT_C : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = 4 * pdsc::ATT_TILE_FLOATS * sizeof(float);   // 64 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_done = true;
+    static int variant = -1;
+    if (variant < 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        const char* env = getenv("PDSC_ATT_VARIANT");       // tuning/A-B knob; default = shipped variant
+        variant = env ? atoi(env) : PDSC_ATT_DEFAULT_VARIANT;
     }
     dim3 grid(pdsc::ceil_div(N, pdsc::ATT_BQ), nsplit, bs);
     pdsc::profile_mark_begin(PDSC_PROF_ATTENTION, st);
-    hipLaunchKernelGGL(pdsc::sc_attention_kernel, grid, dim3(256), lds_bytes, st, a);
+    if (variant == 0)
+        hipLaunchKernelGGL(pdsc::sc_attention_kernel<0>, grid, dim3(256), lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL(pdsc::sc_attention_kernel<1>, grid, dim3(256), lds_bytes, st, a);
     pdsc::profile_mark_end(PDSC_PROF_ATTENTION, st);
     int rc = pdsc::check_launch("pdsc_sc_attention");
     if (rc != PDSC_OK) return rc;

@@ -1,0 +1,199 @@
+// a-2 fused: the whole point-wise chain between two attention calls in ONE launch
+//   tail of layer i   : feat  = featB + fc3( relu(fc2'( relu(fc1'(msg)) )) )         (fc_message, BN folded; reference
+//                                                                                      models/PointDSC.py:43-45)
+//   head of layer i+1 : featB = relu(pcn'(feat)) ; (q|k|v) = Wqkv featB + b            (models/PointDSC.py:75, :36-38)
+// The five GEMMs of a 32-point tile run back to back in one 4-wave workgroup: activations never leave the
+// CU (two 32x132 LDS tiles, ping-pong), each wave owns whole 32-column output tiles and reads the weight rows
+// of its tile straight from L2 into registers (a weight tile is used by exactly one wave of the workgroup, so
+// staging it in LDS would buy nothing), the next stage's weights are prefetched under the current stage's MFMAs.
+// MFMA orientation: D = W_tile (A, rows = output channels) x X^T (B, columns = points), so the accumulator
+// lane is a point and register r = 4g+e holds output channel n0+8g+4h+e: one float4 per (g) goes to LDS / HBM.
+// Bound: MFMA (172 kFLOP per point per layer on v_mfma_f32_32x32x2_f32); weights stream from L2 (336 KB per tile).
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+constexpr int LF_ROWS = 32;                  // points per workgroup
+constexpr int LF_LD = PDSC_CHANNELS + 4;     // padded LDS row (floats)
+constexpr int LF_TILE = LF_ROWS * LF_LD;
+
+struct LayerArgs {
+    const float* msg;        // [M][128]  attention output            (tail)
+    const float* res;        // [M][128]  featB of this layer         (tail residual)
+    const float* feat_in;    // [M][128]  used when there is no tail  (first head)
+    float* feat_out;         // [M][128]  tail result, written when non-null
+    float* featB_out;        // [M][128]  head
+    float* qkv_out;          // [M][384]  head
+    const float *w1, *b1, *w2, *b2, *w3, *b3;      // fc1 [64][128], fc2 [64][64], fc3 [128][64]
+    const float *wp, *bp, *wq, *bq;                // pcn [128][128], qkv [384][128]
+    int M;
+};
+
+template <int K>
+__device__ __forceinline__ void load_w(const float* __restrict__ W, int n0, int l31, int h, f32x4 (&w)[K / 8]) {
+    const float* p = W + (size_t)(n0 + l31) * K + 4 * h;
+#pragma unroll
+    for (int q = 0; q < K / 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+}
+
+template <int K>
+__device__ __forceinline__ void load_x(const float* Xs, int l31, int h, f32x4 (&x)[K / 8]) {
+    const float* p = Xs + l31 * LF_LD + 4 * h;
+#pragma unroll
+    for (int q = 0; q < K / 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+}
+
+template <int K>
+__device__ __forceinline__ f32x16 mma_tile(const f32x4 (&w)[K / 8], const f32x4 (&x)[K / 8]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < K / 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][e], x[q][e], acc, 0, 0, 0);
+    return acc;
+}
+
+// acc -> (+bias)(relu)(+residual row from HBM) -> LDS tile Xo[point][col0 + 8g+4h .. +3]
+template <bool RELU, bool RESID>
+__device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias, int n0, float* Xo, int col0,
+                                           int l31, int h, const float* __restrict__ res_row) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 8 * g + 4 * h);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = acc[4 * g + e] + bv[e];
+            if (RELU) t = fmaxf(t, 0.f);
+            v[e] = t;
+        }
+        if (RESID) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(res_row + n0 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
+        }
+        *reinterpret_cast<f32x4*>(Xo + l31 * LF_LD + col0 + 8 * g + 4 * h) = v;
+    }
+}
+
+// coalesced copies between a 32x128 LDS tile and row-major global memory (ld floats per row)
+__device__ __forceinline__ void tile_to_global(const float* Xs, float* __restrict__ dst, long long ld, int m0, int M, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i, row = f >> 5, c4 = f & 31;
+        if (m0 + row < M)
+            *reinterpret_cast<f32x4*>(dst + (size_t)(m0 + row) * ld + 4 * c4) = *reinterpret_cast<const f32x4*>(Xs + row * LF_LD + 4 * c4);
+    }
+}
+__device__ __forceinline__ void global_to_tile(const float* __restrict__ src, float* Xs, int m0, int M, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i, row = f >> 5, c4 = f & 31;
+        const int m = min(m0 + row, M - 1);
+        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)m * PDSC_CHANNELS + 4 * c4);
+    }
+}
+
+template <bool HAS_TAIL, bool HAS_HEAD>
+__global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float Xa[LF_TILE];
+    __shared__ __attribute__((aligned(16))) float Xb[LF_TILE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * LF_ROWS;
+    const int M = a.M;
+
+    if (HAS_TAIL) {
+        f32x4 w128[16], w64[8];
+        // ---- fc1: 128 -> 64 (+BN, ReLU): tiles {0,1} on waves {0,1} ----
+        if (wave < 2) load_w<128>(a.w1, 32 * wave, l31, h, w128);
+        global_to_tile(a.msg, Xa, m0, M, t);
+        __syncthreads();
+        if (wave < 2) {
+            f32x4 x[16];
+            load_x<128>(Xa, l31, h, x);
+            load_w<64>(a.w2, 32 * wave, l31, h, w64);                 // prefetch fc2 weights
+            const f32x16 acc = mma_tile<128>(w128, x);
+            store_tile<true, false>(acc, a.b1, 32 * wave, Xb, 32 * wave, l31, h, nullptr);
+        }
+        __syncthreads();
+        // ---- fc2: 64 -> 64 (+BN, ReLU) ----
+        f32x4 w3r[8];
+        load_w<64>(a.w3, 32 * wave, l31, h, w3r);                     // prefetch fc3 weights (all waves)
+        if (wave < 2) {
+            f32x4 x[8];
+            load_x<64>(Xb, l31, h, x);
+            const f32x16 acc = mma_tile<64>(w64, x);
+            store_tile<true, false>(acc, a.b2, 32 * wave, Xa, 32 * wave, l31, h, nullptr);
+        }
+        __syncthreads();
+        // ---- fc3: 64 -> 128, + residual featB: tile = wave ----
+        {
+            f32x4 x[8];
+            load_x<64>(Xa, l31, h, x);
+            const f32x16 acc = mma_tile<64>(w3r, x);
+            const float* res_row = a.res + (size_t)min(m0 + l31, M - 1) * PDSC_CHANNELS;
+            store_tile<false, true>(acc, a.b3, 32 * wave, Xb, 32 * wave, l31, h, res_row);
+        }
+        __syncthreads();
+        if (a.feat_out) tile_to_global(Xb, a.feat_out, PDSC_CHANNELS, m0, M, t);
+    } else {
+        global_to_tile(a.feat_in, Xb, m0, M, t);
+        __syncthreads();
+    }
+
+    if (HAS_HEAD) {
+        // ---- PointCN: 128 -> 128 (+BN, ReLU): tile = wave; input Xb, output Xa ----
+        f32x4 w[16], x[16];
+        load_w<128>(a.wp, 32 * wave, l31, h, w);
+        load_x<128>(Xb, l31, h, x);
+        {
+            const f32x16 acc = mma_tile<128>(w, x);
+            load_w<128>(a.wq, 32 * wave, l31, h, w);                  // prefetch first qkv tile
+            store_tile<true, false>(acc, a.bp, 32 * wave, Xa, 32 * wave, l31, h, nullptr);
+        }
+        __syncthreads();
+        tile_to_global(Xa, a.featB_out, PDSC_CHANNELS, m0, M, t);
+        load_x<128>(Xa, l31, h, x);
+        // ---- q|k|v: 128 -> 384 in three 128-column chunks staged through Xb ----
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int n0 = 128 * c + 32 * wave;
+            const f32x16 acc = mma_tile<128>(w, x);
+            if (c < 2) load_w<128>(a.wq, n0 + 128, l31, h, w);        // prefetch next chunk's tile
+            store_tile<false, false>(acc, a.bq, n0, Xb, 32 * wave, l31, h, nullptr);
+            __syncthreads();
+            tile_to_global(Xb, a.qkv_out + 128 * c, 3 * PDSC_CHANNELS, m0, M, t);
+            if (c < 2) __syncthreads();
+        }
+    }
+}
+
+template <bool T, bool H>
+static int launch_layer(const LayerArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((layer_fused_kernel<T, H>), dim3(ceil_div(a.M, LF_ROWS)), dim3(256), 0, st, a);
+    return check_launch("pdsc_layer_fused");
+}
+
+}  // namespace pdsc
+
+extern "C" int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, float* feat_out,
+                                float* featB_out, float* qkv_out, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, const float* wp, const float* bp,
+                                const float* wq, const float* bq, int M, void* stream) {
+    const bool tail = msg != nullptr, head = featB_out != nullptr;
+    PDSC_REQUIRE(tail || head, "pdsc_layer_fused: neither tail (msg) nor head (featB_out) requested");
+    PDSC_REQUIRE(M > 0, "pdsc_layer_fused: M=%d", M);
+    if (tail) PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused: tail needs res, fc1..fc3");
+    else PDSC_REQUIRE(feat_in, "pdsc_layer_fused: head-only needs feat_in");
+    if (head) PDSC_REQUIRE(qkv_out && wp && bp && wq && bq, "pdsc_layer_fused: head needs qkv_out, pcn, qkv weights");
+    else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
+    pdsc::LayerArgs a{msg, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3, wp, bp, wq, bq, M};
+    hipStream_t st = (hipStream_t)stream;
+    if (tail && head) return pdsc::launch_layer<true, true>(a, st);
+    if (tail) return pdsc::launch_layer<true, false>(a, st);
+    return pdsc::launch_layer<false, true>(a, st);
+}

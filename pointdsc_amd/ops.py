@@ -74,6 +74,24 @@ def layer0(corr_pos: torch.Tensor, w0_padded: torch.Tensor, b0: torch.Tensor) ->
     return y
 
 
+def layer_fused(msg, res, feat_in, tail_w=None, head_w=None, want_feat=False):
+    """Fused point-wise chain (pdsc_layer_fused).  tail_w = (w1,b1,w2,b2,w3,b3) folded fc_message of layer i,
+    head_w = (wp,bp,wq,bq) folded PointCN / stacked qkv of layer i+1.  Returns (feat or None, featB or None, qkv or None)."""
+    lib = _lib.load()
+    src = msg if msg is not None else feat_in
+    m, dev = src.shape[0], src.device
+    tail = [_chk(w, "tail_w") for w in tail_w] if tail_w is not None else [None] * 6
+    head = [_chk(w, "head_w") for w in head_w] if head_w is not None else [None] * 4
+    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if (want_feat or head_w is None) else None
+    featB = torch.empty(m, 128, device=dev, dtype=torch.float32) if head_w is not None else None
+    qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if head_w is not None else None
+    args = [_p(_chk(msg, "msg")) if msg is not None else None, _p(_chk(res, "res")) if res is not None else None,
+            _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB), _p(qkv)]
+    args += [_p(w) for w in tail] + [_p(w) for w in head]
+    _lib.check(lib.pdsc_layer_fused(*args, m, _stream()), "pdsc_layer_fused")
+    return feat, featB, qkv
+
+
 def sc_attention(qkv: torch.Tensor, compat: torch.Tensor, bs: int, n: int, nsplit: int = 0) -> torch.Tensor:
     """qkv [bs*N,384] (q pre-scaled by log2(e)/sqrt(128)), compat [bs,N,ld] -> msg [bs*N,128]."""
     lib = _lib.load()

@@ -105,6 +105,30 @@ def test_layer0_matches_oracle():
     assert (y - want).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 1000])
+def test_layer_fused_matches_fp64_chain(m):
+    """pdsc_layer_fused (tail+head, head only, tail only) vs the five GEMMs in fp64."""
+    gen = torch.Generator().manual_seed(m)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    msg, res = rnd(m, 128), rnd(m, 128)
+    w1, b1, w2, b2, w3, b3 = rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128)
+    wp, bp, wq, bq = rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384)
+    d = lambda t: t.double()  # noqa: E731
+    feat = d(res) + (torch.relu(torch.relu(d(msg) @ d(w1).T + d(b1)) @ d(w2).T + d(b2)) @ d(w3).T + d(b3))
+    featB = torch.relu(feat @ d(wp).T + d(bp))
+    qkv = featB @ d(wq).T + d(bq)
+    tail_w, head_w = [g(x) for x in (w1, b1, w2, b2, w3, b3)], [g(x) for x in (wp, bp, wq, bq)]
+    tol = lambda want: 3e-6 * max(1.0, float(want.abs().max()))  # noqa: E731
+    f, fb, q = ops.layer_fused(g(msg), g(res), None, tail_w, head_w, want_feat=True)
+    assert (f.cpu().double() - feat).abs().max() < tol(feat)
+    assert (fb.cpu().double() - featB).abs().max() < tol(featB)
+    assert (q.cpu().double() - qkv).abs().max() < 2 * tol(qkv)
+    f2, fb2, q2 = ops.layer_fused(g(msg), g(res), None, tail_w, None)
+    assert fb2 is None and q2 is None and torch.equal(f2, f)
+    _, fb3, q3 = ops.layer_fused(None, None, f, None, head_w)
+    assert torch.equal(fb3, fb) and torch.equal(q3, q)
+
+
 # ------------------------------------------------------------------------------------------------------
 # a-3 attention
 # ------------------------------------------------------------------------------------------------------
