@@ -13,7 +13,9 @@ namespace pdsc {
 constexpr int CT_ROWS = 64;    // rows per workgroup tile
 constexpr int CT_COLS = 256;   // columns per workgroup tile (64 lanes x float4)
 
-template <bool WRITE_DIST>
+// CHEAP = timing probe only (tools/kernel_microbench.py): skips the sqrt/divide so that the store path can be
+// measured in isolation; never used by the product path.
+template <bool WRITE_DIST, bool CHEAP = false>
 __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
                                                      const float* __restrict__ sigma_spat,
                                                      float* __restrict__ compat, float* __restrict__ src_dist,
@@ -55,10 +57,16 @@ __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ s
         f32x4 o, dd;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float ds = norm3(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
-            const float dt = norm3(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
-            const float df = ds - dt;
-            const float v = fmaxf(1.0f - (df * df) / s2, 0.0f);
+            float ds, v;
+            if (CHEAP) {
+                ds = ps[0] - sx[c];
+                v = fmaxf(ds + (pt[0] - tx[c]) * s2, 0.0f);
+            } else {
+                ds = norm3(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
+                const float dt = norm3(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
+                const float df = ds - dt;
+                v = fmaxf(1.0f - (df * df) / s2, 0.0f);
+            }
             const bool valid = (jc + c) < N;
             o[c] = valid ? v : 0.0f;
             dd[c] = valid ? ds : 0.0f;
@@ -76,6 +84,7 @@ __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ s
 constexpr int CS_T = 128;
 constexpr int CS_LD = CS_T + 4;
 
+template <bool SKIP_TRANSPOSE = false>   // true = timing probe only (wrong lower triangle), never shipped
 __global__ __launch_bounds__(256, 2) void compat_sym_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
                                                             const float* __restrict__ sigma_spat, float* __restrict__ compat,
                                                             long long ld, int N) {
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void compat_sym_kernel(const float* __restr
         if (i < N && jc < ld) *reinterpret_cast<f32x4*>(outb + (size_t)i * ld + jc) = o;
         if (offdiag) *reinterpret_cast<f32x4*>(Ts + il * CS_LD + 4 * l32) = o;
     }
-    if (!offdiag) return;
+    if (!offdiag || SKIP_TRANSPOSE) return;
     __syncthreads();
     // transposed copy: element (i,j) of this tile -> compat[j][i]
     const int il = t & 127, jr = t >> 7;
@@ -156,15 +165,24 @@ extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const flo
     static int variant = -1;
     const size_t sym_lds = (size_t)(pdsc::CS_T * pdsc::CS_LD + pdsc::CS_T * 8) * sizeof(float);
     if (variant < 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::compat_sym_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::compat_sym_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sym_lds);
-        const char* env = getenv("PDSC_COMPAT_VARIANT");    // tuning/A-B knob: 0 = full tiles, 1 = symmetric
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::compat_sym_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sym_lds);
+        // tuning/A-B knob: 0 = full tiles, 1 = symmetric (shipped); 2, 3 = TIMING PROBES that produce wrong values
+        // (2: symmetric without the transposed stores, 3: full tiles without sqrt/divide)
+        const char* env = getenv("PDSC_COMPAT_VARIANT");
         variant = env ? atoi(env) : 1;
     }
     pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
-    if (variant == 1 && !src_dist) {
+    if ((variant == 1 || variant == 2) && !src_dist) {
         const int nt = pdsc::ceil_div(N, pdsc::CS_T);
-        hipLaunchKernelGGL(pdsc::compat_sym_kernel, dim3(nt, nt, bs), dim3(256), sym_lds, st, src, tgt, sigma_spat, compat, ld, N);
+        if (variant == 1)
+            hipLaunchKernelGGL(pdsc::compat_sym_kernel<false>, dim3(nt, nt, bs), dim3(256), sym_lds, st, src, tgt, sigma_spat, compat, ld, N);
+        else
+            hipLaunchKernelGGL(pdsc::compat_sym_kernel<true>, dim3(nt, nt, bs), dim3(256), sym_lds, st, src, tgt, sigma_spat, compat, ld, N);
+    } else if (variant == 3 && !src_dist) {
+        hipLaunchKernelGGL((pdsc::compat_kernel<false, true>), grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
     } else if (src_dist)
         hipLaunchKernelGGL(pdsc::compat_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, src_dist, ld, N);
     else

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--att-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--compat-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     import torch
     from pointdsc_amd import ops, synthetic, PointDSC
@@ -75,9 +76,20 @@ def main():
                         lambda: ops.sc_attention(qkv, compat, bs, n, nsplit=nsplit), args.iters, args.rounds, flops, "TFLOP/s")
         return
 
+    if args.compat_child:
+        bench_stage(f"compat[variant={os.environ.get('PDSC_COMPAT_VARIANT', 'default')}]",
+                    lambda: ops.spatial_compat(src, tgt, sig), args.iters, args.rounds, (4.0 * n * n + 24.0 * n) * bs, "TB/s")
+        return
     if want("compat"):
-        bench_stage("compat", lambda: ops.spatial_compat(src, tgt, sig), args.iters, args.rounds,
-                    (4.0 * n * n + 24.0 * n) * bs, "TB/s")
+        buf = torch.empty(bs, n, ops.compat_ld(n), device=dev)
+        buf2 = torch.empty_like(buf)
+        nbytes = float(buf.numel() * 4)
+        bench_stage("hbm_fill(torch.fill_)", lambda: buf.fill_(1.0), args.iters, args.rounds, nbytes, "TB/s")
+        bench_stage("hbm_copy(torch.copy_, read+write bytes)", lambda: buf2.copy_(buf), args.iters, args.rounds, 2 * nbytes, "TB/s")
+        for variant in os.environ.get("PDSC_MB_COMPAT_VARIANTS", "0,1").split(","):
+            env = dict(os.environ, PDSC_COMPAT_VARIANT=variant)
+            subprocess.run([sys.executable, __file__, "--n", str(n), "--bs", str(bs), "--iters", str(args.iters),
+                            "--rounds", str(args.rounds), "--compat-child"], env=env, check=False)
     if want("attention"):
         splits = "0,1,2,3,4,6"
         for variant in ("0", "1"):
@@ -92,6 +104,17 @@ def main():
             b = torch.randn(nout, generator=gen).to(dev)
             bench_stage(f"linear[K={k},Nout={nout}]", lambda: ops.linear(x, w, b, relu=True), args.iters, args.rounds,
                         2.0 * M * k * nout, "TFLOP/s")
+    if want("layer"):
+        rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)  # noqa: E731
+        msg, res = rnd(M, 128), rnd(M, 128)
+        tail_w = [rnd(64, 128), rnd(64), rnd(64, 64), rnd(64), rnd(128, 64), rnd(128)]
+        head_w = [rnd(128, 128), rnd(128), rnd(384, 128), rnd(384)]
+        bench_stage("layer_fused[tail+head]", lambda: ops.layer_fused(msg, res, None, tail_w, head_w), args.iters, args.rounds,
+                    2.0 * M * 86016, "TFLOP/s")
+        bench_stage("layer_fused[head]", lambda: ops.layer_fused(None, None, res, None, head_w), args.iters, args.rounds,
+                    2.0 * M * (16384 + 49152), "TFLOP/s")
+        bench_stage("layer_fused[tail]", lambda: ops.layer_fused(msg, res, None, tail_w, None), args.iters, args.rounds,
+                    2.0 * M * 20480, "TFLOP/s")
     if want("tail"):
         model = PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.1,
                          sigma_d=0.1, k=40, nms_radius=0.1)
