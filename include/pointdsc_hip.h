@@ -103,6 +103,10 @@ size_t pdsc_workspace_bytes(const pdsc_config* cfg, int bs, int N, int num_seeds
 int pdsc_spatial_compat(const float* src_keypts, const float* tgt_keypts, const float* sigma_spat,
                         float* compat, float* src_dist, long long ld, int bs, int N, void* stream);
 
+/* Self-test hook for the two hand-rolled exact primitives of the compat kernel (correctly rounded sqrt, division
+ * by a loop-invariant): sqrt_out[i] = sqrt(x[i]), div_out[i] = x[i] / divisor, both must equal the IEEE results. */
+int pdsc_selftest_exact_math(const float* x, float divisor, float* sqrt_out, float* div_out, long long n, void* stream);
+
 /* ---- a-2  point-wise layers --------------------------------------------------------------------
  * replaces every Conv1d(kernel_size=1)[+BatchNorm1d(eval)][+ReLU] of models/PointDSC.py:12-23,54-61,107-113.
  *   Y[m][n] = act( sum_k X[m][k] * W[n][k] + bias[n] ) (+ residual[m][n])

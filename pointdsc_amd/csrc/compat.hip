@@ -1,26 +1,79 @@
 // a-1: N x N spatial-consistency matrix build (reference models/PointDSC.py:150-153).
 //
-// HBM-write bound: 4*N*ld bytes out, 24*N bytes in.  One workgroup produces a 64-row x 256-column tile;
-// every lane owns 4 consecutive columns (their 8 keypoints live in registers for the whole tile) and walks
-// 16 rows whose keypoints are broadcast from LDS, so each store instruction is one fully coalesced 1 KiB
-// row segment (float4 per lane).  Arithmetic is the reference's, bit for bit: the fma-chained norm of
-// torch.norm, an IEEE division by sigma^2 and the clamp.
+//   compat[i][j] = max(0, 1 - (||s_i - s_j|| - ||t_i - t_j||)^2 / sigma_spat^2)
+//
+// Algorithmic traffic: 4*N*ld bytes out, 24*N bytes in -> HBM-write roofline.  What actually bounds a naive
+// version is the VALU: two correctly rounded square roots and one correctly rounded divide per element (hipcc's
+// IEEE sequences: ~60 VALU ops incl. v_div_scale/fmas/fixup and their VCC wait states); measured on MI355X
+// the store path alone sustains 5.3 TB/s while the IEEE-math kernel reached 2.3 TB/s.  Two levers, both exact:
+//   * hand-rolled exact math: the same algorithms hipcc's IEEE lowering uses (v_sqrt_f32 + one-ulp up/down
+//     residual test; reciprocal refinement + two residual corrections for the divide) without the denormal
+//     pre-scaling / class fix-ups that cannot trigger here, and with the reciprocal of sigma^2 hoisted out;
+//   * symmetry: compat[i][j] == compat[j][i] bit for bit (negating a difference does not change its square),
+//     so only tiles on/above the diagonal are computed and each off-diagonal tile is also written transposed
+//     (through a 32-row LDS strip, 128-byte row segments).
+// The arithmetic is the reference's to the bit: torch.norm evaluates sqrt(fma(dz,dz,fma(dy,dy,dx*dx))) (measured,
+// oracle/pointdsc_oracle.py), then an IEEE division by sigma^2 (fp32 square) and the clamp.
 #include <stdlib.h>
 #include "pdsc_common.h"
 
+#define PDSC_COMPAT_DEFAULT_VARIANT 3
+
 namespace pdsc {
 
-constexpr int CT_ROWS = 64;    // rows per workgroup tile
-constexpr int CT_COLS = 256;   // columns per workgroup tile (64 lanes x float4)
+// ---- exact fp32 sqrt / divide-by-invariant without the compiler's special-case scaffolding --------------
+// sqrt: hipcc lowers a correctly rounded sqrtf to v_sqrt_f32 followed by exactly this one-ulp test (plus input
+// scaling below 2^-96 and a zero/inf class check).  For x == 0 both residual tests fail and 0 is returned.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+    const float su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x);
+    const float ru = fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    return s;
+}
+struct InvariantDivisor {   // divide by the same b many times: hipcc's v_rcp + refinement, hoisted
+    float b, y;
+    __device__ __forceinline__ explicit InvariantDivisor(float b_) : b(b_) {
+        const float y0 = __builtin_amdgcn_rcpf(b_);
+        const float e = fmaf(-b_, y0, 1.0f);
+        y = fmaf(e, y0, y0);
+    }
+    // a / b: the residual-corrected quotient of the IEEE sequence (v_div_scale/v_div_fixup only matter for
+    // operands near the exponent limits; a tiny or zero quotient is absorbed by the following `1 - q`)
+    __device__ __forceinline__ float div(float a) const {
+        const float q0 = a * y;
+        const float r0 = fmaf(-b, q0, a);
+        const float q1 = fmaf(r0, y, q0);
+        const float r1 = fmaf(-b, q1, a);
+        return fmaf(r1, y, q1);
+    }
+};
 
-// CHEAP = timing probe only (tools/kernel_microbench.py): skips the sqrt/divide so that the store path can be
-// measured in isolation; never used by the product path.
-template <bool WRITE_DIST, bool CHEAP = false>
+template <bool FASTMATH>
+__device__ __forceinline__ float dist3(float x, float y, float z) {
+    const float ss = fmaf(z, z, fmaf(y, y, x * x));
+    return FASTMATH ? sqrt_rn(ss) : sqrtf(ss);
+}
+template <bool FASTMATH>
+__device__ __forceinline__ float compat_from_dists(float ds, float dt, float s2, const InvariantDivisor& inv) {
+    const float df = ds - dt;
+    const float q = FASTMATH ? inv.div(df * df) : (df * df) / s2;
+    return fmaxf(1.0f - q, 0.0f);
+}
+
+// ---- full-tile kernel: 64 rows x 256 columns per workgroup, float4 row segments ---------------------------
+constexpr int CT_ROWS = 64;
+constexpr int CT_COLS = 256;
+
+template <bool WRITE_DIST, bool FASTMATH>
 __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
                                                      const float* __restrict__ sigma_spat,
                                                      float* __restrict__ compat, float* __restrict__ src_dist,
                                                      long long ld, int N) {
-    __shared__ float rows_s[CT_ROWS][8];   // sx sy sz - tx ty tz -
+    __shared__ __attribute__((aligned(16))) float rows_s[CT_ROWS][8];   // sx sy sz - tx ty tz -
     const int b = blockIdx.z;
     const int i0 = blockIdx.y * CT_ROWS;
     const int j0 = blockIdx.x * CT_COLS;
@@ -43,6 +96,7 @@ __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ s
     }
     const float sg = sigma_spat[0];
     const float s2 = sg * sg;                        // `self.sigma_spat ** 2` in fp32
+    const InvariantDivisor inv(s2);
     __syncthreads();
     if (jc >= ld) return;
     float* outb = compat + (size_t)b * N * ld;
@@ -57,16 +111,9 @@ __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ s
         f32x4 o, dd;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float ds, v;
-            if (CHEAP) {
-                ds = ps[0] - sx[c];
-                v = fmaxf(ds + (pt[0] - tx[c]) * s2, 0.0f);
-            } else {
-                ds = norm3(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
-                const float dt = norm3(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
-                const float df = ds - dt;
-                v = fmaxf(1.0f - (df * df) / s2, 0.0f);
-            }
+            const float ds = dist3<FASTMATH>(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
+            const float dt = dist3<FASTMATH>(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
+            const float v = compat_from_dists<FASTMATH>(ds, dt, s2, inv);
             const bool valid = (jc + c) < N;
             o[c] = valid ? v : 0.0f;
             dd[c] = valid ? ds : 0.0f;
@@ -76,23 +123,19 @@ __global__ __launch_bounds__(256) void compat_kernel(const float* __restrict__ s
     }
 }
 
-// ---- symmetric variant ----------------------------------------------------------------------------
-// compat[i][j] == compat[j][i] bit for bit (negating a difference does not change its square), so only the
-// tiles on and above the diagonal are computed (half the VALU work: 2 IEEE sqrt + 1 IEEE divide per element
-// is what bounds the plain kernel, not HBM); every off-diagonal 128x128 tile is written twice: directly
-// (float4 rows) and transposed through LDS (ds_read_b128 along j, dword stores of 64 consecutive i = 256 B).
+// ---- symmetric kernel: 128x128 tiles on/above the diagonal, transposed copy through a 32-row LDS strip ------
 constexpr int CS_T = 128;
+constexpr int CS_STRIP = 32;
 constexpr int CS_LD = CS_T + 4;
 
-template <bool SKIP_TRANSPOSE = false>   // true = timing probe only (wrong lower triangle), never shipped
-__global__ __launch_bounds__(256, 2) void compat_sym_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                            const float* __restrict__ sigma_spat, float* __restrict__ compat,
-                                                            long long ld, int N) {
+template <bool FASTMATH>
+__global__ __launch_bounds__(256) void compat_sym_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                         const float* __restrict__ sigma_spat, float* __restrict__ compat,
+                                                         long long ld, int N) {
     const int I = blockIdx.y, J = blockIdx.x, b = blockIdx.z;
     if (I > J) return;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ts = lds;                                  // [128][CS_LD] this tile, row-major
-    float* rows_s = lds + CS_T * CS_LD;               // [128][8]
+    __shared__ __attribute__((aligned(16))) float Ts[CS_STRIP * CS_LD];   // one 32 x 128 strip, row-major
+    __shared__ __attribute__((aligned(16))) float rows_s[CS_T * 8];
     const int i0 = I * CS_T, j0 = J * CS_T;
     const float* srcb = src + (size_t)b * N * 3;
     const float* tgtb = tgt + (size_t)b * N * 3;
@@ -113,45 +156,68 @@ __global__ __launch_bounds__(256, 2) void compat_sym_kernel(const float* __restr
     }
     const float sg = sigma_spat[0];
     const float s2 = sg * sg;
+    const InvariantDivisor inv(s2);
     float* outb = compat + (size_t)b * N * ld;
-    __syncthreads();
     const bool offdiag = I != J;
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-        const int il = rg + 8 * r;
-        const int i = i0 + il;
-        const f32x4 ps = *reinterpret_cast<const f32x4*>(rows_s + il * 8);
-        const f32x4 pt = *reinterpret_cast<const f32x4*>(rows_s + il * 8 + 4);
-        f32x4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ds = norm3(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
-            const float dt = norm3(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
-            const float df = ds - dt;
-            const float v = fmaxf(1.0f - (df * df) / s2, 0.0f);
-            o[c] = (jc + c) < N ? v : 0.0f;
-        }
-        if (i < N && jc < ld) *reinterpret_cast<f32x4*>(outb + (size_t)i * ld + jc) = o;
-        if (offdiag) *reinterpret_cast<f32x4*>(Ts + il * CS_LD + 4 * l32) = o;
-    }
-    if (!offdiag || SKIP_TRANSPOSE) return;
     __syncthreads();
-    // transposed copy: element (i,j) of this tile -> compat[j][i]
-    const int il = t & 127, jr = t >> 7;
-    const int i = i0 + il;                              // always < N here? no: the last row tile can be ragged
-#pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-        const int jq = 2 * p + jr;                      // group of 4 output rows
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Ts + il * CS_LD + 4 * jq);
+    for (int strip = 0; strip < CS_T / CS_STRIP; ++strip) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = j0 + 4 * jq + c;
-            if (j < N && i < N) outb[(size_t)j * ld + i] = v[c];
+        for (int r = 0; r < 4; ++r) {
+            const int sl = rg + 8 * r;                      // row inside the strip
+            const int il = strip * CS_STRIP + sl;
+            const int i = i0 + il;
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(rows_s + il * 8);
+            const f32x4 pt = *reinterpret_cast<const f32x4*>(rows_s + il * 8 + 4);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ds = dist3<FASTMATH>(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
+                const float dt = dist3<FASTMATH>(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
+                const float v = compat_from_dists<FASTMATH>(ds, dt, s2, inv);
+                o[c] = (jc + c) < N ? v : 0.0f;
+            }
+            if (i < N && jc < ld) *reinterpret_cast<f32x4*>(outb + (size_t)i * ld + jc) = o;
+            if (offdiag) *reinterpret_cast<f32x4*>(Ts + sl * CS_LD + 4 * l32) = o;
+        }
+        if (offdiag) {                                       // block-uniform
+            __syncthreads();
+            // element (i, j) of the strip -> compat[j][i]: lane = i (32 consecutive floats = 128 B per output row)
+            const int sl = t & 31, jq0 = t >> 5;
+            const int i = i0 + strip * CS_STRIP + sl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int jq = jq0 + 8 * p;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Ts + sl * CS_LD + 4 * jq);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = j0 + 4 * jq + c;
+                    if (j < N && i < N) outb[(size_t)j * ld + i] = v[c];
+                }
+            }
+            __syncthreads();
         }
     }
 }
 
+// self-test hook: the two hand-rolled exact primitives on arbitrary inputs (tests compare with IEEE results)
+__global__ void exact_math_selftest_kernel(const float* __restrict__ x, float b, float* __restrict__ sq, float* __restrict__ dv,
+                                           long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const InvariantDivisor inv(b);
+    sq[i] = sqrt_rn(x[i]);
+    dv[i] = inv.div(x[i]);
+}
+
 }  // namespace pdsc
+
+extern "C" int pdsc_selftest_exact_math(const float* x, float divisor, float* sqrt_out, float* div_out, long long n,
+                                        void* stream) {
+    PDSC_REQUIRE(x && sqrt_out && div_out && n > 0, "pdsc_selftest_exact_math: bad argument");
+    hipLaunchKernelGGL(pdsc::exact_math_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, divisor, sqrt_out, div_out, n);
+    return pdsc::check_launch("pdsc_selftest_exact_math");
+}
 
 extern "C" long long pdsc_compat_ld(int N) { return N <= 0 ? -1 : pdsc::round_up(N, 64); }
 
@@ -160,33 +226,28 @@ extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const flo
     PDSC_REQUIRE(src && tgt && sigma_spat && compat, "pdsc_spatial_compat: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_spatial_compat: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= N && ld % 4 == 0, "pdsc_spatial_compat: ld=%lld must be >= N and a multiple of 4", ld);
-    dim3 grid(pdsc::ceil_div((int)ld, pdsc::CT_COLS), pdsc::ceil_div(N, pdsc::CT_ROWS), bs);
     hipStream_t st = (hipStream_t)stream;
     static int variant = -1;
-    const size_t sym_lds = (size_t)(pdsc::CS_T * pdsc::CS_LD + pdsc::CS_T * 8) * sizeof(float);
     if (variant < 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::compat_sym_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sym_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::compat_sym_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sym_lds);
-        // tuning/A-B knob: 0 = full tiles, 1 = symmetric (shipped); 2, 3 = TIMING PROBES that produce wrong values
-        // (2: symmetric without the transposed stores, 3: full tiles without sqrt/divide)
+        // tuning/A-B knob (all variants produce identical bits): 0 = full tiles + hipcc IEEE math, 1 = full tiles +
+        // hand-rolled exact math, 2 = symmetric + IEEE math, 3 = symmetric + hand-rolled exact math
         const char* env = getenv("PDSC_COMPAT_VARIANT");
-        variant = env ? atoi(env) : 1;
+        variant = env ? atoi(env) : PDSC_COMPAT_DEFAULT_VARIANT;
     }
+    const dim3 full_grid(pdsc::ceil_div((int)ld, pdsc::CT_COLS), pdsc::ceil_div(N, pdsc::CT_ROWS), bs);
+    const int nt = pdsc::ceil_div(N, pdsc::CS_T);
+    const dim3 sym_grid(nt, nt, bs);
     pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
-    if ((variant == 1 || variant == 2) && !src_dist) {
-        const int nt = pdsc::ceil_div(N, pdsc::CS_T);
-        if (variant == 1)
-            hipLaunchKernelGGL(pdsc::compat_sym_kernel<false>, dim3(nt, nt, bs), dim3(256), sym_lds, st, src, tgt, sigma_spat, compat, ld, N);
-        else
-            hipLaunchKernelGGL(pdsc::compat_sym_kernel<true>, dim3(nt, nt, bs), dim3(256), sym_lds, st, src, tgt, sigma_spat, compat, ld, N);
-    } else if (variant == 3 && !src_dist) {
-        hipLaunchKernelGGL((pdsc::compat_kernel<false, true>), grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
-    } else if (src_dist)
-        hipLaunchKernelGGL(pdsc::compat_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, src_dist, ld, N);
+    if (src_dist)
+        hipLaunchKernelGGL((pdsc::compat_kernel<true, true>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, src_dist, ld, N);
+    else if (variant == 0)
+        hipLaunchKernelGGL((pdsc::compat_kernel<false, false>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+    else if (variant == 1)
+        hipLaunchKernelGGL((pdsc::compat_kernel<false, true>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+    else if (variant == 2)
+        hipLaunchKernelGGL((pdsc::compat_sym_kernel<false>), sym_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, ld, N);
     else
-        hipLaunchKernelGGL(pdsc::compat_kernel<false>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+        hipLaunchKernelGGL((pdsc::compat_sym_kernel<true>), sym_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, ld, N);
     pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
     return pdsc::check_launch("pdsc_spatial_compat");
 }

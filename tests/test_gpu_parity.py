@@ -65,6 +65,42 @@ def test_spatial_compat_bit_exact(n):
     assert torch.equal(only, compat)
 
 
+def test_exact_math_primitives_match_ieee():
+    """sqrt_rn / InvariantDivisor of compat.hip vs correctly rounded results on 16M values incl. the ranges the
+    kernel sees (squared distances 0 .. 1e4) and far outside them."""
+    import ctypes as C
+    from pointdsc_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    n = 1 << 22
+    chunks = [rs.random_sample(n) * 30.0, rs.random_sample(n) * 1e4, np.exp(rs.uniform(-60, 40, n)),
+              np.concatenate([[0.0, 1.0, 4.0, 2.0, 1e-30, 3.0e38], rs.random_sample(n - 6)])]
+    x = torch.from_numpy(np.concatenate(chunks).astype(np.float32))
+    for b in (0.1 ** 2, 1.2 ** 2, float(np.float32(0.1) * np.float32(0.1)), 3.0, 7.3e-3):
+        b = float(np.float32(b))
+        xd = g(x)
+        sq, dv = torch.empty_like(xd), torch.empty_like(xd)
+        _lib.check(lib.pdsc_selftest_exact_math(C.c_void_p(xd.data_ptr()), b, C.c_void_p(sq.data_ptr()), C.c_void_p(dv.data_ptr()),
+                                                x.numel(), torch.cuda.current_stream().cuda_stream), "selftest")
+        want_sq = np.sqrt(x.numpy().astype(np.float64)).astype(np.float32)
+        assert np.array_equal(sq.cpu().numpy(), want_sq)
+        want_dv = (x.numpy() / np.float32(b)).astype(np.float32)             # IEEE fp32 division
+        normal = (want_dv > 1e-30) & (want_dv < 1e30)                        # quotients that survive `1 - q` at all
+        got = dv.cpu().numpy()
+        assert np.array_equal(got[normal], want_dv[normal])
+        assert np.all(got[x.numpy() == 0] == 0)
+
+
+@pytest.mark.parametrize("scale,sigma,n", [(3.0, 0.1, 5000), (60.0, 1.2, 3000)])
+def test_spatial_compat_bit_exact_large(scale, sigma, n):
+    pair = synthetic.make_pair(n, seed=77, scale=scale, noise=0.01 * scale / 3)
+    sig = torch.tensor([sigma])
+    compat = ops.spatial_compat(g(pair["src_keypts"]), g(pair["tgt_keypts"]), g(sig))
+    _, want = O.spatial_compat(pair["src_keypts"][0], pair["tgt_keypts"][0], sig)
+    assert torch.equal(compat[0, :, :n].cpu(), want)
+    assert torch.equal(compat[0, :, :n], compat[0, :, :n].transpose(0, 1))   # exactly symmetric
+
+
 def test_spatial_compat_batched_and_kitti_scale():
     b = synthetic.make_batch(3, 300, seed=50, scale=60.0, noise=0.1)
     sig = torch.tensor([1.2])
