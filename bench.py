@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 MODEL_KW = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
                 sigma_d=0.10, k=40, nms_radius=0.10)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
 
 
@@ -73,6 +74,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--num-corr", type=int, default=5000, help="N correspondences per pair (headline: 5000)")
     ap.add_argument("--pairs-per-gpu", type=int, default=4, help="batch per GPU per step (32 pairs / 8 GPUs)")
+    ap.add_argument("--attention-precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs timed on the CPU oracle (bounded sample)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
@@ -105,6 +108,7 @@ def main():
     sd = synthetic.make_state_dict(model.state_dict(), seed=6)
     model.load_state_dict(sd)
     model = model.eval().to(dev)
+    model.attention_precision = args.attention_precision
     # each rank owns its shard of the global batch: pairs [rank*B, (rank+1)*B)
     batch = synthetic.make_batch(B, N, seed=1000 + rank * B, inlier_ratio=0.2)
     data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
@@ -167,17 +171,32 @@ def main():
         "metric": "point-cloud pairs/sec @ N=%d corr" % N,
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32" if args.attention_precision == "fp32" else "f32 (attention products as bf16x3 split, f32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "3DMatch-like synthetic correspondences (BASELINE.json configs[2]): N=%d corr, "
                                "%d pairs per GPU per step, 12-layer PointDSC, seeded random weights" % (N, B),
                    "num_corr": N, "pairs_per_gpu": B, "global_batch": total_pairs,
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses" % world},
-        "roofline": {"kernel": "sc_attention_kernel", "bound": "mfma",
-                     "achieved": None if att_tflops is None else round(att_tflops, 2),
-                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "traffic": None, "launches": att_n,
-                     "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops},
+        "roofline": ({"kernel": "sc_attention_kernel", "bound": "mfma",
+                      "achieved": None if att_tflops is None else round(att_tflops, 2),
+                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                      "frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                      "traffic": None, "launches": att_n,
+                      "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}
+                     if args.attention_precision == "fp32" else
+                     # split precision: `achieved` counts ALGORITHMIC flops (4 C N^2 per pair per launch) against the
+                     # dense bf16 MFMA peak; the kernel executes 3 bf16 MFMAs per algorithmic product (hi*hi, hi*lo,
+                     # lo*hi), so its matrix-pipe utilisation is 3 x frac (`executed_frac`).
+                     {"kernel": "sc_attention_split_kernel", "bound": "mfma",
+                      "achieved": None if att_tflops is None else round(att_tflops, 2),
+                      "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                      "frac": None if att_tflops is None else round(att_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
+                      "executed_tflops": None if att_tflops is None else round(3 * att_tflops, 2),
+                      "executed_frac": None if att_tflops is None else round(3 * att_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
+                      "equivalent_fp32_mfma_frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                      "traffic": None, "launches": att_n,
+                      "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}),
         "roofline_compat": {"kernel": "compat_kernel", "bound": "hbm",
                             "achieved": None if cmp_gbs is None else round(cmp_gbs, 1), "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": None if cmp_gbs is None else round(cmp_gbs / PEAK_HBM_GBS, 4),
@@ -190,7 +209,7 @@ def main():
             tj = json.loads(traffic_file.read_text())
             key = f"N{N}_B{B}"
             if key in tj:
-                line["roofline"]["traffic"] = tj[key].get("sc_attention_kernel")
+                line["roofline"]["traffic"] = tj[key].get(line["roofline"]["kernel"])
                 line["roofline_compat"]["traffic"] = tj[key].get("compat_kernel")
         except Exception:
             pass

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 1
+#define PDSC_VERSION 2
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32
@@ -50,7 +50,14 @@ typedef struct pdsc_config {
     float inlier_threshold;  /* hypothesis-scoring threshold (:328,:335)       */
     float nms_radius;        /* NMS radius R (:174)                            */
     float refine_threshold;  /* 0.10 if inlier_threshold == 0.10 else 1.2 (:415-418) */
+    int attention_precision; /* enum pdsc_attention_precision: how the two N x N x C contractions are evaluated */
 } pdsc_config;
+
+/* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
+ *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
+ *           ~2^-16 relative error per product; 12-layer features within 5e-6, R/t within 1e-5 of the fp32 path.
+ *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time. */
+enum pdsc_attention_precision { PDSC_ATT_BF16X3 = 0, PDSC_ATT_FP32 = 1 };
 
 /* ---- packed weights --------------------------------------------------------------------------
  * One flat fp32 buffer holding the model with BatchNorm (eval) folded into the preceding conv and
@@ -132,6 +139,17 @@ int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, f
                      const float* w3, const float* b3, const float* wp, const float* bp,
                      const float* wq, const float* bq, int M, void* stream);
 
+/* Same chain, with the head additionally (or instead of qkv_out, which may then be NULL) emitting the bf16 hi/lo
+ * operand streams of the split-precision attention (layout: pointdsc_amd/csrc/split_layout.h):
+ *   q_split  [bs*N][256] bf16 (hi | lo), pdsc_split_q_bytes(bs, N) bytes;
+ *   kv_tiles [bs][ceil(N/32)][32 KiB],   pdsc_split_kv_bytes(bs, N) bytes.
+ * Rows are bs pairs of N points (a 32-point tile never straddles two pairs). */
+int pdsc_layer_fused_split(const float* msg, const float* res, const float* feat_in, float* feat_out,
+                           float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
+                           const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, const float* wp, const float* bp,
+                           const float* wq, const float* bq, int bs, int N, void* stream);
+
 /* ---- a-3  spatial-consistency guided non-local attention ---------------------------------------
  * replaces models/PointDSC.py:39-42 (both einsums and the softmax; N x N scores never materialised).
  *   msg[o][:] = sum_i softmax_i( compat[o][i] * <Q_o, K_i> / sqrt(C) ) * V_i
@@ -142,6 +160,18 @@ size_t pdsc_attention_scratch_bytes(int bs, int N, int nsplit);
 int    pdsc_attention_default_split(int bs, int N);
 int    pdsc_sc_attention(const float* qkv, const float* compat, long long ld, float* msg,
                          void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream);
+
+/* Split-precision variant (PDSC_ATT_BF16X3): same contract, operands as bf16 hi/lo streams.
+ * pdsc_pack_qkv_split converts fp32 (q|k|v) rows [bs*N][3C] into the two streams (the fused layer kernel emits
+ * them directly; the packer serves stage tests and callers with their own projections). */
+size_t pdsc_split_q_bytes(int bs, int N);
+size_t pdsc_split_kv_bytes(int bs, int N);
+int    pdsc_pack_qkv_split(const float* qkv, void* q_split, void* kv_tiles, int bs, int N, void* stream);
+size_t pdsc_attention_split_scratch_bytes(int bs, int N, int nsplit);
+int    pdsc_attention_split_default_split(int bs, int N);
+int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
+                               float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
+                               void* stream);
 
 /* ---- a-4  L2 normalisation + last classifier layer --------------------------------------------
  * replaces F.normalize (models/PointDSC.py:156) and classification.4 (:112,171).

@@ -24,6 +24,7 @@ class PdscConfig(C.Structure):
         ("in_dim", C.c_int), ("num_layers", C.c_int), ("num_channels", C.c_int),
         ("num_iterations", C.c_int), ("k", C.c_int), ("refine_iters", C.c_int),
         ("inlier_threshold", C.c_float), ("nms_radius", C.c_float), ("refine_threshold", C.c_float),
+        ("attention_precision", C.c_int),
     ]
 
 
@@ -51,6 +52,13 @@ SIGNATURES = {
     "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pdsc_layer_fused": (_i, [_vp] * 16 + [_i, _vp]),
+    "pdsc_layer_fused_split": (_i, [_vp] * 18 + [_i, _i, _vp]),
+    "pdsc_split_q_bytes": (_sz, [_i, _i]),
+    "pdsc_split_kv_bytes": (_sz, [_i, _i]),
+    "pdsc_pack_qkv_split": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "pdsc_attention_split_scratch_bytes": (_sz, [_i, _i, _i]),
+    "pdsc_attention_split_default_split": (_i, [_i, _i]),
+    "pdsc_sc_attention_split": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "pdsc_attention_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_default_split": (_i, [_i, _i]),
     "pdsc_sc_attention": (_i, [_vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
@@ -93,7 +101,7 @@ def load() -> C.CDLL:
             raise PointDSCLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.pdsc_version() != 1:
+    if lib.pdsc_version() != 2:
         raise PointDSCLibraryError(f"unexpected library version {lib.pdsc_version()}")
     _lib = lib
     return lib

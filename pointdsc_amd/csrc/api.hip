@@ -53,6 +53,9 @@ static bool config_ok(const pdsc_config* c) {
     if (c->num_iterations < 0 || c->num_iterations > PDSC_MAX_POWER_ITERS) { set_error("num_iterations=%d", c->num_iterations); return false; }
     if (c->k < 1 || c->k > PDSC_MAX_K) { set_error("k=%d must be in [1,%d]", c->k, PDSC_MAX_K); return false; }
     if (c->refine_iters < 0) { set_error("refine_iters=%d", c->refine_iters); return false; }
+    if (c->attention_precision != PDSC_ATT_BF16X3 && c->attention_precision != PDSC_ATT_FP32) {
+        set_error("attention_precision=%d", c->attention_precision); return false;
+    }
     return true;
 }
 
@@ -140,7 +143,12 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("msg", M * C * f);
     L.add("t64a", M * (C / 2) * f);
     L.add("t64b", M * (C / 2) * f);
-    L.add("att_scratch", pdsc_attention_scratch_bytes(bs, N, 0));
+    {
+        const size_t a32 = pdsc_attention_scratch_bytes(bs, N, 0), a16 = pdsc_attention_split_scratch_bytes(bs, N, 0);
+        L.add("att_scratch", c->attention_precision == PDSC_ATT_FP32 ? a32 : a16);
+    }
+    L.add("q_split", c->attention_precision == PDSC_ATT_BF16X3 ? pdsc_split_q_bytes(bs, N) : 0);
+    L.add("kv_tiles", c->attention_precision == PDSC_ATT_BF16X3 ? pdsc_split_kv_bytes(bs, N) : 0);
     L.add("normed", M * C * f);
     L.add("h1", M * 32 * f);
     L.add("h2", M * 32 * f);
@@ -259,7 +267,11 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     int *seeds = I("seeds"), *knn_idx = I("knn_idx"), *counts = I("counts"), *best = I("best"), *solves = I("solves");
     unsigned int* conv_mask = (unsigned int*)(ws + L.find("conv_mask"));
     void* att_scratch = ws + L.find("att_scratch");
-    const size_t att_bytes = pdsc_attention_scratch_bytes(bs, N, 0);
+    const bool split = cfg->attention_precision == PDSC_ATT_BF16X3;
+    const size_t att_bytes = split ? pdsc_attention_split_scratch_bytes(bs, N, 0) : pdsc_attention_scratch_bytes(bs, N, 0);
+    void* q_split = split ? ws + L.find("q_split") : nullptr;
+    void* kv_tiles = split ? ws + L.find("kv_tiles") : nullptr;
+    float* qkv32 = split ? nullptr : qkv;
 
     // Step 1 (models/PointDSC.py:150-155): compat, then the SCNonlocal encoder
     PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
@@ -271,26 +283,34 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     }
     if (fused && cfg->num_layers > 0) {
         // head of layer 0, then per layer: attention + (tail of layer i fused with head of layer i+1)
-        PDSC_TRY(pdsc_layer_fused(nullptr, nullptr, featA, nullptr, featB, qkv, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0), W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), M,
-                                  stream));
+        PDSC_TRY(pdsc_layer_fused_split(nullptr, nullptr, featA, nullptr, featB, qkv32, q_split, kv_tiles, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
+                                        W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            if (split)
+                PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            else
+                PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
             const bool last = i + 1 == cfg->num_layers;
-            PDSC_TRY(pdsc_layer_fused(msg, cur, nullptr, last ? featA : nullptr, last ? nullptr : nxt, last ? nullptr : qkv,
-                                      W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
-                                      W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
-                                      last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
-                                      last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1), M,
-                                      stream));
+            PDSC_TRY(pdsc_layer_fused_split(msg, cur, nullptr, last ? featA : nullptr, last ? nullptr : nxt,
+                                            last ? nullptr : qkv32, last ? nullptr : q_split, last ? nullptr : kv_tiles,
+                                            W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
+                                            W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
+                                            last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
+                                            last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
+                                            bs, N, stream));
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
     } else
     for (int i = 0; i < cfg->num_layers; ++i) {
         PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_PCN_W, i), W(PDSC_W_PCN_B, i), nullptr, 0, featB, C, M, C, C, 1, stream));
         PDSC_TRY(pdsc_linear(featB, C, W(PDSC_W_QKV_W, i), W(PDSC_W_QKV_B, i), nullptr, 0, qkv, 3 * C, M, C, 3 * C, 0, stream));
-        PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+        if (split) {
+            PDSC_TRY(pdsc_pack_qkv_split(qkv, q_split, kv_tiles, bs, N, stream));
+            PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+        } else
+            PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
         PDSC_TRY(pdsc_linear(msg, C, W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), nullptr, 0, t64a, C / 2, M, C, C / 2, 1, stream));
         PDSC_TRY(pdsc_linear(t64a, C / 2, W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i), nullptr, 0, t64b, C / 2, M, C / 2, C / 2, 1, stream));
         PDSC_TRY(pdsc_linear(t64b, C / 2, W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i), featB, C, featA, C, M, C / 2, C, 0, stream));

@@ -23,6 +23,7 @@
 // so p = exp2(compat*s - m).
 #include <stdlib.h>
 #include "pdsc_common.h"
+#include "attention_common.h"
 
 namespace pdsc {
 
@@ -33,18 +34,7 @@ constexpr int ATT_C = PDSC_CHANNELS;
 constexpr int ATT_QKV_LD = 3 * PDSC_CHANNELS;
 constexpr int ATT_TILE_FLOATS = ATT_BK * ATT_C;        // 4096 floats = 16 KiB
 
-struct AttArgs {
-    const float* qkv;        // [bs*N][384]
-    const float* compat;     // [bs][N][ld]
-    long long ld;
-    float* msg;              // [bs*N][128]
-    float* part_o;           // [bs][nsplit][Npad][128]   un-normalised partial outputs
-    float* part_ml;          // [bs][nsplit][Npad][2]     (running max (log2 domain), partial sum)
-    int N, Npad, nsplit, num_tiles;
-};
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // one wave issues its quarter (4 x 1 KiB) of a 32-key K tile and V tile
 __device__ __forceinline__ void issue_tile_loads(const float* __restrict__ kbase, const float* __restrict__ vbase,
@@ -267,6 +257,12 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttArgs a) {
 
 static int attention_npad(int N) { return (int)round_up(N, ATT_BQ); }
 
+int launch_attention_combine(const AttArgs& a, int bs, hipStream_t st) {
+    const long long threads = (long long)a.N * 32;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((threads + 255) / 256), bs), dim3(256), 0, st, a);
+    return check_launch("pdsc_sc_attention(combine)");
+}
+
 }  // namespace pdsc
 
 extern "C" int pdsc_attention_default_split(int bs, int N) {
@@ -329,9 +325,7 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
     int rc = pdsc::check_launch("pdsc_sc_attention");
     if (rc != PDSC_OK) return rc;
     if (nsplit > 1) {
-        const long long threads = (long long)N * 32;
-        hipLaunchKernelGGL(pdsc::attention_combine_kernel, dim3((unsigned)((threads + 255) / 256), bs), dim3(256), 0, st, a);
-        rc = pdsc::check_launch("pdsc_sc_attention(combine)");
+        rc = pdsc::launch_attention_combine(a, bs, st);
     }
     return rc;
 }

@@ -10,6 +10,7 @@
 // lane is a point and register r = 4g+e holds output channel n0+8g+4h+e: one float4 per (g) goes to LDS / HBM.
 // Bound: MFMA (172 kFLOP per point per layer on v_mfma_f32_32x32x2_f32); weights stream from L2 (336 KB per tile).
 #include "pdsc_common.h"
+#include "split_layout.h"
 
 namespace pdsc {
 
@@ -26,7 +27,9 @@ struct LayerArgs {
     float* qkv_out;          // [M][384]  head
     const float *w1, *b1, *w2, *b2, *w3, *b3;      // fc1 [64][128], fc2 [64][64], fc3 [128][64]
     const float *wp, *bp, *wq, *bq;                // pcn [128][128], qkv [384][128]
-    int M;
+    __bf16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
+    unsigned char* kv;       // head, optional: K/V tile stream  [bs][tiles][32 KiB]  (split_layout.h)
+    int N, bs;               // rows are bs pairs of N points; a workgroup's 32-point tile never straddles two pairs
 };
 
 template <int K>
@@ -96,6 +99,57 @@ __device__ __forceinline__ void global_to_tile(const float* __restrict__ src, fl
     }
 }
 
+// 32x128 fp32 LDS tile (one of q / k / v for 32 points = one key tile) -> bf16 hi/lo streams (split_layout.h).
+// WHICH: 0 = q rows, 1 = K image, 2 = V^T image.  `valid` = number of real points in the tile (the rest is zero).
+template <int WHICH>
+__device__ __forceinline__ void tile_to_split(const float* Xs, __bf16* __restrict__ qrows, unsigned char* __restrict__ img,
+                                              int valid, int t) {
+    if (WHICH == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+            if (row < valid) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * LF_LD + c4);
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { __bf16 x, y; split_bf16(v[e], x, y); hi[e] = x; lo[e] = y; }
+                __bf16* dst = qrows + (size_t)row * SPL_Q_LD + c4;
+                *reinterpret_cast<bf16x4*>(dst) = hi;
+                *reinterpret_cast<bf16x4*>(dst + PDSC_CHANNELS) = lo;
+            }
+        }
+    } else if (WHICH == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = t + 256 * i, key = f >> 4, chunk = f & 15;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(Xs + key * LF_LD + 8 * chunk);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(Xs + key * LF_LD + 8 * chunk + 4);
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = key < valid ? (e < 4 ? v0[e & 3] : v1[e & 3]) : 0.f;
+                __bf16 x, y; split_bf16(v, x, y); hi[e] = x; lo[e] = y;
+            }
+            *reinterpret_cast<bf16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
+            *reinterpret_cast<bf16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = t + 256 * i, ch = f & 127, jh = f >> 7;
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = spl_v_key(jh, e);
+                const float v = key < valid ? Xs[key * LF_LD + ch] : 0.f;
+                __bf16 x, y; split_bf16(v, x, y); hi[e] = x; lo[e] = y;
+            }
+            *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
+            *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
+        }
+    }
+}
+
 template <bool HAS_TAIL, bool HAS_HEAD>
 __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) float Xa[LF_TILE];
@@ -103,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * LF_ROWS;
-    const int M = a.M;
+    const int m0 = blockIdx.y * a.N + blockIdx.x * LF_ROWS;     // first row of this tile
+    const int M = (blockIdx.y + 1) * a.N;                        // end of this pair's rows
 
     if (HAS_TAIL) {
         f32x4 w128[16], w64[8];
@@ -166,7 +220,14 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
             if (c < 2) load_w<128>(a.wq, n0 + 128, l31, h, w);        // prefetch next chunk's tile
             store_tile<false, false>(acc, a.bq, n0, Xb, 32 * wave, l31, h, nullptr);
             __syncthreads();
-            tile_to_global(Xb, a.qkv_out + 128 * c, 3 * PDSC_CHANNELS, m0, M, t);
+            if (a.qkv_out) tile_to_global(Xb, a.qkv_out + 128 * c, 3 * PDSC_CHANNELS, m0, M, t);
+            if (a.qs) {
+                unsigned char* img = a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_BYTES;
+                const int valid = min(LF_ROWS, M - m0);
+                if (c == 0) tile_to_split<0>(Xb, a.qs + (size_t)m0 * SPL_Q_LD, img, valid, t);
+                else if (c == 1) tile_to_split<1>(Xb, nullptr, img, valid, t);
+                else tile_to_split<2>(Xb, nullptr, img, valid, t);
+            }
             if (c < 2) __syncthreads();
         }
     }
@@ -174,26 +235,38 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
 
 template <bool T, bool H>
 static int launch_layer(const LayerArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((layer_fused_kernel<T, H>), dim3(ceil_div(a.M, LF_ROWS)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((layer_fused_kernel<T, H>), dim3(ceil_div(a.N, LF_ROWS), a.bs), dim3(256), 0, st, a);
     return check_launch("pdsc_layer_fused");
 }
 
 }  // namespace pdsc
 
-extern "C" int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, float* feat_out,
-                                float* featB_out, float* qkv_out, const float* w1, const float* b1, const float* w2,
-                                const float* b2, const float* w3, const float* b3, const float* wp, const float* bp,
-                                const float* wq, const float* bq, int M, void* stream) {
+extern "C" int pdsc_layer_fused_split(const float* msg, const float* res, const float* feat_in, float* feat_out,
+                                      float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
+                                      const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                      const float* b3, const float* wp, const float* bp, const float* wq, const float* bq,
+                                      int bs, int N, void* stream) {
     const bool tail = msg != nullptr, head = featB_out != nullptr;
     PDSC_REQUIRE(tail || head, "pdsc_layer_fused: neither tail (msg) nor head (featB_out) requested");
-    PDSC_REQUIRE(M > 0, "pdsc_layer_fused: M=%d", M);
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused: bs=%d N=%d", bs, N);
     if (tail) PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused: tail needs res, fc1..fc3");
     else PDSC_REQUIRE(feat_in, "pdsc_layer_fused: head-only needs feat_in");
-    if (head) PDSC_REQUIRE(qkv_out && wp && bp && wq && bq, "pdsc_layer_fused: head needs qkv_out, pcn, qkv weights");
+    if (head) PDSC_REQUIRE((qkv_out || q_split) && wp && bp && wq && bq, "pdsc_layer_fused: head needs qkv_out or the split streams, pcn, qkv weights");
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
-    pdsc::LayerArgs a{msg, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3, wp, bp, wq, bq, M};
+    PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
+    pdsc::LayerArgs a{msg, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3, wp, bp, wq, bq,
+                      (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs};
     hipStream_t st = (hipStream_t)stream;
     if (tail && head) return pdsc::launch_layer<true, true>(a, st);
     if (tail) return pdsc::launch_layer<true, false>(a, st);
     return pdsc::launch_layer<false, true>(a, st);
+}
+
+extern "C" int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, float* feat_out,
+                                float* featB_out, float* qkv_out, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, const float* wp, const float* bp,
+                                const float* wq, const float* bq, int M, void* stream) {
+    if (featB_out) PDSC_REQUIRE(qkv_out, "pdsc_layer_fused: head needs qkv_out");
+    return pdsc_layer_fused_split(msg, res, feat_in, feat_out, featB_out, qkv_out, nullptr, nullptr, w1, b1, w2, b2, w3, b3,
+                                  wp, bp, wq, bq, 1, M, stream);
 }

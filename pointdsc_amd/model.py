@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -26,6 +27,8 @@ import torch.nn as nn
 from . import _lib
 
 _NUM_CHANNELS = 128
+# enum pdsc_attention_precision (include/pointdsc_hip.h)
+ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1}
 
 
 def _conv(cin: int, cout: int) -> nn.Conv1d:
@@ -94,6 +97,10 @@ class PointDSC(nn.Module):
             elif isinstance(m, nn.BatchNorm1d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        # Not a reference constructor argument (the signature stays the reference's): arithmetic of the two
+        # attention contractions.  "bf16x3" = split-precision bf16 MFMA (default; features within 5e-6 of fp32),
+        # "fp32" = exact fp32 MFMA.  Set the attribute (or POINTDSC_ATTENTION_PRECISION) before calling forward.
+        self.attention_precision = os.environ.get("POINTDSC_ATTENTION_PRECISION", "bf16x3")
         self._wpack: Optional[torch.Tensor] = None
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
@@ -102,8 +109,11 @@ class PointDSC(nn.Module):
     def _config(self) -> _lib.PdscConfig:
         # reference post_refinement picks its threshold by exact equality with 0.10 (:415-418)
         refine_thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
+        if self.attention_precision not in ATTENTION_PRECISIONS:
+            raise ValueError(f"attention_precision must be one of {sorted(ATTENTION_PRECISIONS)}, got {self.attention_precision!r}")
         return _lib.PdscConfig(self.in_dim, self.num_layers, self.num_channels, self.num_iterations, self.k, 20,
-                               float(self.inlier_threshold), float(self.nms_radius), float(refine_thr))
+                               float(self.inlier_threshold), float(self.nms_radius), float(refine_thr),
+                               ATTENTION_PRECISIONS[self.attention_precision])
 
     # The packed buffer is rebuilt after anything that can change weights through the nn.Module API
     # (load_state_dict, .to()/.cuda()/.float(), train()); after editing parameters in place call

@@ -105,6 +105,51 @@ def sc_attention(qkv: torch.Tensor, compat: torch.Tensor, bs: int, n: int, nspli
     return msg
 
 
+def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
+    """fp32 (q|k|v) rows [bs*N,384] -> (q_split, kv_tiles) byte tensors in the layout of csrc/split_layout.h."""
+    lib = _lib.load()
+    qkv = _chk(qkv, "qkv")
+    qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=qkv.device, dtype=torch.uint8)
+    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=qkv.device, dtype=torch.uint8)
+    _lib.check(lib.pdsc_pack_qkv_split(_p(qkv), _p(qs), _p(kv), bs, n, _stream()), "pdsc_pack_qkv_split")
+    return qs, kv
+
+
+def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: torch.Tensor, bs: int, n: int,
+                       nsplit: int = 0) -> torch.Tensor:
+    """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128]."""
+    lib = _lib.load()
+    compat = _chk(compat, "compat")
+    qs, kv = _chk(q_split, "q_split", torch.uint8), _chk(kv_tiles, "kv_tiles", torch.uint8)
+    msg = torch.empty(bs * n, 128, device=compat.device, dtype=torch.float32)
+    nb = int(lib.pdsc_attention_split_scratch_bytes(bs, n, nsplit))
+    scratch = torch.empty(max(nb, 16), device=compat.device, dtype=torch.uint8)
+    _lib.check(lib.pdsc_sc_attention_split(_p(qs), _p(kv), _p(compat), compat.shape[-1], _p(msg), _p(scratch), nb, bs, n,
+                                           nsplit, _stream()), "pdsc_sc_attention_split")
+    return msg
+
+
+def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False):
+    """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
+    Returns (feat or None, featB, qkv or None, q_split, kv_tiles)."""
+    lib = _lib.load()
+    src = msg if msg is not None else feat_in
+    m, dev = src.shape[0], src.device
+    assert m == bs * n
+    tail = [_chk(w, "tail_w") for w in tail_w] if tail_w is not None else [None] * 6
+    head = [_chk(w, "head_w") for w in head_w]
+    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if msg is not None else None
+    featB = torch.empty(m, 128, device=dev, dtype=torch.float32)
+    qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if want_qkv else None
+    qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8)
+    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8)
+    args = [_p(_chk(msg, "msg")) if msg is not None else None, _p(_chk(res, "res")) if res is not None else None,
+            _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB), _p(qkv), _p(qs), _p(kv)]
+    args += [_p(w) for w in tail] + [_p(w) for w in head]
+    _lib.check(lib.pdsc_layer_fused_split(*args, bs, n, _stream()), "pdsc_layer_fused_split")
+    return feat, featB, qkv, qs, kv
+
+
 def normalize_confidence(feat, h2, w3, b3) -> Tuple[torch.Tensor, torch.Tensor]:
     lib = _lib.load()
     feat, h2, w3, b3 = _chk(feat, "feat"), _chk(h2, "h2"), _chk(w3.reshape(-1), "w3"), _chk(b3.reshape(-1), "b3")

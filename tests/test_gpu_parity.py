@@ -204,12 +204,150 @@ def test_sc_attention_online_softmax_rescale_branch():
         assert (msg.double() - want).abs().max() < 1e-5
 
 
+
+# ------------------------------------------------------------------------------------------------------
+# a-3 split-precision attention (bf16 hi/lo operands, three MFMAs per operand pair) and its operand streams
+# ------------------------------------------------------------------------------------------------------
+def _split(x):
+    hi = x.float().bfloat16()
+    lo = (x.float() - hi.float()).bfloat16()
+    return hi, lo
+
+
+def _pack_reference(qkv, bs, n):
+    """CPU restatement of pointdsc_amd/csrc/split_layout.h: (q_split bytes, kv_tiles bytes)."""
+    tiles = (n + 31) // 32
+    qkv = qkv.reshape(bs, n, 384)
+    qh, ql = _split(qkv[..., :128])
+    qs = torch.cat([qh, ql], dim=-1).reshape(bs * n, 256)
+    kv = torch.zeros(bs, tiles, 4, 4096, dtype=torch.bfloat16)
+    pad = torch.zeros(bs, tiles * 32, 256)
+    pad[:, :n] = qkv[..., 128:]
+    k = pad[..., :128].reshape(bs, tiles, 32, 128)
+    v = pad[..., 128:].reshape(bs, tiles, 32, 128)
+    key = torch.arange(32)
+    # K image: [key][chunk ^ (key & 15)][8 channels]
+    kimg = torch.zeros(bs, tiles, 32, 16, 8)
+    for chunk in range(16):
+        dst = chunk ^ (key & 15)
+        kimg[:, :, key, dst] = k[:, :, key, 8 * chunk:8 * chunk + 8]
+    # V^T image: [channel][jh ^ ((channel >> 2) & 3)][e] = V[16j + 8(e>>2) + 4h + (e&3)][channel], jh = 2j+h
+    vimg = torch.zeros(bs, tiles, 128, 4, 8)
+    ch = torch.arange(128)
+    for jh in range(4):
+        dst = jh ^ ((ch >> 2) & 3)
+        for e in range(8):
+            kk = 16 * (jh >> 1) + 8 * (e >> 2) + 4 * (jh & 1) + (e & 3)
+            vimg[:, :, ch, dst, e] = v[:, :, kk, :][..., ch]
+    for which, img in ((0, kimg), (2, vimg)):
+        hi, lo = _split(img.reshape(bs, tiles, 4096))
+        kv[:, :, which], kv[:, :, which + 1] = hi, lo
+    return qs.view(torch.uint8).reshape(-1), kv.view(torch.uint8).reshape(-1)
+
+
+@pytest.mark.parametrize("n,bs", [(33, 1), (96, 3), (257, 2), (1000, 1)])
+def test_pack_qkv_split_streams_bit_exact(n, bs):
+    gen = torch.Generator().manual_seed(n)
+    qkv = torch.randn(bs * n, 384, generator=gen) * torch.logspace(-3, 1, 384)[None]
+    qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+    want_qs, want_kv = _pack_reference(qkv, bs, n)
+    assert torch.equal(qs.cpu(), want_qs)
+    assert torch.equal(kv.cpu(), want_kv)
+
+
+@pytest.mark.parametrize("n,bs", [(33, 1), (257, 2), (1000, 1)])
+def test_layer_fused_split_emits_the_streams_of_its_own_qkv(n, bs):
+    """The fused layer kernel's head writes the split streams directly; they must be exactly the packing of the
+    fp32 q|k|v it would have written, and every fp32 output must equal the M-row entry point's."""
+    gen = torch.Generator().manual_seed(n)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    m = bs * n
+    msg, res = rnd(m, 128), rnd(m, 128)
+    tail_w = [g(x) for x in (rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128))]
+    head_w = [g(x) for x in (rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384))]
+    f, fb, qkv, qs, kv = ops.layer_fused_split(g(msg), g(res), None, tail_w, head_w, bs, n, want_qkv=True)
+    f0, fb0, qkv0 = ops.layer_fused(g(msg), g(res), None, tail_w, head_w, want_feat=True)
+    assert torch.equal(f, f0) and torch.equal(fb, fb0) and torch.equal(qkv, qkv0)
+    want_qs, want_kv = _pack_reference(qkv.cpu(), bs, n)
+    assert torch.equal(qs.cpu(), want_qs) and torch.equal(kv.cpu(), want_kv)
+    _, _, none_qkv, qs2, kv2 = ops.layer_fused_split(g(msg), g(res), None, tail_w, head_w, bs, n)
+    assert none_qkv is None and torch.equal(qs2, qs) and torch.equal(kv2, kv)
+
+
+def _attention_split_model(q, k, v, compat):
+    """fp64 evaluation of the split arithmetic: S = qh kh + qh kl + ql kh; O = (P V) with V = vh + vl."""
+    (qh, ql), (kh, kl), (vh, vl) = _split(q), _split(k), _split(v)
+    d = lambda t: t.double()  # noqa: E731
+    s = d(qh) @ d(kh).T + d(qh) @ d(kl).T + d(ql) @ d(kh).T
+    w = torch.softmax(compat.double() * s * np.log(2.0), dim=-1)
+    return w @ (d(vh) + d(vl))
+
+
+@pytest.mark.parametrize("n,bs", [(257, 1), (1000, 2), (2053, 1), (96, 3), (33, 1), (5000, 1)])
+@pytest.mark.parametrize("nsplit", [1, 0, 3])
+def test_sc_attention_split_matches_fp64_softmax(n, bs, nsplit):
+    gen = torch.Generator().manual_seed(n + bs)
+    batch = synthetic.make_batch(bs, n, seed=70 + n)
+    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    # network-like magnitudes (|q.k|/sqrt(C) of order 1) and a harsh case (logits of order 30)
+    for qk_scale, tol_true in ((0.35, 2e-5), (2.0, 5e-4)):
+        q, k, v = (torch.randn(bs, n, 128, generator=gen) * s for s in (qk_scale, qk_scale, 1.0))
+        qkv = torch.cat([q * QSCALE, k, v], dim=-1).reshape(bs * n, 384)
+        qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+        msg = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit).cpu().reshape(bs, n, 128)
+        for b in range(bs):
+            cm = compat[b, :, :n].cpu()
+            want = _attention_ref(q[b], k[b], v[b], cm)
+            scale = max(1.0, float(want.abs().max()))
+            err = float((msg[b].double() - want).abs().max())
+            assert err < tol_true * scale, (qk_scale, b, err)     # split-precision error, grows with |logit|
+            model = _attention_split_model(q[b] * QSCALE, k[b], v[b], cm)
+            errm = float((msg[b].double() - model).abs().max())
+            assert errm < 2e-5 * scale, (qk_scale, b, errm)       # what is left: the 2^-17 residual of P's split
+
+
+def test_sc_attention_split_online_softmax_rescale_branch():
+    n = 320
+    gen = torch.Generator().manual_seed(5)
+    q, k, v = torch.randn(n, 128, generator=gen), torch.randn(n, 128, generator=gen), torch.randn(n, 128, generator=gen)
+    k[n - 3] = q[7] * 3.0            # spike in the last tile for query 7
+    k[2] = q[200] * 3.0              # spike in the first tile for query 200
+    compat = torch.ones(1, n, ops.compat_ld(n))
+    qkv = torch.cat([q * QSCALE, k, v], dim=-1)
+    qs, kv = ops.pack_qkv_split(g(qkv), 1, n)
+    for nsplit in (1, 2, 5):
+        msg = ops.sc_attention_split(qs, kv, g(compat), 1, n, nsplit=nsplit).cpu()
+        want = _attention_ref(q, k, v, compat[0, :, :n])
+        assert (msg.double() - want).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("n", [257, 1000])
+def test_split_and_fp32_attention_agree_through_the_encoder(n):
+    """Default (bf16x3) vs exact fp32 attention: 12-layer features within 1e-5, identical seeds/labels, R/t 1e-5."""
+    c = case(n)
+    model = c["model"]
+    out = {}
+    for prec in ("fp32", "bf16x3"):
+        model.attention_precision = prec
+        res = _forward(model, c["pair"])
+        out[prec] = (model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
+                     model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
+    model.attention_precision = "bf16x3"
+    scale = max(1.0, float(out["fp32"][0].abs().max()))
+    assert (out["fp32"][0] - out["bf16x3"][0]).abs().max() < 1e-5 * scale
+    assert torch.equal(out["fp32"][1], out["bf16x3"][1])
+    assert torch.equal(out["fp32"][2]["final_labels"], out["bf16x3"][2]["final_labels"])
+    assert (out["fp32"][2]["final_trans"] - out["bf16x3"][2]["final_trans"]).abs().max() < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------------
 # encoder end to end (a-2 + a-3 chained over 12 layers) and a-4
 # ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("n", [257, 1000])
-def test_encoder_and_head_match_oracle(n):
+def test_encoder_and_head_match_oracle(n, precision):
     c = case(n)
+    c["model"].attention_precision = precision
     data = {k: g(c["pair"][k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     data["testing"] = True
     c["model"](data)
@@ -221,6 +359,7 @@ def test_encoder_and_head_match_oracle(n):
     assert (normed - c["st"]["normed"]).abs().max() < 2e-5
     conf = c["model"].workspace_view("conf", 1, n)[:n].cpu()
     assert (conf - c["st"]["confidence"]).abs().max() < 3e-5 * max(scale, 1.0)
+    c["model"].attention_precision = "bf16x3"
 
 
 def test_normalize_confidence_stage():
@@ -435,10 +574,13 @@ def _forward(model, pair_or_batch):
     return res
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("n", [257, 1000, 2053])
-def test_forward_matches_oracle(n):
+def test_forward_matches_oracle(n, precision):
     c = case(n)
+    c["model"].attention_precision = precision
     res = _forward(c["model"], c["pair"])
+    c["model"].attention_precision = "bf16x3"
     assert res["M"] is None and res["final_trans"].shape == (1, 4, 4) and res["final_labels"].shape == (1, n)
     assert torch.equal(res["final_labels"].cpu(), c["res"]["final_labels"])            # inlier mask bit-exact
     assert (res["final_trans"].cpu() - c["res"]["final_trans"]).abs().max() < 1e-4      # R/t within 1e-4
@@ -446,14 +588,16 @@ def test_forward_matches_oracle(n):
     assert re < 1.0 and te < 5.0
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("name", ["n257_s0", "n1000_s1", "n1000_s2_defaultbn", "n2053_s3", "kitti_n1500_s4", "n5000_s5"])
-def test_forward_matches_reference_golden(name):
+def test_forward_matches_reference_golden(name, precision):
     fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
     kw = json.loads(str(fx["model_json"]))
     model = PointDSC(**kw)
     sd = synthetic.make_state_dict(model.state_dict(), seed=int(fx["wseed"]), randomize_bn=bool(fx["randomize_bn"]))
     model.load_state_dict(sd)
     model = model.eval().to(DEV)
+    model.attention_precision = precision
     batch = {k: torch.from_numpy(fx[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     res = _forward(model, batch)
     flips = int((res["final_labels"].cpu() != torch.from_numpy(fx["ref_final_labels"])).sum())
