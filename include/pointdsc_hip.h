@@ -173,6 +173,12 @@ int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const 
                                float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                void* stream);
 
+/* Diagnostics hook of the split-precision kernel: when a device buffer of (#workgroups * 8 waves * 8) int64 is set,
+ * the 8-wave kernel variant is replaced by an instrumented build that accumulates per-wave shader-clock sums of its
+ * phases (0 prologue, 1 first tile, 2 own-DMA wait, 3 barrier, 4 DMA issue, 5 phase A, 6 phase B, 7 rest) there.
+ * NULL (default) switches it off.  Used by tools/attention_trace.py only. */
+int pdsc_attention_trace(long long* device_buffer);
+
 /* ---- a-4  L2 normalisation + last classifier layer --------------------------------------------
  * replaces F.normalize (models/PointDSC.py:156) and classification.4 (:112,171).
  *   normed[m][:] = feat[m][:] / max(||feat[m]||_2, 1e-12);  conf[m] = <h2[m][0:32], w3> + b3 */

@@ -19,6 +19,7 @@
 // (global_load_lds_dwordx4, 1 KiB per wave instruction), double buffered, one barrier per tile.  Workgroups that
 // share a K/V range (same pair, same key split) are placed on the same XCD so the tiles are served by one L2.
 #include <stdlib.h>
+#include <type_traits>
 #include "attention_common.h"
 #include "split_layout.h"
 
@@ -33,39 +34,85 @@ struct AttSplitArgs {
     float* part_o;               // [bs][nsplit][Npad][128]
     float* part_ml;              // [bs][nsplit][Npad][2]
     int N, Npad, nsplit, num_tiles, nq, bs;
+    long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
 };
 
-template <int NW>
-__device__ __forceinline__ void issue_tile(const unsigned char* __restrict__ tile, unsigned char* buf, int wave, int lane) {
-    constexpr int PPW = 32 / NW;                 // 1-KiB pieces per wave
+// LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, descriptor + scalar offset + one 32-bit lane
+// offset -- no 64-bit address registers) of one part of a tile.  The K part (17 KiB) and the V^T part (20 KiB) of a
+// 37 KiB tile image are linear copies, pieces dealt round-robin to the waves.
+template <int NW, int BYTES>
+__device__ __forceinline__ void issue_linear(__amdgpu_buffer_rsrc_t rsrc, int src_off, unsigned char* dst, int wave, unsigned lane16) {
+    constexpr int PIECES = BYTES / 1024;
+    static_assert(BYTES % 1024 == 0, "tile parts are whole KiB");
 #pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-        const int i = wave * PPW + u;
-        __builtin_amdgcn_global_load_lds((gptr_t)(tile + i * 1024 + lane * 16), (lptr_t)(buf + i * 1024), 16, 0, 0);
+    for (int u = 0; u < (PIECES + NW - 1) / NW; ++u) {
+        const int i = wave + NW * u;
+        if ((u + 1) * NW <= PIECES || i < PIECES)        // wave-uniform; only the last round can be partial
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + i * 1024), 16, lane16, src_off + i * 1024, 0, 0);
     }
 }
+// The compat slice of this workgroup's NW*32 queries for one tile's 32 keys (128 B per query row); every wave fetches
+// its own 32 rows.  A wave instruction covers 8 rows x 128 B (8 lanes per row = one full cache line each); LDS row = 8
+// chunks of 16 B, chunk c stored at c ^ ((row >> 1) & 7) so that the per-query ds_read_b128 (row = lane) is
+// bank-conflict free -- the swizzle is in the SOURCE offsets `coff` because the LDS-DMA destination is lane-linear.
+__device__ __forceinline__ void issue_compat(__amdgpu_buffer_rsrc_t c_rsrc, int kt, const unsigned (&coff)[4],
+                                             unsigned char* dst, int wave) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(dst + (wave * 4 + u) * 1024), 16, coff[u], kt * (SPL_BK * 4), 0, 0);
+}
 
-template <int NW>
+// o *= alpha in place: one asm statement per accumulator register keeps the 64 registers where they are (a plain
+// `o[c][r] *= alpha` inside a branch made the register allocator keep two copies of O and move one per tile)
+__device__ __forceinline__ f32x16 scale_acc(f32x16 o, float alpha) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = o[r];
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v) : "v"(alpha));
+        o[r] = v;
+    }
+    return o;
+}
+
+constexpr float ATT_RESCALE_THR = 8.0f;   // running max is only moved when a logit exceeds it by 2^8 (log2 domain)
+constexpr int SPL_K_BYTES = 2 * 32 * SPL_K_STRIDE;    // Kh | Kl   17 KiB
+constexpr int SPL_V_BYTES = 2 * 128 * SPL_V_STRIDE;   // Vh | Vl   20 KiB
+
+// Software pipeline (per wave, per key tile t):  phase A = QK^T of tile t+1 on the matrix pipe WHILE the VALU turns
+// tile t's logits into P (exp2, hi/lo split);  phase B = P V of tile t WHILE the VALU forms tile t+1's logits.  Both
+// waves of a SIMD therefore always have matrix and vector work to interleave (with the plain QK -> softmax -> PV order
+// the two waves, released by the same barrier, do their softmax at the same time and the matrix pipe idles).
+// K and compat consequently run one tile ahead of V: per array two LDS stages, 138 KiB in all.
+#define PDSC_TRACE_STAMP(k)                                                      \
+    if (TRACE) {                                                                 \
+        const long long now__ = __builtin_readcyclecounter();                    \
+        tr[k] += now__ - tlast;                                                  \
+        tlast = now__;                                                           \
+    }
+
+template <int NW, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 32 KiB tile images
+    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = TRACE ? (long long)__builtin_readcyclecounter() : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const Ks = lds;                                  // 2 x 17 KiB
+    unsigned char* const Vs = lds + 2 * SPL_K_BYTES;                // 2 x 20 KiB
+    unsigned char* const Cs = Vs + 2 * SPL_V_BYTES;                 // 2 x NW*4 KiB
+    constexpr int CSTAGE = NW * 4096;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int N = a.N;
 
-    // block -> (query block, key split, pair).  Blocks b, b+8, b+16.. run on the same XCD: give every
-    // (pair, split) group -- the blocks that stream the same K/V tiles -- to one XCD when the group count allows.
+    // block -> (query block, key split, pair).  Blocks i, i+8, i+16.. run on the same XCD (own L2): hand every XCD
+    // a contiguous run of the (pair, split, query block) list, so that the workgroups streaming the same K/V tiles
+    // -- same pair, same split -- sit on one or two XCDs instead of all eight.
     int qb, grp;
     {
-        const int id = blockIdx.x, G = a.nsplit * a.bs;
-        if ((G & 7) == 0) {
-            const int i = id >> 3;
-            grp = (id & 7) + 8 * (i / a.nq);
-            qb = i % a.nq;
-        } else {
-            qb = id % a.nq;
-            grp = id / a.nq;
-        }
+        const int id = blockIdx.x, W = gridDim.x;
+        const int rank = (W & 7) == 0 ? (id & 7) * (W >> 3) + (id >> 3) : id;
+        grp = rank / a.nq;
+        qb = rank % a.nq;
     }
     const int sp = grp % a.nsplit, b = grp / a.nsplit;
 
@@ -73,12 +120,50 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const int kt0 = sp * per + min(sp, rem);
     const int kt1 = kt0 + per + (sp < rem ? 1 : 0);
 
-    const unsigned char* kvb = a.kv + (size_t)b * a.num_tiles * SPL_TILE_BYTES;
-    const int qrow = min(qb * (NW * 32) + wave * 32 + l31, N - 1);
-    const float* crow = a.compat + ((size_t)b * N + qrow) * a.ld + 4 * h;
+    // buffer descriptors of this pair's K/V tile stream and compat matrix (both < 4 GiB per pair)
+    const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.kv + (size_t)b * a.num_tiles * SPL_TILE_BYTES), 0, a.num_tiles * SPL_TILE_BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.compat + (size_t)b * N * a.ld), 0, (int)((unsigned)N * (unsigned)a.ld * 4u), 0x00020000);
+    const unsigned lane16 = lane * 16;
+    unsigned coff[4];                            // byte offset of this lane's 16-B compat chunk per DMA piece, tile 0
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = wave * 32 + 8 * u + (lane >> 3);             // row inside the workgroup's query block
+        const int c = (lane & 7) ^ ((row >> 1) & 7);                 // logical 16-B chunk (4 keys) this lane fetches
+        const int q = min(qb * (NW * 32) + row, N - 1);
+        coff[u] = (unsigned)q * (unsigned)a.ld * 4u + 16u * c;
+    }
+    // DMA work of one wave for one loop iteration kt, as 9 slots that are issued BETWEEN the MFMA groups (an LDS-DMA
+    // instruction costs its wave ~100 cycles of issue; bunched after the barrier that is ~1000 cycles per tile during
+    // which neither wave of a SIMD feeds the matrix pipe):
+    //   slots 0-3: compat_{kt+2} pieces (HBM latency: first), slots 4-8: K_{kt+2} / V_{kt+1} pieces i = wave + NW*u.
+    // Straight-line: tiles past the end of the split are fetched like any other (<= 2 wasted tiles per workgroup; past
+    // the end of the buffer the descriptor's bounds check returns zeros); they land in stages nobody reads any more.
+    constexpr int KPIECES = SPL_K_BYTES / 1024, PIECES = SPL_TILE_BYTES / 1024, KV_SLOTS = (PIECES + NW - 1) / NW;
+    auto dma_slot = [&](int kt, int st, int slot) {
+        if (slot < 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * 4 + slot) * 1024), 16, coff[slot],
+                                                     (kt + 2) * (SPL_BK * 4), 0, 0);
+        } else {
+            const int i = min(wave + NW * (slot - 4), PIECES - 1);      // surplus slots repeat the last piece
+            const bool isk = i < KPIECES;                                // wave-uniform
+            unsigned char* dst = isk ? Ks + st * SPL_K_BYTES + i * 1024 : Vs + (st ^ 1) * SPL_V_BYTES + (i - KPIECES) * 1024;
+            const int src = ((isk ? kt + 2 : kt + 1) * PIECES + i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (lptr_t)dst, 16, lane16, src, 0, 0);
+        }
+    };
+    constexpr int DMA_SLOTS = 4 + KV_SLOTS;      // 9 (NW = 8) or 14 (NW = 4): 8 go after the QK steps, the rest after PV steps
+    static_assert(DMA_SLOTS <= 16, "16 places per iteration");
+    auto dma_k = [&](int kt) { issue_linear<NW, SPL_K_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_KH, Ks + ((kt - kt0) & 1) * SPL_K_BYTES, wave, lane16); };
+    auto dma_v = [&](int kt) { issue_linear<NW, SPL_V_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_VH, Vs + ((kt - kt0) & 1) * SPL_V_BYTES, wave, lane16); };
+    auto dma_c = [&](int kt) { issue_compat(c_rsrc, kt, coff, Cs + ((kt - kt0) & 1) * CSTAGE, wave); };
 
-    // prologue: first tile in flight, then this lane's Q fragments (hi and lo) and the first compat slice
-    issue_tile<NW>(kvb + (size_t)kt0 * SPL_TILE_BYTES, lds, wave, lane);
+    // prologue: K, compat of the first two tiles and V of the first in flight, then this lane's Q fragments
+    dma_k(kt0); dma_c(kt0);
+    if (kt0 + 1 < kt1) { dma_k(kt0 + 1); dma_c(kt0 + 1); }
+    dma_v(kt0);
+    const int qrow = min(qb * (NW * 32) + wave * 32 + l31, N - 1);
     bf16x8 qh[8], ql[8];
     {
         const __bf16* qsrc = a.qs + ((size_t)b * N + qrow) * SPL_Q_LD + 8 * h;
@@ -88,101 +173,150 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             ql[j] = *reinterpret_cast<const bf16x8*>(qsrc + PDSC_CHANNELS + 16 * j);
         }
     }
-    f32x4 cc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const f32x4*>(crow + kt0 * SPL_BK + 8 * g);
 
     f32x16 o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;              // m_run: reference exponent of this query's p values (set by the first tile)
 
-    const int koff = l31 * 256;                  // K image row of this lane (key l31)
-    const int ksw = l31 & 15;
-    const int voff = l31 * 64;                   // V^T image row of this lane (channel 32c + l31)
-    const int vsw = (l31 >> 2) & 3;
+    const int koff = l31 * SPL_K_STRIDE + 16 * h;   // K image: row of key l31, chunk 2j+h -> + 32 j   (immediates)
+    const int voff = l31 * SPL_V_STRIDE + 16 * h;   // V^T image: row of channel 32c + l31, chunk 2j+h -> + 32 j + 32 c stride
+    const int crow_off = (wave * 32 + l31) * 128;   // compat row of this lane's query in a compat stage
+    const int csw = ((wave * 32 + l31) >> 1) & 7;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        const unsigned char* T = lds + buf * SPL_TILE_BYTES;
-        // tile kt landed (own LDS-DMA pieces) + everyone finished reading the other buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < kt1) issue_tile<NW>(kvb + (size_t)(kt + 1) * SPL_TILE_BYTES, lds + (buf ^ 1) * SPL_TILE_BYTES, wave, lane);
-
-        // ---- S^T = K Q^T : hi*hi on one accumulator, the two cross terms on another --------------------
-        f32x16 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int co = koff + (((2 * j + h) ^ ksw) << 4);
-            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(T + SPL_KH + co);
-            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(T + SPL_KL + co);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[j], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[j], s1, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[j], s1, 0, 0, 0);
-        }
-
-        // ---- online softmax (log2 domain), lane-local: this lane = query l31, keys (r&3)+8(r>>2)+4h --------
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = cc[r >> 2][r & 3] * (s0[r] + s1[r]);
-        if (kt + 1 < kt1) {   // compat of the NEXT tile into the registers just consumed
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const f32x4*>(crow + (kt + 1) * SPL_BK + 8 * g);
-        }
+    // logits of one tile relative to the current reference: tl = compat * s - m_run, keys >= N masked
+    auto mask_tail = [&](int kt, float (&tl)[16]) {
         if ((kt + 1) * SPL_BK > N) {   // tail tile (wave-uniform branch)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * SPL_BK + (r & 3) + 8 * (r >> 2) + 4 * h;
-                x[r] = key < N ? x[r] : -INFINITY;
+                tl[r] = key < N ? tl[r] : -INFINITY;
             }
         }
-        float mloc = x[0];
+    };
+    auto row_max = [&](const float (&tl)[16]) {
+        float m = tl[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, x[r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        if (!__all(m_new == m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, tl[r]);
+        return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+
+    float tl[16];                                // logits of the tile whose P is formed next
+    f32x16 sacc;
+    PDSC_TRACE_STAMP(0)                          // 0: prologue issue + Q loads
+    // ---- tile kt0: S^T = K Q^T, logits, reference = row maximum ---------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const unsigned char* K = Ks;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
-            m_run = m_new;
+        for (int j = 0; j < 8; ++j) {
+            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 32 * j);
+            const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 32 * j);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(Cs + crow_off + (((2 * g + h) ^ csw) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tl[4 * g + e] = cc[e] * sacc[4 * g + e];
+        }
+        mask_tail(kt0, tl);
+        m_run = row_max(tl);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tl[r] -= m_run;
+    }
+
+    PDSC_TRACE_STAMP(1)                          // 1: first tile (wait + QK + logits)
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int st = (kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
+        const bool has_next = kt + 1 < kt1;
+        // K_{kt+1}, compat_{kt+1}, V_kt landed (own LDS-DMA pieces) + everyone finished the previous iteration
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PDSC_TRACE_STAMP(2)                      // 2: wait for own DMA
+        __syncthreads();
+        PDSC_TRACE_STAMP(3)                      // 3: barrier
+        PDSC_TRACE_STAMP(4)                      // 4: (unused)
+
+        // ---- phase A: S^T(kt+1) = K Q^T on the matrix pipe | P(kt) = exp2(tl), hi/lo split on the VALU ---------
+        // (24 MFMAs on one accumulator: dependent bf16 MFMAs issue back to back at full rate, tools/mfma_chain_probe.hip.
+        //  Straight-line on purpose: on the last tile the "next" K stage holds stale data and the 24 MFMAs + logits are
+        //  wasted work that nothing reads -- cheaper than a second code path, which makes the register allocator keep
+        //  copies of the 64 accumulator registers.)
         float psum = 0.f;
         bf16x8 ph[2], pl[2];
+        {
+            const unsigned char* K = Ks + (st ^ 1) * SPL_K_BYTES;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(x[r] - m_run);
-            psum += p;
-            __bf16 hi, lo;
-            split_bf16(p, hi, lo);
-            ph[r >> 3][r & 7] = hi;
-            pl[r >> 3][r & 7] = lo;
+            for (int j = 0; j < 8; ++j) {
+                const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 32 * j);
+                const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 32 * j);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
+                dma_slot(kt, st, j);
+#pragma unroll
+                for (int r = 2 * j; r < 2 * j + 2; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(tl[r]);
+                    psum += p;
+                    __bf16 hi, lo;
+                    split_bf16(p, hi, lo);
+                    ph[r >> 3][r & 7] = hi;
+                    pl[r >> 3][r & 7] = lo;
+                }
+            }
         }
         l_run += psum;
+        PDSC_TRACE_STAMP(5)                      // 5: phase A
 
-        // ---- O^T += V^T P^T : small terms first ------------------------------------------------------------
+        // ---- phase B: O^T += V^T P^T (8 steps: channel block c, key half j) | logits of tile kt+1 ---------------
+        {
+            const unsigned char* V = Vs + st * SPL_V_BYTES;
+            const unsigned char* Cn = Cs + (st ^ 1) * CSTAGE + crow_off;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int vo = c * 2048 + voff + (((2 * j + h) ^ vsw) << 4);
-                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(T + SPL_VH + vo);
-                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(T + SPL_VL + vo);
+            for (int u = 0; u < 8; ++u) {
+                const int c = u >> 1, j = u & 1;
+                const int vo = c * 32 * SPL_V_STRIDE + voff + 32 * j;
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(V + vo);
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(V + 128 * SPL_V_STRIDE + vo);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[j], o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[j], o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[j], o[c], 0, 0, 0);
+                if (8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
+                if (u & 1) {                     // compat chunk 2g+h = keys 8g+4h..+3 = accumulator registers 4g..4g+3
+                    const int g = u >> 1;
+                    const f32x4 cc = *reinterpret_cast<const f32x4*>(Cn + (((2 * g + h) ^ csw) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                }
             }
         }
+
+        PDSC_TRACE_STAMP(6)                      // 6: phase B
+        // ---- does tile kt+1 move the reference exponent of any query?  (rare after the first tiles) -------------
+        if (has_next) {
+            mask_tail(kt + 1, tl);
+            const float mloc = row_max(tl);
+            if (!__all(mloc <= ATT_RESCALE_THR)) {
+                const float delta = mloc > ATT_RESCALE_THR ? mloc : 0.f;      // per query; 0 = stays
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l_run *= alpha;
+                m_run += delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tl[r] -= delta;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = scale_acc(o[c], alpha);
+            }
+        }
+        PDSC_TRACE_STAMP(7)
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead DMA of the last iterations targets this workgroup's LDS
     // ---- epilogue: o[c][4g+e] = O^T[channel 32c + 8g + 4h + e][query l31] ---------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int query = qb * (NW * 32) + wave * 32 + l31;
@@ -210,6 +344,15 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 a.part_ml[slot * 2 + 0] = m_run;
                 a.part_ml[slot * 2 + 1] = l_tot;
             }
+        }
+    }
+    if (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PDSC_TRACE_STAMP(7)                      // 7: rescale decisions (accumulated below) + epilogue
+        if (lane == 0 && a.trace) {
+            long long* dst = a.trace + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k] = tr[k];
         }
     }
 }
@@ -263,6 +406,7 @@ __global__ __launch_bounds__(256) void pack_qkv_split_kernel(const float* __rest
         *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
         *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
     }
+    spl_zero_pads(img, t);
 }
 
 // waves per workgroup and key split for (bs, N): fill the 256 CUs (one 8-wave or two 4-wave workgroups each)
@@ -326,6 +470,12 @@ extern "C" int pdsc_pack_qkv_split(const float* qkv, void* q_split, void* kv_til
     return check_launch("pdsc_pack_qkv_split");
 }
 
+static long long* g_att_trace = nullptr;
+extern "C" int pdsc_attention_trace(long long* device_buffer) {   // diagnostics: see include/pointdsc_hip.h
+    g_att_trace = device_buffer;
+    return PDSC_OK;
+}
+
 extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
                                        float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                        void* stream) {
@@ -355,19 +505,24 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     a.nq = ceil_div(N, nw * 32);
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
+    a.trace = g_att_trace;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = 2 * SPL_TILE_BYTES;
+    const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 4096);   // 2 stages x (K 17 KiB + V 20 KiB + compat nw*4 KiB)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sc_attention_split_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (SPL_TILE_BYTES + 4 * 4096));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sc_attention_split_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (SPL_TILE_BYTES + 8 * 4096));
         attr_set = true;
     }
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
     profile_mark_begin(PDSC_PROF_ATTENTION, st);
-    if (nw == 8)
+    if (nw == 8 && a.trace) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sc_attention_split_kernel<8, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (SPL_TILE_BYTES + 8 * 4096));
+        hipLaunchKernelGGL((sc_attention_split_kernel<8, true>), dim3(grid), dim3(512), lds_bytes, st, a);
+    } else if (nw == 8)
         hipLaunchKernelGGL(sc_attention_split_kernel<8>, dim3(grid), dim3(512), lds_bytes, st, a);
     else
         hipLaunchKernelGGL(sc_attention_split_kernel<4>, dim3(grid), dim3(256), lds_bytes, st, a);

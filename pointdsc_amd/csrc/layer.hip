@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
                 const int valid = min(LF_ROWS, M - m0);
                 if (c == 0) tile_to_split<0>(Xb, a.qs + (size_t)m0 * SPL_Q_LD, img, valid, t);
                 else if (c == 1) tile_to_split<1>(Xb, nullptr, img, valid, t);
-                else tile_to_split<2>(Xb, nullptr, img, valid, t);
+                else { tile_to_split<2>(Xb, nullptr, img, valid, t); spl_zero_pads(img, t); }
             }
             if (c < 2) __syncthreads();
         }

@@ -7,14 +7,16 @@
 // three v_mfma_f32_32x32x16_bf16 per operand pair = 3/16 of the cost of the exact fp32 MFMA.
 //
 //   Q stream : [bs*N][256] bf16   row = (hi[0..127] | lo[0..127]), natural channel order
-//   KV stream: [bs][ntiles][SPL_TILE_BYTES]  one 32 KiB block per tile of 32 keys, laid out as the exact LDS image
+//   KV stream: [bs][ntiles][SPL_TILE_BYTES]  one 37 KiB block per tile of 32 keys, laid out as the exact LDS image
 //              the attention kernel wants, so that the LDS-DMA copy is linear and fully coalesced:
-//       +SPL_KH / +SPL_KL : K hi / lo   [32 keys][16 chunks of 8 channels (16 B)], chunk stored at chunk ^ (key & 15)
-//                           (XOR swizzle: the column-slice ds_read_b128 of 16 different keys hits 16 different bank slots)
-//       +SPL_VH / +SPL_VL : V^T hi / lo [128 channels][4 chunks of 8 keys (16 B)]; chunk jh = 2j+h holds, in order
-//                           e = 0..7, keys 16j + 8(e>>2) + 4h + (e&3) -- the keys lane-half h holds in accumulator
-//                           registers 8j..8j+7 of S^T = K Q^T -- stored at jh ^ ((channel>>2) & 3)
-//   keys >= N of the last tile are zero.
+//       +SPL_KH / +SPL_KL : K hi / lo   [32 keys][SPL_K_STRIDE = 272 B]: 16 chunks of 8 channels (16 B) + one pad chunk.
+//                           The odd number of chunks per row rotates consecutive keys by one 16-B bank slot, so the
+//                           column-slice ds_read_b128 (16 different keys, same chunk) is conflict-free AND every read of
+//                           a lane is `lane base + immediate` (an XOR swizzle would need one address register per chunk).
+//       +SPL_VH / +SPL_VL : V^T hi / lo [128 channels][SPL_V_STRIDE = 80 B]: 4 chunks of 8 keys (16 B) + one pad chunk;
+//                           chunk jh = 2j+h holds, in order e = 0..7, keys 16j + 8(e>>2) + 4h + (e&3) -- the keys
+//                           lane-half h holds in accumulator registers 8j..8j+7 of S^T = K Q^T.
+//   keys >= N of the last tile and all pad chunks are zero.
 #pragma once
 #include "pdsc_common.h"
 
@@ -24,17 +26,31 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SPL_BK = 32;                       // keys per tile
-constexpr int SPL_TILE_BYTES = 32768;
-constexpr int SPL_KH = 0, SPL_KL = 8192, SPL_VH = 16384, SPL_VL = 24576;
+constexpr int SPL_K_STRIDE = 272, SPL_V_STRIDE = 80;      // bytes per K row (key) / V^T row (channel), pad chunk included
+constexpr int SPL_KH = 0, SPL_KL = 32 * SPL_K_STRIDE, SPL_VH = 2 * SPL_KL, SPL_VL = SPL_VH + 128 * SPL_V_STRIDE;
+constexpr int SPL_TILE_BYTES = SPL_VL + 128 * SPL_V_STRIDE;     // 37888 = 37 KiB
 constexpr int SPL_Q_LD = 2 * PDSC_CHANNELS;     // bf16 elements per row of the Q stream
 
-__host__ __device__ __forceinline__ int spl_k_offset(int key, int chunk) { return key * 256 + ((chunk ^ (key & 15)) << 4); }
-__host__ __device__ __forceinline__ int spl_v_offset(int ch, int jh) { return ch * 64 + ((jh ^ ((ch >> 2) & 3)) << 4); }
+__host__ __device__ __forceinline__ int spl_k_offset(int key, int chunk) { return key * SPL_K_STRIDE + (chunk << 4); }   // chunk 16 = pad
+__host__ __device__ __forceinline__ int spl_v_offset(int ch, int jh) { return ch * SPL_V_STRIDE + (jh << 4); }          // jh 4 = pad
 __host__ __device__ __forceinline__ int spl_v_key(int jh, int e) { return 16 * (jh >> 1) + 8 * (e >> 2) + 4 * (jh & 1) + (e & 3); }
 
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
     hi = (__bf16)x;
     lo = (__bf16)(x - (float)hi);
+}
+
+// pad chunks of one tile image (never read by the attention kernel; zeroed so the stream is deterministic)
+__device__ __forceinline__ void spl_zero_pads(unsigned char* __restrict__ img, int t) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (t < 32) {
+        *reinterpret_cast<f32x4*>(img + SPL_KH + spl_k_offset(t, 16)) = z;
+        *reinterpret_cast<f32x4*>(img + SPL_KL + spl_k_offset(t, 16)) = z;
+    }
+    if (t < 128) {
+        *reinterpret_cast<f32x4*>(img + SPL_VH + spl_v_offset(t, 4)) = z;
+        *reinterpret_cast<f32x4*>(img + SPL_VL + spl_v_offset(t, 4)) = z;
+    }
 }
 
 static inline int spl_num_tiles(int N) { return ceil_div(N, SPL_BK); }

@@ -220,29 +220,25 @@ def _pack_reference(qkv, bs, n):
     qkv = qkv.reshape(bs, n, 384)
     qh, ql = _split(qkv[..., :128])
     qs = torch.cat([qh, ql], dim=-1).reshape(bs * n, 256)
-    kv = torch.zeros(bs, tiles, 4, 4096, dtype=torch.bfloat16)
     pad = torch.zeros(bs, tiles * 32, 256)
     pad[:, :n] = qkv[..., 128:]
     k = pad[..., :128].reshape(bs, tiles, 32, 128)
     v = pad[..., 128:].reshape(bs, tiles, 32, 128)
-    key = torch.arange(32)
-    # K image: [key][chunk ^ (key & 15)][8 channels]
-    kimg = torch.zeros(bs, tiles, 32, 16, 8)
-    for chunk in range(16):
-        dst = chunk ^ (key & 15)
-        kimg[:, :, key, dst] = k[:, :, key, 8 * chunk:8 * chunk + 8]
-    # V^T image: [channel][jh ^ ((channel >> 2) & 3)][e] = V[16j + 8(e>>2) + 4h + (e&3)][channel], jh = 2j+h
-    vimg = torch.zeros(bs, tiles, 128, 4, 8)
-    ch = torch.arange(128)
+    # K image: [32 keys][16 chunks of 8 channels + 1 zero pad chunk]  (row stride 272 B)
+    kimg = torch.zeros(bs, tiles, 32, 17, 8)
+    kimg[:, :, :, :16] = k.reshape(bs, tiles, 32, 16, 8)
+    # V^T image: [128 channels][4 chunks of 8 keys + 1 zero pad chunk] (row stride 80 B);
+    # chunk jh = 2j+h, element e = V[16j + 8(e>>2) + 4h + (e&3)][channel]
+    vimg = torch.zeros(bs, tiles, 128, 5, 8)
     for jh in range(4):
-        dst = jh ^ ((ch >> 2) & 3)
         for e in range(8):
             kk = 16 * (jh >> 1) + 8 * (e >> 2) + 4 * (jh & 1) + (e & 3)
-            vimg[:, :, ch, dst, e] = v[:, :, kk, :][..., ch]
-    for which, img in ((0, kimg), (2, vimg)):
-        hi, lo = _split(img.reshape(bs, tiles, 4096))
-        kv[:, :, which], kv[:, :, which + 1] = hi, lo
-    return qs.view(torch.uint8).reshape(-1), kv.view(torch.uint8).reshape(-1)
+            vimg[:, :, :, jh, e] = v[:, :, kk, :]
+    kh, kl = _split(kimg.reshape(bs, tiles, -1))
+    vh, vl = _split(vimg.reshape(bs, tiles, -1))
+    kv = torch.cat([kh, kl, vh, vl], dim=-1)
+    assert kv.shape[-1] * 2 == 37888
+    return qs.view(torch.uint8).reshape(-1), kv.contiguous().view(torch.uint8).reshape(-1)
 
 
 @pytest.mark.parametrize("n,bs", [(33, 1), (96, 3), (257, 2), (1000, 1)])
