@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--num-corr", type=int, default=5000, help="N correspondences per pair (headline: 5000)")
     ap.add_argument("--pairs-per-gpu", type=int, default=4, help="batch per GPU per step (32 pairs / 8 GPUs)")
-    ap.add_argument("--attention-precision", choices=["bf16x3", "fp32"], default="bf16x3",
+    ap.add_argument("--attention-precision", choices=["bf16x3", "fp32", "bf16x3_all"], default="bf16x3",
                     help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs timed on the CPU oracle (bounded sample)")

@@ -56,8 +56,11 @@ typedef struct pdsc_config {
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
  *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
  *           ~2^-16 relative error per product; 12-layer features within 5e-6, R/t within 1e-5 of the fp32 path.
- *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time. */
-enum pdsc_attention_precision { PDSC_ATT_BF16X3 = 0, PDSC_ATT_FP32 = 1 };
+ *           The point-wise GEMMs between the attention calls stay exact fp32.                          [default]
+ *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time.
+ *   BF16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): ~10 us less per layer, but their error lands on the
+ *           residual stream un-averaged: 12-layer features within 2e-5 of the fp32 path (opt-in). */
+enum pdsc_attention_precision { PDSC_ATT_BF16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_BF16X3_ALL = 2 };
 
 /* ---- packed weights --------------------------------------------------------------------------
  * One flat fp32 buffer holding the model with BatchNorm (eval) folded into the preceding conv and
@@ -143,12 +146,30 @@ int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, f
  * operand streams of the split-precision attention (layout: pointdsc_amd/csrc/split_layout.h):
  *   q_split  [bs*N][256] bf16 (hi | lo), pdsc_split_q_bytes(bs, N) bytes;
  *   kv_tiles [bs][ceil(N/32)][32 KiB],   pdsc_split_kv_bytes(bs, N) bytes.
- * Rows are bs pairs of N points (a 32-point tile never straddles two pairs). */
-int pdsc_layer_fused_split(const float* msg, const float* res, const float* feat_in, float* feat_out,
+ * Rows are bs pairs of N points (a 32-point tile never straddles two pairs).
+ * The tail input is either `msg` (merged rows) or the un-merged key-split partials (`part_o`, `part_ml`, nsplit, Npad)
+ * exactly as pdsc_sc_attention_split leaves them in its scratch when called with msg == NULL: the merge then happens
+ * while the tile is loaded (no combine launch, no round trip of msg through HBM). */
+int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                           const float* res, const float* feat_in, float* feat_out,
                            float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
                            const float* w1, const float* b1, const float* w2, const float* b2,
                            const float* w3, const float* b3, const float* wp, const float* bp,
                            const float* wq, const float* bq, int bs, int N, void* stream);
+
+/* Split-precision variant of the whole chain (PDSC_ATT_BF16X3_ALL: every GEMM as three bf16 MFMAs per operand pair);
+ * same tail-input convention.  Weights come from the split-weight buffer:
+ *   pdsc_wsplit_bytes(cfg) bytes, filled once per model by pdsc_wsplit_build(cfg, wpack, wsplit, stream);
+ *   matrix of `section` (PDSC_W_PCN_W, _QKV_W, _FC1_W, _FC2_W, _FC3_W) of `layer` starts at bf16 element
+ *   pdsc_wsplit_offset(cfg, section, layer): [out][in] hi, then [out][in] lo.  Biases stay fp32 (packed buffer). */
+size_t    pdsc_wsplit_bytes(const pdsc_config* cfg);
+long long pdsc_wsplit_offset(const pdsc_config* cfg, int section, int layer);
+int       pdsc_wsplit_build(const pdsc_config* cfg, const float* wpack, void* wsplit, void* stream);
+int pdsc_layer_fused_x3(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                        const float* res, const float* feat_in, float* feat_out, float* featB_out, float* qkv_out,
+                        void* q_split, void* kv_tiles,
+                        const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
+                        const void* wp, const float* bp, const void* wq, const float* bq, int bs, int N, void* stream);
 
 /* ---- a-3  spatial-consistency guided non-local attention ---------------------------------------
  * replaces models/PointDSC.py:39-42 (both einsums and the softmax; N x N scores never materialised).
@@ -172,6 +193,9 @@ int    pdsc_attention_split_default_split(int bs, int N);
 int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
                                float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                void* stream);
+/* msg == NULL (only when the key split is > 1): the partials are left un-merged in `scratch` for pdsc_layer_fused_x3:
+ * part_o = scratch as [bs][nsplit][Npad][C] floats, Npad = N rounded up to 256, part_ml right behind it as
+ * [bs][nsplit][Npad][2]. */
 
 /* Diagnostics hook of the split-precision kernel: when a device buffer of (#workgroups * 8 waves * 8) int64 is set,
  * the 8-wave kernel variant is replaced by an instrumented build that accumulates per-wave shader-clock sums of its
@@ -246,7 +270,7 @@ int pdsc_post_refinement(const float* initial_trans, const float* src_keypts, co
  * replaces PointDSC.forward(data) with 'testing' in data (models/PointDSC.py:128-197).
  * corr_pos [bs][N][in_dim], src/tgt [bs][N][3]  ->  final_trans [bs][16], final_labels [bs][N] (0/1).
  * num_seeds = int(N * ratio) computed by the caller in double precision like the reference (:174). */
-int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack,
+int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void* wsplit /* needed for PDSC_ATT_BF16X3_ALL only, else may be NULL */,
                          const float* corr_pos, const float* src_keypts, const float* tgt_keypts,
                          int bs, int N, int num_seeds,
                          float* final_trans, float* final_labels,

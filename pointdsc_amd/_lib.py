@@ -52,7 +52,11 @@ SIGNATURES = {
     "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pdsc_layer_fused": (_i, [_vp] * 16 + [_i, _vp]),
-    "pdsc_layer_fused_split": (_i, [_vp] * 18 + [_i, _i, _vp]),
+    "pdsc_layer_fused_split": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 17 + [_i, _i, _vp]),
+    "pdsc_wsplit_bytes": (_sz, [_cfgp]),
+    "pdsc_wsplit_offset": (_ll, [_cfgp, _i, _i]),
+    "pdsc_wsplit_build": (_i, [_cfgp, _vp, _vp, _vp]),
+    "pdsc_layer_fused_x3": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 17 + [_i, _i, _vp]),
     "pdsc_split_q_bytes": (_sz, [_i, _i]),
     "pdsc_split_kv_bytes": (_sz, [_i, _i]),
     "pdsc_pack_qkv_split": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -76,7 +80,7 @@ SIGNATURES = {
     "pdsc_profile_enable": (_i, [_i]),
     "pdsc_profile_reset": (_i, []),
     "pdsc_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "pdsc_forward_testing": (_i, [_cfgp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pdsc_forward_testing": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

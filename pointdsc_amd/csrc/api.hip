@@ -53,7 +53,7 @@ static bool config_ok(const pdsc_config* c) {
     if (c->num_iterations < 0 || c->num_iterations > PDSC_MAX_POWER_ITERS) { set_error("num_iterations=%d", c->num_iterations); return false; }
     if (c->k < 1 || c->k > PDSC_MAX_K) { set_error("k=%d must be in [1,%d]", c->k, PDSC_MAX_K); return false; }
     if (c->refine_iters < 0) { set_error("refine_iters=%d", c->refine_iters); return false; }
-    if (c->attention_precision != PDSC_ATT_BF16X3 && c->attention_precision != PDSC_ATT_FP32) {
+    if (c->attention_precision < PDSC_ATT_BF16X3 || c->attention_precision > PDSC_ATT_BF16X3_ALL) {
         set_error("attention_precision=%d", c->attention_precision); return false;
     }
     return true;
@@ -147,8 +147,8 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
         const size_t a32 = pdsc_attention_scratch_bytes(bs, N, 0), a16 = pdsc_attention_split_scratch_bytes(bs, N, 0);
         L.add("att_scratch", c->attention_precision == PDSC_ATT_FP32 ? a32 : a16);
     }
-    L.add("q_split", c->attention_precision == PDSC_ATT_BF16X3 ? pdsc_split_q_bytes(bs, N) : 0);
-    L.add("kv_tiles", c->attention_precision == PDSC_ATT_BF16X3 ? pdsc_split_kv_bytes(bs, N) : 0);
+    L.add("q_split", c->attention_precision != PDSC_ATT_FP32 ? pdsc_split_q_bytes(bs, N) : 0);
+    L.add("kv_tiles", c->attention_precision != PDSC_ATT_FP32 ? pdsc_split_kv_bytes(bs, N) : 0);
     L.add("normed", M * C * f);
     L.add("h1", M * 32 * f);
     L.add("h2", M * 32 * f);
@@ -236,7 +236,7 @@ extern "C" int pdsc_profile_read(int kind, double* total_ms, int* launches) {
         if (rc__ != PDSC_OK) return rc__; \
     } while (0)
 
-extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const float* corr_pos,
+extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
                                     const float* src, const float* tgt, int bs, int N, int num_seeds,
                                     float* final_trans, float* final_labels, void* workspace, size_t workspace_bytes,
                                     void* stream) {
@@ -267,11 +267,13 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     int *seeds = I("seeds"), *knn_idx = I("knn_idx"), *counts = I("counts"), *best = I("best"), *solves = I("solves");
     unsigned int* conv_mask = (unsigned int*)(ws + L.find("conv_mask"));
     void* att_scratch = ws + L.find("att_scratch");
-    const bool split = cfg->attention_precision == PDSC_ATT_BF16X3;
+    const bool split = cfg->attention_precision != PDSC_ATT_FP32;
+    const bool x3_gemm = cfg->attention_precision == PDSC_ATT_BF16X3_ALL;
+    PDSC_REQUIRE(!x3_gemm || wsplit, "pdsc_forward_testing: PDSC_ATT_BF16X3_ALL needs the split-weight buffer (pdsc_wsplit_build)");
+    auto WS = [&](int section, int layer) { return (const void*)((const unsigned short*)wsplit + pdsc_wsplit_offset(cfg, section, layer)); };
     const size_t att_bytes = split ? pdsc_attention_split_scratch_bytes(bs, N, 0) : pdsc_attention_scratch_bytes(bs, N, 0);
     void* q_split = split ? ws + L.find("q_split") : nullptr;
     void* kv_tiles = split ? ws + L.find("kv_tiles") : nullptr;
-    float* qkv32 = split ? nullptr : qkv;
 
     // Step 1 (models/PointDSC.py:150-155): compat, then the SCNonlocal encoder
     PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
@@ -281,25 +283,60 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
         const char* env = getenv("PDSC_FUSED_LAYERS");          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
         fused = env ? atoi(env) : 1;
     }
-    if (fused && cfg->num_layers > 0) {
-        // head of layer 0, then per layer: attention + (tail of layer i fused with head of layer i+1)
-        PDSC_TRY(pdsc_layer_fused_split(nullptr, nullptr, featA, nullptr, featB, qkv32, q_split, kv_tiles, nullptr, nullptr,
-                                        nullptr, nullptr, nullptr, nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
-                                        W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
+    if (fused && cfg->num_layers > 0 && split) {
+        // split precision: head of layer 0, then per layer attention (partials left un-merged when the keys are split)
+        // + ONE launch for the merge, the tail of layer i and the head of layer i+1
+        const int ns = pdsc_attention_split_default_split(bs, N);
+        const int Npad = (int)round_up(N, 256);
+        const float* part_o = ns > 1 ? (const float*)att_scratch : nullptr;
+        const float* part_ml = ns > 1 ? part_o + (size_t)bs * ns * Npad * C : nullptr;
+        if (x3_gemm)
+            PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
+                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
+                                         WS(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
+        else
+            PDSC_TRY(pdsc_layer_fused_split(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
+                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
+                                            W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            if (split)
-                PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
-            else
-                PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, ns > 1 ? nullptr : msg, att_scratch, att_bytes, bs, N,
+                                             ns, stream));
             const bool last = i + 1 == cfg->num_layers;
-            PDSC_TRY(pdsc_layer_fused_split(msg, cur, nullptr, last ? featA : nullptr, last ? nullptr : nxt,
-                                            last ? nullptr : qkv32, last ? nullptr : q_split, last ? nullptr : kv_tiles,
-                                            W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
-                                            W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
-                                            last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
-                                            last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
-                                            bs, N, stream));
+            if (x3_gemm)
+                PDSC_TRY(pdsc_layer_fused_x3(ns > 1 ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
+                                             last ? nullptr : nxt, nullptr, last ? nullptr : q_split, last ? nullptr : kv_tiles,
+                                             WS(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), WS(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
+                                             WS(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
+                                             last ? nullptr : WS(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
+                                             last ? nullptr : WS(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
+                                             bs, N, stream));
+            else
+                PDSC_TRY(pdsc_layer_fused_split(ns > 1 ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
+                                                last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,
+                                                last ? nullptr : kv_tiles,
+                                                W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
+                                                W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
+                                                last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
+                                                last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
+                                                bs, N, stream));
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+    } else if (fused && cfg->num_layers > 0) {
+        // exact fp32: head of layer 0, then per layer: attention + (tail of layer i fused with head of layer i+1)
+        PDSC_TRY(pdsc_layer_fused(nullptr, nullptr, featA, nullptr, featB, qkv, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0), W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), M,
+                                  stream));
+        float *cur = featB, *nxt = featC;
+        for (int i = 0; i < cfg->num_layers; ++i) {
+            PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            const bool last = i + 1 == cfg->num_layers;
+            PDSC_TRY(pdsc_layer_fused(msg, cur, nullptr, last ? featA : nullptr, last ? nullptr : nxt, last ? nullptr : qkv,
+                                      W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
+                                      W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
+                                      last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
+                                      last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1), M,
+                                      stream));
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
     } else

@@ -479,7 +479,7 @@ extern "C" int pdsc_attention_trace(long long* device_buffer) {   // diagnostics
 extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
                                        float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                        void* stream) {
-    PDSC_REQUIRE(q_split && kv_tiles && compat && msg, "pdsc_sc_attention_split: null pointer");
+    PDSC_REQUIRE(q_split && kv_tiles && compat, "pdsc_sc_attention_split: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_split: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % 4 == 0,
                  "pdsc_sc_attention_split: ld=%lld must be a multiple of 4 and >= N rounded up to 32", ld);
@@ -494,6 +494,7 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     if (force_nw == 4 || force_nw == 8) nw = force_nw;
     if (nsplit <= 0) nsplit = ns;
     if (nsplit > tiles) nsplit = tiles;
+    PDSC_REQUIRE(msg || nsplit > 1, "pdsc_sc_attention_split: msg == NULL needs a key split > 1 (partials stay in scratch)");
     const size_t need = nsplit == 1 ? 0 : (size_t)bs * nsplit * round_up(N, 256) * (PDSC_CHANNELS + 2) * sizeof(float);
     if (need > 0 && (!scratch || scratch_bytes < need)) {
         set_error("pdsc_sc_attention_split: scratch %zu < %zu bytes", scratch_bytes, need);
@@ -529,7 +530,7 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     profile_mark_end(PDSC_PROF_ATTENTION, st);
     int rc = check_launch("pdsc_sc_attention_split");
     if (rc != PDSC_OK) return rc;
-    if (nsplit > 1) {
+    if (nsplit > 1 && msg) {
         AttArgs c{};
         c.msg = msg; c.part_o = a.part_o; c.part_ml = a.part_ml;
         c.N = N; c.Npad = a.Npad; c.nsplit = nsplit; c.num_tiles = tiles;

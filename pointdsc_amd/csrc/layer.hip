@@ -19,7 +19,10 @@ constexpr int LF_LD = PDSC_CHANNELS + 4;     // padded LDS row (floats)
 constexpr int LF_TILE = LF_ROWS * LF_LD;
 
 struct LayerArgs {
-    const float* msg;        // [M][128]  attention output            (tail)
+    const float* msg;        // [M][128]  attention output            (tail), or NULL when the partials below are given
+    const float* part_o;     // [bs][nsplit][Npad][128] un-normalised partial outputs of the attention key splits
+    const float* part_ml;    // [bs][nsplit][Npad][2]   (reference exponent (log2), partial sum)
+    int nsplit, Npad;
     const float* res;        // [M][128]  featB of this layer         (tail residual)
     const float* feat_in;    // [M][128]  used when there is no tail  (first head)
     float* feat_out;         // [M][128]  tail result, written when non-null
@@ -44,6 +47,38 @@ __device__ __forceinline__ void load_x(const float* Xs, int l31, int h, f32x4 (&
     const float* p = Xs + l31 * LF_LD + 4 * h;
 #pragma unroll
     for (int q = 0; q < K / 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+}
+
+// tail input: merged msg rows, or the merge of the attention's key-split partials (attention_combine_kernel's
+// arithmetic, attention.hip) -- saves that kernel's launch and one round trip of msg through HBM
+__device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs, int m0, int M, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+        const int m = min(m0 + row, M - 1);
+        f32x4 v;
+        if (a.msg) {
+            v = *reinterpret_cast<const f32x4*>(a.msg + (size_t)m * PDSC_CHANNELS + c4);
+        } else {
+            const int query = m - b * a.N;
+            float mmax = -INFINITY;
+            for (int sp = 0; sp < a.nsplit; ++sp)
+                mmax = fmaxf(mmax, a.part_ml[(((size_t)b * a.nsplit + sp) * a.Npad + query) * 2]);
+            float L = 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < a.nsplit; ++sp) {
+                const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + query;
+                const float w = __builtin_amdgcn_exp2f(a.part_ml[slot * 2] - mmax);
+                L = fmaf(a.part_ml[slot * 2 + 1], w, L);
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(a.part_o + slot * PDSC_CHANNELS + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[e], w, acc[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[e] / L;
+        }
+        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = v;
+    }
 }
 
 template <int K>
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
         f32x4 w128[16], w64[8];
         // ---- fc1: 128 -> 64 (+BN, ReLU): tiles {0,1} on waves {0,1} ----
         if (wave < 2) load_w<128>(a.w1, 32 * wave, l31, h, w128);
-        global_to_tile(a.msg, Xa, m0, M, t);
+        msg_to_tile(a, blockIdx.y, Xa, m0, M, t);
         __syncthreads();
         if (wave < 2) {
             f32x4 x[16];
@@ -241,21 +276,24 @@ static int launch_layer(const LayerArgs& a, hipStream_t st) {
 
 }  // namespace pdsc
 
-extern "C" int pdsc_layer_fused_split(const float* msg, const float* res, const float* feat_in, float* feat_out,
+extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                                      const float* res, const float* feat_in, float* feat_out,
                                       float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
                                       const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                       const float* b3, const float* wp, const float* bp, const float* wq, const float* bq,
                                       int bs, int N, void* stream) {
-    const bool tail = msg != nullptr, head = featB_out != nullptr;
-    PDSC_REQUIRE(tail || head, "pdsc_layer_fused: neither tail (msg) nor head (featB_out) requested");
+    const bool tail = msg != nullptr || part_o != nullptr, head = featB_out != nullptr;
+    PDSC_REQUIRE(tail || head, "pdsc_layer_fused: neither tail (msg / partials) nor head (featB_out) requested");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused: bs=%d N=%d", bs, N);
-    if (tail) PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused: tail needs res, fc1..fc3");
-    else PDSC_REQUIRE(feat_in, "pdsc_layer_fused: head-only needs feat_in");
+    if (tail) {
+        PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused: tail needs res, fc1..fc3");
+        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && Npad >= N, "pdsc_layer_fused: partials need part_ml, nsplit, Npad");
+    } else PDSC_REQUIRE(feat_in, "pdsc_layer_fused: head-only needs feat_in");
     if (head) PDSC_REQUIRE((qkv_out || q_split) && wp && bp && wq && bq, "pdsc_layer_fused: head needs qkv_out or the split streams, pcn, qkv weights");
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
-    pdsc::LayerArgs a{msg, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3, wp, bp, wq, bq,
-                      (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs};
+    pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
+                      wp, bp, wq, bq, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs};
     hipStream_t st = (hipStream_t)stream;
     if (tail && head) return pdsc::launch_layer<true, true>(a, st);
     if (tail) return pdsc::launch_layer<true, false>(a, st);
@@ -267,6 +305,6 @@ extern "C" int pdsc_layer_fused(const float* msg, const float* res, const float*
                                 const float* b2, const float* w3, const float* b3, const float* wp, const float* bp,
                                 const float* wq, const float* bq, int M, void* stream) {
     if (featB_out) PDSC_REQUIRE(qkv_out, "pdsc_layer_fused: head needs qkv_out");
-    return pdsc_layer_fused_split(msg, res, feat_in, feat_out, featB_out, qkv_out, nullptr, nullptr, w1, b1, w2, b2, w3, b3,
-                                  wp, bp, wq, bq, 1, M, stream);
+    return pdsc_layer_fused_split(msg, nullptr, nullptr, 0, 0, res, feat_in, feat_out, featB_out, qkv_out, nullptr, nullptr,
+                                  w1, b1, w2, b2, w3, b3, wp, bp, wq, bq, 1, M, stream);
 }

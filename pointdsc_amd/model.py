@@ -28,7 +28,7 @@ from . import _lib
 
 _NUM_CHANNELS = 128
 # enum pdsc_attention_precision (include/pointdsc_hip.h)
-ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1}
+ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1, "bf16x3_all": 2}
 
 
 def _conv(cin: int, cout: int) -> nn.Conv1d:
@@ -99,9 +99,11 @@ class PointDSC(nn.Module):
                 nn.init.constant_(m.bias, 0)
         # Not a reference constructor argument (the signature stays the reference's): arithmetic of the two
         # attention contractions.  "bf16x3" = split-precision bf16 MFMA (default; features within 5e-6 of fp32),
-        # "fp32" = exact fp32 MFMA.  Set the attribute (or POINTDSC_ATTENTION_PRECISION) before calling forward.
+        # "fp32" = exact fp32 MFMA, "bf16x3_all" = the point-wise GEMMs in split precision too (features within 2e-5).
+        # Set the attribute (or POINTDSC_ATTENTION_PRECISION) before calling forward.
         self.attention_precision = os.environ.get("POINTDSC_ATTENTION_PRECISION", "bf16x3")
         self._wpack: Optional[torch.Tensor] = None
+        self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
 
@@ -120,6 +122,7 @@ class PointDSC(nn.Module):
     # invalidate_packed_weights() yourself.
     def invalidate_packed_weights(self) -> None:
         self._wpack = None
+        self._wsplit = None
         self._wpack_key = None
 
     def _apply(self, fn, *args, **kwargs):
@@ -183,8 +186,23 @@ class PointDSC(nn.Module):
             put(sec + "_W", 0, w); put(sec + "_B", 0, b)
         put("SIGMA", 0, self.sigma.detach())
         put("SIGMA_SPAT", 0, self.sigma_spat.detach())
-        self._wpack, self._wpack_key = pack, key
+        self._wpack, self._wsplit, self._wpack_key = pack, None, key
         return pack
+
+    def split_weights(self, device=None) -> torch.Tensor:
+        """bf16 hi/lo split of the per-layer matrices for the split-precision GEMMs (pdsc_wsplit_build): built on the
+        GPU from the packed buffer, once per packing."""
+        pack = self.packed_weights(device)
+        if self._wsplit is None:
+            lib = _lib.load()
+            cfg = self._config()
+            nb = int(lib.pdsc_wsplit_bytes(C.byref(cfg)))
+            wsplit = torch.empty(max(nb, 16), dtype=torch.uint8, device=pack.device)
+            with torch.cuda.device(pack.device):
+                _lib.check(lib.pdsc_wsplit_build(C.byref(cfg), C.c_void_p(pack.data_ptr()), C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None,
+                                                 torch.cuda.current_stream().cuda_stream), "pdsc_wsplit_build")
+            self._wsplit = wsplit
+        return self._wsplit
 
     def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
         ws = self._workspace
@@ -219,13 +237,15 @@ class PointDSC(nn.Module):
         cfg = self._config()
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
+            wsplit = self.split_weights(dev) if self.attention_precision == "bf16x3_all" else None
             nbytes = int(lib.pdsc_workspace_bytes(C.byref(cfg), bs, n, num_seeds))
             if nbytes == 0:
                 raise RuntimeError(f"unsupported problem size bs={bs} N={n} seeds={num_seeds}: " + _lib.last_error())
             ws = self._get_workspace(nbytes, dev)
             final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
             final_labels = torch.empty(bs, n, device=dev, dtype=torch.float32)
-            rc = lib.pdsc_forward_testing(C.byref(cfg), C.c_void_p(wpack.data_ptr()), C.c_void_p(corr_pos.data_ptr()),
+            rc = lib.pdsc_forward_testing(C.byref(cfg), C.c_void_p(wpack.data_ptr()), C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None,
+                                          C.c_void_p(corr_pos.data_ptr()),
                                           C.c_void_p(src_keypts.data_ptr()), C.c_void_p(tgt_keypts.data_ptr()),
                                           bs, n, num_seeds, C.c_void_p(final_trans.data_ptr()),
                                           C.c_void_p(final_labels.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,

@@ -116,37 +116,101 @@ def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
 
 
 def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: torch.Tensor, bs: int, n: int,
-                       nsplit: int = 0) -> torch.Tensor:
-    """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128]."""
+                       nsplit: int = 0, merge: bool = True):
+    """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128].
+    merge=False (needs a key split > 1): returns (scratch, nsplit) with the un-merged partials for layer_fused_x3."""
     lib = _lib.load()
     compat = _chk(compat, "compat")
     qs, kv = _chk(q_split, "q_split", torch.uint8), _chk(kv_tiles, "kv_tiles", torch.uint8)
-    msg = torch.empty(bs * n, 128, device=compat.device, dtype=torch.float32)
+    if nsplit <= 0:
+        nsplit = int(lib.pdsc_attention_split_default_split(bs, n))
+    msg = torch.empty(bs * n, 128, device=compat.device, dtype=torch.float32) if merge else None
     nb = int(lib.pdsc_attention_split_scratch_bytes(bs, n, nsplit))
     scratch = torch.empty(max(nb, 16), device=compat.device, dtype=torch.uint8)
     _lib.check(lib.pdsc_sc_attention_split(_p(qs), _p(kv), _p(compat), compat.shape[-1], _p(msg), _p(scratch), nb, bs, n,
                                            nsplit, _stream()), "pdsc_sc_attention_split")
-    return msg
+    return msg if merge else (scratch, nsplit)
 
 
-def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False):
+def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False, partials=None):
     """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
+    partials = (scratch, nsplit) from sc_attention_split(..., merge=False) replaces msg.
     Returns (feat or None, featB, qkv or None, q_split, kv_tiles)."""
     lib = _lib.load()
-    src = msg if msg is not None else feat_in
+    src = res if res is not None else feat_in
     m, dev = src.shape[0], src.device
     assert m == bs * n
     tail = [_chk(w, "tail_w") for w in tail_w] if tail_w is not None else [None] * 6
     head = [_chk(w, "head_w") for w in head_w]
-    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if msg is not None else None
+    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if tail_w is not None else None
     featB = torch.empty(m, 128, device=dev, dtype=torch.float32)
     qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if want_qkv else None
     qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8)
     kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8)
-    args = [_p(_chk(msg, "msg")) if msg is not None else None, _p(_chk(res, "res")) if res is not None else None,
+    part_o = part_ml = None
+    nsplit = npad = 0
+    if partials is not None:
+        scratch, nsplit = partials
+        npad = (n + 255) // 256 * 256
+        part_o = C.c_void_p(scratch.data_ptr())
+        part_ml = C.c_void_p(scratch.data_ptr() + bs * nsplit * npad * 128 * 4)
+    args = [_p(_chk(msg, "msg")) if msg is not None else None, part_o, part_ml, nsplit, npad,
+            _p(_chk(res, "res")) if res is not None else None,
             _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB), _p(qkv), _p(qs), _p(kv)]
     args += [_p(w) for w in tail] + [_p(w) for w in head]
     _lib.check(lib.pdsc_layer_fused_split(*args, bs, n, _stream()), "pdsc_layer_fused_split")
+    return feat, featB, qkv, qs, kv
+
+
+def split_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 matrix [out,in] -> uint8 tensor holding bf16 hi [out,in] then bf16 lo [out,in] (layout of pdsc_wsplit_build)."""
+    w = _chk(w, "weight")
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi.reshape(-1), lo.reshape(-1)]).view(torch.uint8)
+
+
+def layer_fused_x3(msg, res, feat_in, tail_w, head_w, bs: int, n: int, partials=None, want_qkv: bool = False,
+                   want_feat: bool = False):
+    """pdsc_layer_fused_x3 (split-precision chain).  tail_w/head_w as in layer_fused (fp32 matrices; split here).
+    partials = (scratch uint8 tensor, nsplit) left by sc_attention_split(..., merge=False) replaces msg.
+    Returns (feat or None, featB or None, qkv or None, q_split or None, kv_tiles or None)."""
+    lib = _lib.load()
+    src = res if res is not None else feat_in
+    m, dev = src.shape[0], src.device
+    assert m == bs * n
+    tail = list(tail_w) if tail_w is not None else [None] * 6
+    head = list(head_w) if head_w is not None else [None] * 4
+    keep = []
+
+    def mat(w):
+        if w is None:
+            return None
+        keep.append(split_weight(w))
+        return _p(keep[-1])
+
+    def vec(b):
+        return None if b is None else _p(_chk(b, "bias"))
+
+    has_tail, has_head = tail_w is not None, head_w is not None
+    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if (has_tail and (want_feat or not has_head)) else None
+    featB = torch.empty(m, 128, device=dev, dtype=torch.float32) if has_head else None
+    qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if (has_head and want_qkv) else None
+    qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    part_o = part_ml = None
+    nsplit = npad = 0
+    if partials is not None:
+        scratch, nsplit = partials
+        npad = (n + 255) // 256 * 256
+        part_o = C.c_void_p(scratch.data_ptr())
+        part_ml = C.c_void_p(scratch.data_ptr() + bs * nsplit * npad * 128 * 4)
+    args = [_p(_chk(msg, "msg")) if msg is not None else None, part_o, part_ml, nsplit, npad,
+            _p(_chk(res, "res")) if res is not None else None, _p(_chk(feat_in, "feat_in")) if feat_in is not None else None,
+            _p(feat), _p(featB), _p(qkv), _p(qs), _p(kv),
+            mat(tail[0]), vec(tail[1]), mat(tail[2]), vec(tail[3]), mat(tail[4]), vec(tail[5]),
+            mat(head[0]), vec(head[1]), mat(head[2]), vec(head[3])]
+    _lib.check(lib.pdsc_layer_fused_x3(*args, bs, n, _stream()), "pdsc_layer_fused_x3")
     return feat, featB, qkv, qs, kv
 
 
