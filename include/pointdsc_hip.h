@@ -56,7 +56,8 @@ typedef struct pdsc_config {
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
  *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
  *           ~2^-16 relative error per product; 12-layer features within 5e-6, R/t within 1e-5 of the fp32 path.
- *           The point-wise GEMMs between the attention calls stay exact fp32.                          [default]
+ *           Also used for the q|k|v projection (its results only feed the attention); every GEMM whose result
+ *           lands on the residual stream (PointCN, fc_message) stays exact fp32.                       [default]
  *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time.
  *   BF16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): ~10 us less per layer, but their error lands on the
  *           residual stream un-averaged: 12-layer features within 2e-5 of the fp32 path (opt-in). */
@@ -149,13 +150,17 @@ int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, f
  * Rows are bs pairs of N points (a 32-point tile never straddles two pairs).
  * The tail input is either `msg` (merged rows) or the un-merged key-split partials (`part_o`, `part_ml`, nsplit, Npad)
  * exactly as pdsc_sc_attention_split leaves them in its scratch when called with msg == NULL: the merge then happens
- * while the tile is loaded (no combine launch, no round trip of msg through HBM). */
+ * while the tile is loaded (no combine launch, no round trip of msg through HBM).
+ * wq_split (optional): the q|k|v weights as bf16 hi [3C][C] | lo [3C][C] (section PDSC_W_QKV_W of the split-weight
+ * buffer, pdsc_wsplit_build below) -> that one GEMM runs in split precision; q, k, v only feed the attention, whose
+ * own operand split has an error of the same order, and never touch the residual stream. */
 int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
                            const float* res, const float* feat_in, float* feat_out,
                            float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
                            const float* w1, const float* b1, const float* w2, const float* b2,
                            const float* w3, const float* b3, const float* wp, const float* bp,
-                           const float* wq, const float* bq, int bs, int N, void* stream);
+                           const float* wq, const float* bq, const void* wq_split /* optional */, int bs, int N,
+                           void* stream);
 
 /* Split-precision variant of the whole chain (PDSC_ATT_BF16X3_ALL: every GEMM as three bf16 MFMAs per operand pair);
  * same tail-input convention.  Weights come from the split-weight buffer:
@@ -270,7 +275,7 @@ int pdsc_post_refinement(const float* initial_trans, const float* src_keypts, co
  * replaces PointDSC.forward(data) with 'testing' in data (models/PointDSC.py:128-197).
  * corr_pos [bs][N][in_dim], src/tgt [bs][N][3]  ->  final_trans [bs][16], final_labels [bs][N] (0/1).
  * num_seeds = int(N * ratio) computed by the caller in double precision like the reference (:174). */
-int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void* wsplit /* needed for PDSC_ATT_BF16X3_ALL only, else may be NULL */,
+int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void* wsplit /* NULL iff PDSC_ATT_FP32 */,
                          const float* corr_pos, const float* src_keypts, const float* tgt_keypts,
                          int bs, int N, int num_seeds,
                          float* final_trans, float* final_labels,

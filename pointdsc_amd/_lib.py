@@ -52,7 +52,7 @@ SIGNATURES = {
     "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pdsc_layer_fused": (_i, [_vp] * 16 + [_i, _vp]),
-    "pdsc_layer_fused_split": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 17 + [_i, _i, _vp]),
+    "pdsc_layer_fused_split": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 18 + [_i, _i, _vp]),
     "pdsc_wsplit_bytes": (_sz, [_cfgp]),
     "pdsc_wsplit_offset": (_ll, [_cfgp, _i, _i]),
     "pdsc_wsplit_build": (_i, [_cfgp, _vp, _vp, _vp]),

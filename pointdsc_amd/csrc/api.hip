@@ -269,7 +269,7 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     void* att_scratch = ws + L.find("att_scratch");
     const bool split = cfg->attention_precision != PDSC_ATT_FP32;
     const bool x3_gemm = cfg->attention_precision == PDSC_ATT_BF16X3_ALL;
-    PDSC_REQUIRE(!x3_gemm || wsplit, "pdsc_forward_testing: PDSC_ATT_BF16X3_ALL needs the split-weight buffer (pdsc_wsplit_build)");
+    PDSC_REQUIRE(!split || wsplit, "pdsc_forward_testing: the split-precision modes need the split-weight buffer (pdsc_wsplit_build)");
     auto WS = [&](int section, int layer) { return (const void*)((const unsigned short*)wsplit + pdsc_wsplit_offset(cfg, section, layer)); };
     const size_t att_bytes = split ? pdsc_attention_split_scratch_bytes(bs, N, 0) : pdsc_attention_scratch_bytes(bs, N, 0);
     void* q_split = split ? ws + L.find("q_split") : nullptr;
@@ -288,8 +288,14 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
         // + ONE launch for the merge, the tail of layer i and the head of layer i+1
         const int ns = pdsc_attention_split_default_split(bs, N);
         const int Npad = (int)round_up(N, 256);
-        const float* part_o = ns > 1 ? (const float*)att_scratch : nullptr;
-        const float* part_ml = ns > 1 ? part_o + (size_t)bs * ns * Npad * C : nullptr;
+        static int fuse_env = -1;
+        if (fuse_env < 0) {
+            const char* env = getenv("PDSC_FUSE_MERGE");         // tuning/A-B knob
+            fuse_env = env ? atoi(env) : 1;
+        }
+        const bool fuse_merge = fuse_env && ns > 1 && ns <= 4;   // the layer kernels merge up to 4 splits while loading (merge_partials.h)
+        const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;
+        const float* part_ml = fuse_merge ? part_o + (size_t)bs * ns * Npad * C : nullptr;
         if (x3_gemm)
             PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
@@ -297,14 +303,14 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
         else
             PDSC_TRY(pdsc_layer_fused_split(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
-                                            W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
+                                            W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), WS(PDSC_W_QKV_W, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, ns > 1 ? nullptr : msg, att_scratch, att_bytes, bs, N,
+            PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, fuse_merge ? nullptr : msg, att_scratch, att_bytes, bs, N,
                                              ns, stream));
             const bool last = i + 1 == cfg->num_layers;
             if (x3_gemm)
-                PDSC_TRY(pdsc_layer_fused_x3(ns > 1 ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
+                PDSC_TRY(pdsc_layer_fused_x3(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
                                              last ? nullptr : nxt, nullptr, last ? nullptr : q_split, last ? nullptr : kv_tiles,
                                              WS(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), WS(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
                                              WS(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
@@ -312,14 +318,14 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
                                              last ? nullptr : WS(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
                                              bs, N, stream));
             else
-                PDSC_TRY(pdsc_layer_fused_split(ns > 1 ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
+                PDSC_TRY(pdsc_layer_fused_split(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
                                                 last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,
                                                 last ? nullptr : kv_tiles,
                                                 W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
                                                 W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i),
                                                 last ? nullptr : W(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
                                                 last ? nullptr : W(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
-                                                bs, N, stream));
+                                                last ? nullptr : WS(PDSC_W_QKV_W, i + 1), bs, N, stream));
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
     } else if (fused && cfg->num_layers > 0) {

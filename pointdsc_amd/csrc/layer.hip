@@ -11,6 +11,7 @@
 // Bound: MFMA (172 kFLOP per point per layer on v_mfma_f32_32x32x2_f32); weights stream from L2 (336 KB per tile).
 #include "pdsc_common.h"
 #include "split_layout.h"
+#include "merge_partials.h"
 
 namespace pdsc {
 
@@ -30,6 +31,9 @@ struct LayerArgs {
     float* qkv_out;          // [M][384]  head
     const float *w1, *b1, *w2, *b2, *w3, *b3;      // fc1 [64][128], fc2 [64][64], fc3 [128][64]
     const float *wp, *bp, *wq, *bq;                // pcn [128][128], qkv [384][128]
+    const __bf16* wq_split;  // optional: qkv weights as bf16 hi [384][128] | lo [384][128] -> the q|k|v projection runs in
+                             // split precision (three bf16 MFMAs per operand pair); its error is of the order the attention's
+                             // operand split already has, and q, k, v never touch the residual stream
     __bf16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
     unsigned char* kv;       // head, optional: K/V tile stream  [bs][tiles][32 KiB]  (split_layout.h)
     int N, bs;               // rows are bs pairs of N points; a workgroup's 32-point tile never straddles two pairs
@@ -47,38 +51,6 @@ __device__ __forceinline__ void load_x(const float* Xs, int l31, int h, f32x4 (&
     const float* p = Xs + l31 * LF_LD + 4 * h;
 #pragma unroll
     for (int q = 0; q < K / 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
-}
-
-// tail input: merged msg rows, or the merge of the attention's key-split partials (attention_combine_kernel's
-// arithmetic, attention.hip) -- saves that kernel's launch and one round trip of msg through HBM
-__device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs, int m0, int M, int t) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
-        const int m = min(m0 + row, M - 1);
-        f32x4 v;
-        if (a.msg) {
-            v = *reinterpret_cast<const f32x4*>(a.msg + (size_t)m * PDSC_CHANNELS + c4);
-        } else {
-            const int query = m - b * a.N;
-            float mmax = -INFINITY;
-            for (int sp = 0; sp < a.nsplit; ++sp)
-                mmax = fmaxf(mmax, a.part_ml[(((size_t)b * a.nsplit + sp) * a.Npad + query) * 2]);
-            float L = 0.f;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-                const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + query;
-                const float w = __builtin_amdgcn_exp2f(a.part_ml[slot * 2] - mmax);
-                L = fmaf(a.part_ml[slot * 2 + 1], w, L);
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(a.part_o + slot * PDSC_CHANNELS + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[e], w, acc[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[e] / L;
-        }
-        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = v;
-    }
 }
 
 template <int K>
@@ -185,10 +157,28 @@ __device__ __forceinline__ void tile_to_split(const float* Xs, __bf16* __restric
     }
 }
 
-template <bool HAS_TAIL, bool HAS_HEAD>
+// tail input: merged msg rows, or the merge of the attention's key-split partials (merge_partials.h)
+__device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs, int m0, int M, int t) {
+    if (a.msg) {
+        global_to_tile(a.msg, Xs, m0, M, t);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+        const int m = min(m0 + row, M - 1);
+        const size_t slot0 = (size_t)b * a.nsplit * a.Npad + (size_t)(m - b * a.N);
+        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_chunk(a.part_o, a.part_ml, slot0, (size_t)a.Npad, a.nsplit, c4);
+    }
+}
+
+constexpr int LF_XLD16 = PDSC_CHANNELS + 8;          // bf16 elements per row of a hi / lo activation tile (272 B)
+constexpr int LF_XB_FLOATS = LF_ROWS * LF_XLD16;     // Xb doubles as the bf16 hi|lo image of featB: 2 * 32 * 136 * 2 B
+
+template <bool HAS_TAIL, bool HAS_HEAD, bool QKV_X3>
 __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) float Xa[LF_TILE];
-    __shared__ __attribute__((aligned(16))) float Xb[LF_TILE];
+    __shared__ __attribute__((aligned(16))) float Xb[LF_XB_FLOATS > LF_TILE ? LF_XB_FLOATS : LF_TILE];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -234,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
         __syncthreads();
     }
 
-    if (HAS_HEAD) {
+    if (HAS_HEAD && !QKV_X3) {
         // ---- PointCN: 128 -> 128 (+BN, ReLU): tile = wave; input Xb, output Xa ----
         f32x4 w[16], x[16];
         load_w<128>(a.wp, 32 * wave, l31, h, w);
@@ -266,11 +256,89 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
             if (c < 2) __syncthreads();
         }
     }
+    if (HAS_HEAD && QKV_X3) {
+        // ---- PointCN exactly as above (exact fp32: featB is the next residual) ... ----
+        __bf16* Xh = reinterpret_cast<__bf16*>(Xb);
+        __bf16* Xl = Xh + LF_ROWS * LF_XLD16;
+        bf16x8 wh[8], wl[8];
+        {
+            f32x4 w[16], x[16];
+            load_w<128>(a.wp, 32 * wave, l31, h, w);
+            load_x<128>(Xb, l31, h, x);
+            const f32x16 acc = mma_tile<128>(w, x);
+            // prefetch the first split qkv tile: lane (row l31, half h), step kk holds k = 16kk+8h..+7
+            {
+                const __bf16* p = a.wq_split + (size_t)(32 * wave + l31) * PDSC_CHANNELS + 8 * h;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    wh[kk] = *reinterpret_cast<const bf16x8*>(p + 16 * kk);
+                    wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
+                }
+            }
+            __syncthreads();                                          // every wave holds its copy of Xb: Xb may be rewritten
+            // ... stored twice: fp32 -> Xa (featB_out), bf16 hi|lo -> Xb (operand of the split-precision q|k|v GEMM)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 32 * wave + 8 * g + 4 * h;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bp + col);
+                f32x4 v;
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[4 * g + e] + bv[e], 0.f);
+                    __bf16 xh, xl; split_bf16(v[e], xh, xl); hi[e] = xh; lo[e] = xl;
+                }
+                *reinterpret_cast<f32x4*>(Xa + l31 * LF_LD + col) = v;
+                *reinterpret_cast<bf16x4*>(Xh + l31 * LF_XLD16 + col) = hi;
+                *reinterpret_cast<bf16x4*>(Xl + l31 * LF_XLD16 + col) = lo;
+            }
+        }
+        __syncthreads();
+        tile_to_global(Xa, a.featB_out, PDSC_CHANNELS, m0, M, t);
+        // ---- q|k|v: 128 -> 384, three 128-column chunks, hi*hi + hi*lo + lo*hi on the bf16 matrix cores, staged via Xa ----
+        unsigned char* img = a.kv ? a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_BYTES : nullptr;
+        const int valid = min(LF_ROWS, M - m0);
+        const int xo = l31 * LF_XLD16 + 8 * h;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int n0 = 128 * c + 32 * wave;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc = zero;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(Xh + xo + 16 * kk);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(Xl + xo + 16 * kk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kk], xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kk], xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kk], xh, acc, 0, 0, 0);
+            }
+            if (c < 2) {                                              // prefetch next chunk's tile
+                const __bf16* p = a.wq_split + (size_t)(n0 + 128 + l31) * PDSC_CHANNELS + 8 * h;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    wh[kk] = *reinterpret_cast<const bf16x8*>(p + 16 * kk);
+                    wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
+                }
+            }
+            __syncthreads();                                          // previous readers of Xa are done
+            store_tile<false, false>(acc, a.bq, n0, Xa, 32 * wave, l31, h, nullptr);
+            __syncthreads();
+            if (a.qkv_out) tile_to_global(Xa, a.qkv_out + 128 * c, 3 * PDSC_CHANNELS, m0, M, t);
+            if (a.qs) {
+                if (c == 0) tile_to_split<0>(Xa, a.qs + (size_t)m0 * SPL_Q_LD, img, valid, t);
+                else if (c == 1) tile_to_split<1>(Xa, nullptr, img, valid, t);
+                else { tile_to_split<2>(Xa, nullptr, img, valid, t); spl_zero_pads(img, t); }
+            }
+        }
+    }
 }
 
 template <bool T, bool H>
 static int launch_layer(const LayerArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((layer_fused_kernel<T, H>), dim3(ceil_div(a.N, LF_ROWS), a.bs), dim3(256), 0, st, a);
+    if (H && a.wq_split)
+        hipLaunchKernelGGL((layer_fused_kernel<T, H, H>), dim3(ceil_div(a.N, LF_ROWS), a.bs), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((layer_fused_kernel<T, H, false>), dim3(ceil_div(a.N, LF_ROWS), a.bs), dim3(256), 0, st, a);
     return check_launch("pdsc_layer_fused");
 }
 
@@ -281,19 +349,20 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
                                       float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
                                       const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                       const float* b3, const float* wp, const float* bp, const float* wq, const float* bq,
-                                      int bs, int N, void* stream) {
+                                      const void* wq_split, int bs, int N, void* stream) {
     const bool tail = msg != nullptr || part_o != nullptr, head = featB_out != nullptr;
     PDSC_REQUIRE(tail || head, "pdsc_layer_fused: neither tail (msg / partials) nor head (featB_out) requested");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused: bs=%d N=%d", bs, N);
     if (tail) {
         PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused: tail needs res, fc1..fc3");
-        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && Npad >= N, "pdsc_layer_fused: partials need part_ml, nsplit, Npad");
+        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= pdsc::MERGE_MAX_SPLIT && Npad >= N,
+                               "pdsc_layer_fused: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", pdsc::MERGE_MAX_SPLIT);
     } else PDSC_REQUIRE(feat_in, "pdsc_layer_fused: head-only needs feat_in");
     if (head) PDSC_REQUIRE((qkv_out || q_split) && wp && bp && wq && bq, "pdsc_layer_fused: head needs qkv_out or the split streams, pcn, qkv weights");
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
-                      wp, bp, wq, bq, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs};
+                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs};
     hipStream_t st = (hipStream_t)stream;
     if (tail && head) return pdsc::launch_layer<true, true>(a, st);
     if (tail) return pdsc::launch_layer<true, false>(a, st);
@@ -306,5 +375,5 @@ extern "C" int pdsc_layer_fused(const float* msg, const float* res, const float*
                                 const float* wq, const float* bq, int M, void* stream) {
     if (featB_out) PDSC_REQUIRE(qkv_out, "pdsc_layer_fused: head needs qkv_out");
     return pdsc_layer_fused_split(msg, nullptr, nullptr, 0, 0, res, feat_in, feat_out, featB_out, qkv_out, nullptr, nullptr,
-                                  w1, b1, w2, b2, w3, b3, wp, bp, wq, bq, 1, M, stream);
+                                  w1, b1, w2, b2, w3, b3, wp, bp, wq, bq, nullptr, 1, M, stream);
 }

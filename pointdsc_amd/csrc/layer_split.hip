@@ -15,6 +15,7 @@
 // Bound: L2 weight stream (344 KB per workgroup) and launch latency; MFMA time is ~5 us per launch at M = 20 000.
 #include "pdsc_common.h"
 #include "split_layout.h"
+#include "merge_partials.h"
 
 namespace pdsc {
 
@@ -123,23 +124,8 @@ __device__ __forceinline__ void rows_to_x(const LayerX3Args& a, const float* __r
         if (!merge) {
             v = *reinterpret_cast<const f32x4*>(src + (size_t)m * PDSC_CHANNELS + c4);
         } else {
-            // same arithmetic as attention_combine_kernel (attention.hip)
-            const int query = m - b * a.N;
-            float mmax = -INFINITY;
-            for (int sp = 0; sp < a.nsplit; ++sp)
-                mmax = fmaxf(mmax, a.part_ml[(((size_t)b * a.nsplit + sp) * a.Npad + query) * 2]);
-            float L = 0.f;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-                const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + query;
-                const float w = __builtin_amdgcn_exp2f(a.part_ml[slot * 2] - mmax);
-                L = fmaf(a.part_ml[slot * 2 + 1], w, L);
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(a.part_o + slot * PDSC_CHANNELS + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[e], w, acc[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[e] / L;
+            const size_t slot0 = (size_t)b * a.nsplit * a.Npad + (size_t)(m - b * a.N);
+            v = merge_partials_chunk(a.part_o, a.part_ml, slot0, (size_t)a.Npad, a.nsplit, c4);
         }
         bf16x4 hi, lo;
 #pragma unroll
@@ -355,7 +341,8 @@ extern "C" int pdsc_layer_fused_x3(const float* msg, const float* part_o, const 
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused_x3: bs=%d N=%d", bs, N);
     if (tail) {
         PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused_x3: tail needs res, fc1..fc3");
-        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && Npad >= N, "pdsc_layer_fused_x3: partials need part_ml, nsplit, Npad");
+        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= MERGE_MAX_SPLIT && Npad >= N,
+                               "pdsc_layer_fused_x3: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", MERGE_MAX_SPLIT);
         PDSC_REQUIRE(head || feat_out, "pdsc_layer_fused_x3: tail-only needs feat_out");
     } else {
         PDSC_REQUIRE(feat_in, "pdsc_layer_fused_x3: head-only needs feat_in");

@@ -6,6 +6,7 @@
 // one wavefront per row, lanes stride the columns (coalesced), wave shuffles/ballots do the reductions.
 // Ordering rules (ties): equal NMS keys -> ascending index; equal kNN distances -> ascending index
 // (DESIGN.md "tie semantics"; torch.argsort / torch.topk leave both unspecified).
+#include <math.h>
 #include "pdsc_common.h"
 
 namespace pdsc {
@@ -33,8 +34,11 @@ __global__ __launch_bounds__(256) void normalize_conf_kernel(const float* __rest
 }
 
 // ---- NMS keys: key[i] = conf[i] * all_j( conf[i] >= conf[j] || dist(i,j) >= R ) ---------------------
+// `radius2` = the smallest fp32 x with sqrt_rn(x) >= radius (computed on the host): since the correctly rounded square
+// root is monotone, `sqrt(x) >= radius` and `x >= radius2` are the same predicate bit for bit -- without the ~20
+// instructions of an IEEE sqrt per pair.
 __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ src, const float* __restrict__ conf,
-                                                       float radius, float* __restrict__ keys, int N) {
+                                                       float radius2, float* __restrict__ keys, int N) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -44,11 +48,14 @@ __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__
     const float ci = c[i];
     const float xi = s[i * 3], yi = s[i * 3 + 1], zi = s[i * 3 + 2];
     bool ok = true;
-    for (int j0 = 0; j0 < N; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < N) {
-            const float d = norm3(xi - s[j * 3], yi - s[j * 3 + 1], zi - s[j * 3 + 2]);
-            ok = ok && ((ci >= c[j]) || (d >= radius));
+    for (int j0 = 0; j0 < N; j0 += 256) {               // 4 independent chunks per early-exit test
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u + lane;
+            const int jc = min(j, N - 1);
+            const float dx = xi - s[jc * 3], dy = yi - s[jc * 3 + 1], dz = zi - s[jc * 3 + 2];
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));            // norm3's radicand, same rounding
+            ok = ok && ((j >= N) || (ci >= c[jc]) || (d2 >= radius2));
         }
         if (__any(!ok)) break;
     }
@@ -77,7 +84,9 @@ __global__ __launch_bounds__(256) void rank_select_kernel(const float* __restric
     if (lane == 0 && cnt < num_seeds) seeds[(size_t)b * num_seeds + cnt] = i;
 }
 
-// ---- kNN selection: one workgroup per seed row, radix descent on (monotone(dist) << IDX_BITS | index) ---
+// ---- kNN selection: one workgroup per seed row, radix select (8-bit digits, most significant first) of the
+//      (k+1)-th smallest composite value (monotone(dist) << IDX_BITS | index): ties in distance resolve by ascending
+//      index through the same comparison, as the oracle's stable sort does ------------------------------------------
 __device__ __forceinline__ unsigned int float_order_bits(float f) {
     const unsigned int u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending float order == ascending unsigned order
@@ -90,40 +99,46 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __
                                                                  int idx_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds_u[];
     unsigned int* keys = lds_u;                     // [N] monotone distance bits
-    __shared__ int wave_cnt[KNN_THREADS / 64];
+    __shared__ int hist[256];
+    __shared__ int wave_tot[KNN_THREADS / 64];
+    __shared__ int sel_digit, sel_remaining;
     __shared__ unsigned long long cand[PDSC_MAX_K + 1];
     __shared__ int cand_n;
-    const int s = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int s = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* row = dist + ((size_t)b * S + s) * ldd;
     for (int j = t; j < N; j += KNN_THREADS) keys[j] = float_order_bits(row[j]);
     if (t == 0) cand_n = 0;
-    __syncthreads();
 
-    // find the (k+1)-th smallest composite value, most significant bit first
     const int want = k + 1;
     int remaining = want;
-    unsigned long long prefix = 0;
-    const int total_bits = 32 + idx_bits;
-    for (int bit = total_bits - 1; bit >= 0; --bit) {
-        const unsigned long long hi_mask = ~((2ULL << bit) - 1ULL);          // bits above `bit`
-        int c = 0;
+    unsigned long long prefix = 0;                  // digits fixed so far (the bits above `shift + 8`)
+    const int top = (32 + idx_bits + 7) / 8 * 8;    // composite width rounded up to whole digits
+    for (int shift = top - 8; shift >= 0; shift -= 8) {
+        hist[t] = 0;                                // KNN_THREADS == 256 bins
+        __syncthreads();                            // (also orders the key writes / the previous pass's reads)
         for (int j = t; j < N; j += KNN_THREADS) {
             const unsigned long long v = ((unsigned long long)keys[j] << idx_bits) | (unsigned)j;
-            c += ((v & hi_mask) == prefix) && (((v >> bit) & 1ULL) == 0ULL);
+            if ((v >> (shift + 8)) == prefix) atomicAdd(&hist[(int)(v >> shift) & 255], 1);
         }
-        c = wave_sum(c);
         __syncthreads();
-        if ((t & 63) == 0) wave_cnt[t >> 6] = c;
-        __syncthreads();
-        int tot = 0;
+        // inclusive scan of the 256 bins: wave scan + wave totals
+        const int h = hist[t];
+        int incl = h;
 #pragma unroll
-        for (int w = 0; w < KNN_THREADS / 64; ++w) tot += wave_cnt[w];
-        if (tot >= remaining) {
-            // target has a 0 here: keep prefix
-        } else {
-            remaining -= tot;
-            prefix |= (1ULL << bit);
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
         }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) incl += wave_tot[w];
+        if (incl >= remaining && incl - h < remaining) {   // exactly one bin: the digit of the target
+            sel_digit = t;
+            sel_remaining = remaining - (incl - h);
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (unsigned long long)sel_digit;
+        remaining = sel_remaining;
     }
     // prefix == the (k+1)-th smallest composite; collect everything <= prefix (exactly k+1 values)
     for (int j = t; j < N; j += KNN_THREADS) {
@@ -157,8 +172,17 @@ extern "C" int pdsc_normalize_confidence(const float* feat, const float* h2, con
 extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, float* keys, int bs, int N, void* stream) {
     PDSC_REQUIRE(src && conf && keys, "pdsc_nms_keys: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_nms_keys: bs=%d N=%d", bs, N);
+    // smallest x with sqrtf(x) >= radius (host sqrtf is correctly rounded, like the device's)
+    float radius2 = 0.f;
+    if (radius > 0.f) {
+        radius2 = radius * radius;
+        while (radius2 > 0.f && sqrtf(nextafterf(radius2, 0.f)) >= radius) radius2 = nextafterf(radius2, 0.f);
+        while (sqrtf(radius2) < radius) radius2 = nextafterf(radius2, INFINITY);
+    } else if (radius != radius) {
+        radius2 = radius;                                                    // NaN radius: every comparison is false
+    }
     hipLaunchKernelGGL(pdsc::nms_keys_kernel, dim3(pdsc::ceil_div(N, 4), bs), dim3(256), 0, (hipStream_t)stream, src, conf,
-                       radius, keys, N);
+                       radius2, keys, N);
     return pdsc::check_launch("pdsc_nms_keys");
 }
 

@@ -3,7 +3,8 @@
 //   reference: models/PointDSC.py:257-282 (matrices + weight normalisation), :347-358 (power iteration),
 //              models/common.py:7-45 (rigid_transform_3d; torch.svd is done on the HOST there),
 //              utils/SE3.py:73-96 (integrate_trans).
-// One wavefront per seed: lane i owns neighbour i (k <= 64).  Nothing here is bandwidth- or MFMA-bound
+// One workgroup per seed, lane i of every wave owns neighbour i (k <= 64); the k x k matrix build (k^2 x 128 MACs, the
+// only sizeable part) is split column-wise over the 4 waves.  Nothing here is bandwidth- or MFMA-bound
 // (S * ~0.5 MFLOP); the point is zero host round trips (the reference pays one D2H+H2D per SVD batch and
 // one sync per power iteration) and k x k never leaving LDS.
 #include "pdsc_common.h"
@@ -13,7 +14,9 @@ namespace pdsc {
 constexpr int FS_LD = PDSC_CHANNELS + 4;     // padded feature row (16 distinct bank slots for b128 reads)
 constexpr int MS_LD = PDSC_MAX_K + 1;
 
-__global__ __launch_bounds__(64) void seed_power_kernel(const float* __restrict__ normed, const float* __restrict__ src,
+constexpr int SP_WAVES = 4;
+
+__global__ __launch_bounds__(64 * SP_WAVES) void seed_power_kernel(const float* __restrict__ normed, const float* __restrict__ src,
                                                         const float* __restrict__ tgt, const int* __restrict__ knn_idx,
                                                         const float* __restrict__ sigma, const float* __restrict__ sigma_spat,
                                                         float* __restrict__ eig_iters, unsigned int* __restrict__ conv_mask,
@@ -21,8 +24,7 @@ __global__ __launch_bounds__(64) void seed_power_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float Fs[];        // [k][FS_LD]
     __shared__ __attribute__((aligned(16))) float Ms[PDSC_MAX_K * MS_LD];
     __shared__ __attribute__((aligned(16))) float pts[PDSC_MAX_K][8];
-    __shared__ float vs[PDSC_MAX_K];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x, b = blockIdx.y;
     const bool valid = lane < k;
     const int* idxp = knn_idx + ((size_t)b * S + s) * k;
@@ -30,12 +32,14 @@ __global__ __launch_bounds__(64) void seed_power_kernel(const float* __restrict_
     const float* srcb = src + (size_t)b * N * 3;
     const float* tgtb = tgt + (size_t)b * N * 3;
     const float* nb = normed + (size_t)b * N * PDSC_CHANNELS;
-    pts[lane][0] = srcb[idx * 3]; pts[lane][1] = srcb[idx * 3 + 1]; pts[lane][2] = srcb[idx * 3 + 2];
-    pts[lane][4] = tgtb[idx * 3]; pts[lane][5] = tgtb[idx * 3 + 1]; pts[lane][6] = tgtb[idx * 3 + 2];
+    if (wave == 0) {
+        pts[lane][0] = srcb[idx * 3]; pts[lane][1] = srcb[idx * 3 + 1]; pts[lane][2] = srcb[idx * 3 + 2];
+        pts[lane][4] = tgtb[idx * 3]; pts[lane][5] = tgtb[idx * 3 + 1]; pts[lane][6] = tgtb[idx * 3 + 2];
+    }
     // gather the k feature rows (32 float4 chunks each), two rows per wave instruction
-    for (int e = lane; e < k * 32; e += 64) {
+    for (int e = threadIdx.x; e < k * 32; e += 64 * SP_WAVES) {
         const int j = e >> 5, c = e & 31;
-        const int rj = __shfl(idx, j, 64);
+        const int rj = __shfl(idx, j, 64);           // every wave holds the same idx vector
         *reinterpret_cast<f32x4*>(Fs + j * FS_LD + c * 4) = *reinterpret_cast<const f32x4*>(nb + (size_t)rj * PDSC_CHANNELS + c * 4);
     }
     __syncthreads();
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(64) void seed_power_kernel(const float* __restrict_
     const int me = valid ? lane : 0;
     const float ax = pts[me][0], ay = pts[me][1], az = pts[me][2];
     const float bx = pts[me][4], by = pts[me][5], bz = pts[me][6];
-    for (int j = 0; j < k; ++j) {
+    for (int j = wave; j < k; j += SP_WAVES) {       // columns dealt round-robin to the waves
         const float* fj = Fs + j * FS_LD;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -78,26 +82,33 @@ __global__ __launch_bounds__(64) void seed_power_kernel(const float* __restrict_
         if (seed_M && valid) seed_M[(((size_t)b * S + s) * k + lane) * k + j] = m;
     }
     // power iteration: v <- M v / (||M v|| + 1e-6), every iterate kept, allclose flag per iteration
+    // (tiny: every wave runs it redundantly on identical values, wave 0 publishes)
     float v = valid ? 1.0f : 0.0f;
     float last = v;
     unsigned int bits = 0;
     float* out = eig_iters + ((size_t)b * S + s) * num_iter * PDSC_MAX_K;
-    for (int it = 0; it < num_iter; ++it) {
-        __syncthreads();
-        vs[lane] = v;
-        __syncthreads();
-        float nv = 0.f;
+    __syncthreads();                                 // Ms complete
+    float mrow[PDSC_MAX_K];                          // this lane's row of M, in registers for all iterations
+    {
         const float* mr = Ms + lane * MS_LD;
-        for (int j = 0; j < k; ++j) nv = fmaf(mr[j], vs[j], nv);
+#pragma unroll
+        for (int j = 0; j < PDSC_MAX_K; ++j) mrow[j] = j < k ? mr[j] : 0.f;
+    }
+    for (int it = 0; it < num_iter; ++it) {
+        float nv = 0.f;
+#pragma unroll
+        for (int j = 0; j < PDSC_MAX_K; ++j)
+            if (j < k)                                                 // same order as a j = 0..k-1 loop (k is wave-uniform)
+                nv = fmaf(mrow[j], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j)), nv);
         nv = valid ? nv : 0.f;
         const float nrm = sqrtf(wave_sum(nv * nv));
         v = nv / (nrm + 1e-6f);
-        out[it * PDSC_MAX_K + lane] = v;
+        if (wave == 0) out[it * PDSC_MAX_K + lane] = v;
         const bool close = fabsf(v - last) <= (1e-8f + 1e-5f * fabsf(last));   // torch.allclose(v, last)
         if (__all(close || !valid)) bits |= (1u << it);
         last = v;
     }
-    if (lane == 0) atomicAnd(conv_mask + b, bits);
+    if (threadIdx.x == 0) atomicAnd(conv_mask + b, bits);
 }
 
 // chosen iterate = first iteration at which EVERY seed of the pair passed allclose (the reference breaks
@@ -195,7 +206,7 @@ extern "C" int pdsc_seed_power_iteration(const float* normed, const float* src, 
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(conv_mask, 0xFF, sizeof(unsigned int) * bs, st) != hipSuccess) return pdsc::check_launch("memset");
     const size_t lds_bytes = (size_t)k * pdsc::FS_LD * sizeof(float);
-    hipLaunchKernelGGL(pdsc::seed_power_kernel, dim3(S, bs), dim3(64), lds_bytes, st, normed, src, tgt, knn_idx, sigma,
+    hipLaunchKernelGGL(pdsc::seed_power_kernel, dim3(S, bs), dim3(64 * pdsc::SP_WAVES), lds_bytes, st, normed, src, tgt, knn_idx, sigma,
                        sigma_spat, eig_iters, conv_mask, seed_M, N, S, k, num_iterations);
     return pdsc::check_launch("pdsc_seed_power_iteration");
 }

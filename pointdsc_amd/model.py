@@ -237,7 +237,7 @@ class PointDSC(nn.Module):
         cfg = self._config()
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
-            wsplit = self.split_weights(dev) if self.attention_precision == "bf16x3_all" else None
+            wsplit = self.split_weights(dev) if self.attention_precision != "fp32" else None
             nbytes = int(lib.pdsc_workspace_bytes(C.byref(cfg), bs, n, num_seeds))
             if nbytes == 0:
                 raise RuntimeError(f"unsupported problem size bs={bs} N={n} seeds={num_seeds}: " + _lib.last_error())

@@ -132,9 +132,11 @@ def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: to
     return msg if merge else (scratch, nsplit)
 
 
-def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False, partials=None):
+def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False, partials=None,
+                      qkv_split: bool = False):
     """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
     partials = (scratch, nsplit) from sc_attention_split(..., merge=False) replaces msg.
+    qkv_split: run the q|k|v projection in split precision (bf16 hi/lo weights).
     Returns (feat or None, featB, qkv or None, q_split, kv_tiles)."""
     lib = _lib.load()
     src = res if res is not None else feat_in
@@ -158,7 +160,8 @@ def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_q
             _p(_chk(res, "res")) if res is not None else None,
             _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB), _p(qkv), _p(qs), _p(kv)]
     args += [_p(w) for w in tail] + [_p(w) for w in head]
-    _lib.check(lib.pdsc_layer_fused_split(*args, bs, n, _stream()), "pdsc_layer_fused_split")
+    wqs = split_weight(head[2]) if qkv_split else None
+    _lib.check(lib.pdsc_layer_fused_split(*args, _p(wqs), bs, n, _stream()), "pdsc_layer_fused_split")
     return feat, featB, qkv, qs, kv
 
 

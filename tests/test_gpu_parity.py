@@ -302,7 +302,28 @@ def test_layer_fused_x3_matches_fp64_chain(n, bs):
     assert (f - f0).abs().max() < tol(feat) and (fb - fb0).abs().max() < tol(featB) and (q - q0).abs().max() < 2 * tol(qkv)
 
 
-@pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 2), (1000, 2, 3), (300, 3, 5)])
+@pytest.mark.parametrize("n,bs", [(1, 1), (33, 2), (1000, 1)])
+def test_layer_fused_split_precision_qkv_projection(n, bs):
+    """Default mode: only the q|k|v projection runs in split precision; feat / featB are bit-identical to the exact
+    kernel, q|k|v within the split tolerance, streams = packing of the kernel's own fp32 q|k|v."""
+    gen = torch.Generator().manual_seed(100 + n)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    m = bs * n
+    msg, res = rnd(m, 128), rnd(m, 128)
+    tail_w = [g(x) for x in (rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128))]
+    head_w = [g(x) for x in (rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384))]
+    f0, fb0, q0, _, _ = ops.layer_fused_split(g(msg), g(res), None, tail_w, head_w, bs, n, want_qkv=True)
+    f1, fb1, q1, qs1, kv1 = ops.layer_fused_split(g(msg), g(res), None, tail_w, head_w, bs, n, want_qkv=True, qkv_split=True)
+    assert torch.equal(f0, f1) and torch.equal(fb0, fb1)
+    want = fb0.cpu().double() @ head_w[2].cpu().double().T + head_w[3].cpu().double()
+    assert (q1.cpu().double() - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
+    want_qs, want_kv = _pack_reference(q1.cpu(), bs, n)
+    assert torch.equal(qs1.cpu(), want_qs) and torch.equal(kv1.cpu(), want_kv)
+    _, fb2, q2, qs2, kv2 = ops.layer_fused_split(None, None, f0, None, head_w, bs, n, want_qkv=True, qkv_split=True)
+    assert torch.equal(fb2, fb1) and torch.equal(q2, q1) and torch.equal(qs2, qs1) and torch.equal(kv2, kv1)
+
+
+@pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 2), (1000, 2, 3), (300, 3, 4)])
 def test_layer_fused_x3_merges_attention_partials(n, bs, nsplit):
     """Un-merged key-split partials fed to the layer kernel == merged msg fed to it (the merge arithmetic is the
     combine kernel's)."""
