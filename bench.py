@@ -5,9 +5,10 @@
 
 Metric (BASELINE.json): point-cloud pairs/sec at N=5000 correspondences.  One "step" = one pass of the whole
 hot path (pdsc_forward_testing: compat build, 12 SCNonlocal layers, seeds, per-seed solver, scoring,
-refinement) over one batch of `--pairs-per-gpu` synthetic correspondence sets per GPU, inputs already
-resident in HBM.  Pairs are independent units: every rank processes its own shard (weak scaling) and the
-only collective is the final all_gather of the poses (RCCL), which is inside the timed region.
+refinement) over one batch of 32 synthetic correspondence sets (BASELINE.json configs[2]) sharded over the
+GPUs (32 / N per GPU: strong scaling; `--pairs-per-gpu` fixes the per-GPU batch instead), inputs already
+resident in HBM.  Pairs are independent units: every rank processes its own shard and the only collective
+is the final all_gather of the poses (RCCL), which is inside the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      -- the dominant kernel (sc_attention_kernel, MFMA-bound, fp32 in/fp32 acc): algorithmic
@@ -73,7 +74,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--num-corr", type=int, default=5000, help="N correspondences per pair (headline: 5000)")
-    ap.add_argument("--pairs-per-gpu", type=int, default=4, help="batch per GPU per step (32 pairs / 8 GPUs)")
+    ap.add_argument("--global-batch", type=int, default=32,
+                    help="pairs per step over ALL GPUs (BASELINE.json configs[2]: 32 pairs sharded over the GPUs -> strong scaling)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0,
+                    help="override: fixed batch per GPU per step (weak scaling); 0 = global-batch / gpus")
     ap.add_argument("--attention-precision", choices=["bf16x3", "fp32", "bf16x3_all"], default="bf16x3",
                     help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,7 +107,13 @@ def main():
 
     from pointdsc_amd import PointDSC, _lib, sharding, synthetic
     lib = _lib.load()
-    N, B = args.num_corr, args.pairs_per_gpu
+    if args.pairs_per_gpu > 0:
+        B, scaling = args.pairs_per_gpu, "weak"
+    else:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} GPUs")
+        B, scaling = args.global_batch // world, "strong"
+    N = args.num_corr
     model = PointDSC(**MODEL_KW)
     sd = synthetic.make_state_dict(model.state_dict(), seed=6)
     model.load_state_dict(sd)
@@ -170,12 +180,13 @@ def main():
     line = {
         "metric": "point-cloud pairs/sec @ N=%d corr" % N,
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32" if args.attention_precision == "fp32" else "f32 (attention products as bf16x3 split, f32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "3DMatch-like synthetic correspondences (BASELINE.json configs[2]): N=%d corr, "
-                               "%d pairs per GPU per step, 12-layer PointDSC, seeded random weights" % (N, B),
+        "config": {"workload": "3DMatch-like synthetic correspondences (BASELINE.json configs[2]): N=%d corr, %d pairs per "
+                               "step sharded over %d GPU(s) = %d per GPU, 12-layer PointDSC, seeded random weights"
+                               % (N, total_pairs, world, B),
                    "num_corr": N, "pairs_per_gpu": B, "global_batch": total_pairs,
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses" % world},
         "roofline": ({"kernel": "sc_attention_kernel", "bound": "mfma",
@@ -197,7 +208,7 @@ def main():
                       "equivalent_fp32_mfma_frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                       "traffic": None, "launches": att_n,
                       "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}),
-        "roofline_compat": {"kernel": "compat_kernel", "bound": "hbm",
+        "roofline_compat": {"kernel": "compat_sym_kernel", "bound": "hbm",
                             "achieved": None if cmp_gbs is None else round(cmp_gbs, 1), "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": None if cmp_gbs is None else round(cmp_gbs / PEAK_HBM_GBS, 4),
                             "traffic": None, "launches": cmp_n, "avg_launch_ms": round(cmp_avg * 1e3, 4),
@@ -210,7 +221,7 @@ def main():
             key = f"N{N}_B{B}"
             if key in tj:
                 line["roofline"]["traffic"] = tj[key].get(line["roofline"]["kernel"])
-                line["roofline_compat"]["traffic"] = tj[key].get("compat_kernel")
+                line["roofline_compat"]["traffic"] = tj[key].get("compat_sym_kernel")
         except Exception:
             pass
 

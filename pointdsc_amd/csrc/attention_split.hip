@@ -35,6 +35,7 @@ struct AttSplitArgs {
     float* part_ml;              // [bs][nsplit][Npad][2]
     int N, Npad, nsplit, num_tiles, nq, bs;
     long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
+    int prio;                    // tuning knob: 1 = s_setprio 1 for the second half of the waves
 };
 
 // LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, descriptor + scalar offset + one 32-bit lane
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         for (int r = 0; r < 16; ++r) tl[r] -= m_run;
     }
 
+    if (a.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     PDSC_TRACE_STAMP(1)                          // 1: first tile (wait + QK + logits)
     for (int kt = kt0; kt < kt1; ++kt) {
         const int st = (kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
@@ -427,8 +429,11 @@ static void split_plan(int bs, int N, int* nw_out, int* nsplit_out) {
         if (((ns * bs) & 7) != 0) cost *= 1.03;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
     }
-    *nw_out = nw;
-    *nsplit_out = best;
+    static int force_nw = -1, force_ns = -1;             // tuning/A-B knobs
+    if (force_nw < 0) { const char* e = getenv("PDSC_ATT_SPLIT_NW"); force_nw = e ? atoi(e) : 0; }
+    if (force_ns < 0) { const char* e = getenv("PDSC_ATT_SPLIT_NS"); force_ns = e ? atoi(e) : 0; }
+    *nw_out = (force_nw == 4 || force_nw == 8) ? force_nw : nw;
+    *nsplit_out = force_ns > 0 ? (force_ns < tiles ? force_ns : tiles) : best;
 }
 
 }  // namespace pdsc
@@ -486,12 +491,6 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     const int tiles = spl_num_tiles(N);
     int nw, ns;
     split_plan(bs, N, &nw, &ns);
-    static int force_nw = -1;
-    if (force_nw < 0) {
-        const char* env = getenv("PDSC_ATT_SPLIT_NW");      // tuning/A-B knob
-        force_nw = env ? atoi(env) : 0;
-    }
-    if (force_nw == 4 || force_nw == 8) nw = force_nw;
     if (nsplit <= 0) nsplit = ns;
     if (nsplit > tiles) nsplit = tiles;
     PDSC_REQUIRE(msg || nsplit > 1, "pdsc_sc_attention_split: msg == NULL needs a key split > 1 (partials stay in scratch)");
@@ -507,6 +506,9 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("PDSC_ATT_PRIO"); prio = e ? atoi(e) : 0; }
+    a.prio = prio;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 4096);   // 2 stages x (K 17 KiB + V 20 KiB + compat nw*4 KiB)
     static bool attr_set = false;

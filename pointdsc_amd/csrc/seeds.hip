@@ -63,6 +63,43 @@ __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__
     if (lane == 0) keys[(size_t)b * N + i] = ci * (is_max ? 1.0f : 0.0f);   // -0.0 for suppressed negatives, like torch
 }
 
+// Same predicate with the pair's (x, y, z, conf) records staged once per workgroup in LDS (16 B per correspondence):
+// a workgroup owns NMS_ROWS_PER_WG rows, each wave walks its rows with the lanes striding the columns
+// (one conflict-free ds_read_b128 per pair instead of four cached global loads).  N <= NMS_LDS_MAX_N.
+constexpr int NMS_ROWS_PER_WG = 32;
+constexpr int NMS_LDS_MAX_N = 10000;                 // 160 000 B of the 160 KiB LDS
+
+__global__ __launch_bounds__(256) void nms_keys_lds_kernel(const float* __restrict__ src, const float* __restrict__ conf,
+                                                           float radius2, float* __restrict__ keys, int N) {
+    extern __shared__ __attribute__((aligned(16))) float4 rec[];      // [N] x, y, z, conf
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.y;
+    const float* s = src + (size_t)b * N * 3;
+    const float* c = conf + (size_t)b * N;
+    for (int j = t; j < N; j += 256) rec[j] = make_float4(s[j * 3], s[j * 3 + 1], s[j * 3 + 2], c[j]);
+    __syncthreads();
+    const int row0 = blockIdx.x * NMS_ROWS_PER_WG;
+    for (int r = wave; r < NMS_ROWS_PER_WG; r += 4) {
+        const int i = row0 + r;
+        if (i >= N) break;                              // wave-uniform
+        const float4 me = rec[i];
+        bool ok = true;
+        for (int j0 = 0; j0 < N; j0 += 256) {           // 4 independent chunks per early-exit test
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u + lane;
+                const float4 o = rec[min(j, N - 1)];
+                const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));        // norm3's radicand, same rounding
+                ok = ok && ((j >= N) || (me.w >= o.w) || (d2 >= radius2));
+            }
+            if (__any(!ok)) break;
+        }
+        const bool is_max = !__any(!ok);
+        if (lane == 0) keys[(size_t)b * N + i] = me.w * (is_max ? 1.0f : 0.0f);   // -0.0 for suppressed negatives, like torch
+    }
+}
+
 // ---- stable descending rank by counting; seeds[rank] = index for rank < num_seeds -------------------
 __global__ __launch_bounds__(256) void rank_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds,
                                                           int N, int num_seeds) {
@@ -181,6 +218,16 @@ extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, 
     } else if (radius != radius) {
         radius2 = radius;                                                    // NaN radius: every comparison is false
     }
+    if (N <= pdsc::NMS_LDS_MAX_N) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::nms_keys_lds_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, pdsc::NMS_LDS_MAX_N * 16);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(pdsc::nms_keys_lds_kernel, dim3(pdsc::ceil_div(N, pdsc::NMS_ROWS_PER_WG), bs), dim3(256),
+                           (size_t)N * 16, (hipStream_t)stream, src, conf, radius2, keys, N);
+    } else
     hipLaunchKernelGGL(pdsc::nms_keys_kernel, dim3(pdsc::ceil_div(N, 4), bs), dim3(256), 0, (hipStream_t)stream, src, conf,
                        radius2, keys, N);
     return pdsc::check_launch("pdsc_nms_keys");

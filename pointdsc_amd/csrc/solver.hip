@@ -98,8 +98,8 @@ __global__ __launch_bounds__(64 * SP_WAVES) void seed_power_kernel(const float* 
         float nv = 0.f;
 #pragma unroll
         for (int j = 0; j < PDSC_MAX_K; ++j)
-            if (j < k)                                                 // same order as a j = 0..k-1 loop (k is wave-uniform)
-                nv = fmaf(mrow[j], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j)), nv);
+            // j >= k: mrow[j] = 0 and v[j] = 0 add an exact zero, so this is the j = 0..k-1 chain without 64 branches
+            nv = fmaf(mrow[j], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j)), nv);
         nv = valid ? nv : 0.f;
         const float nrm = sqrtf(wave_sum(nv * nv));
         v = nv / (nrm + 1e-6f);
