@@ -281,6 +281,25 @@ int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void*
                          float* final_trans, float* final_labels,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- validation forward -------------------------------------------------
+ * replaces PointDSC.forward(data) WITHOUT the 'testing' key on a module in eval() mode (libs/trainer.py:158-222
+ * calls it so): models/PointDSC.py:158-163 (feature similarity matrix M), :176 (seeds = top int(N*ratio) by
+ * confidence, no NMS), :182 (per-seed hypotheses; the power iteration's allclose exit is taken over the whole batch),
+ * no post refinement, :190-191 (the returned labels are the confidence logits).  Forward only (no autograd).
+ *   final_trans [bs][16] = best seed hypothesis; logits [bs][N]; M [bs][N][ldM]. */
+int pdsc_forward_validation(const pdsc_config* cfg, const float* wpack, const void* wsplit,
+                            const float* corr_pos, const float* src_keypts, const float* tgt_keypts,
+                            int bs, int N, int num_seeds, float* final_trans, float* logits,
+                            float* M, long long ldM, void* workspace, size_t workspace_bytes, void* stream);
+
+/* M[b][i][j] = clamp(1 - (1 - <normed_i, normed_j>) / sigma^2, 0, 1), M[b][i][i] = 0   (models/PointDSC.py:158-163);
+ * normed [bs*N][C], sigma: device pointer to the learned sigma, M [bs][N][ld >= N]. */
+int pdsc_feature_compat(const float* normed, const float* sigma, float* M, long long ld, int bs, int N, void* stream);
+
+/* AND of the per-pair convergence masks of pdsc_seed_power_iteration into every entry: the reference's
+ * power-iteration exit (models/PointDSC.py:347-358) is global over all matrices of one call. */
+int pdsc_conv_mask_all_pairs(unsigned int* conv_mask, int bs, void* stream);
+
 /* Named views into the workspace of the last layout computed for (cfg, bs, N, num_seeds): lets the
  * parity tests read intermediates after pdsc_forward_testing.  Returns byte offset or -1. */
 long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name);

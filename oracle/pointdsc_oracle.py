@@ -3,7 +3,7 @@
 This file is a from-scratch restatement, in plain fp32 torch-CPU tensor algebra, of what the
 reference computes in ``PointDSC.forward`` with ``'testing' in data``:
 
-    /root/reference/models/PointDSC.py:128-197   forward
+    /root/reference/models/PointDSC.py:128-197   forward (testing mode, and the validation forward without 'testing')
     /root/reference/models/PointDSC.py:9-77      NonLocalBlock / NonLocalNet
     /root/reference/models/PointDSC.py:199-217   pick_seeds
     /root/reference/models/PointDSC.py:234-336   cal_seed_trans
@@ -334,6 +334,57 @@ def _forward_one(sd, corr_pos, src, tgt, num_layers, num_channels, num_iteration
               power_iters=iters, seed_weights=w, seed_trans=seed_trans, counts=counts, best=best,
               initial_trans=initial, refine_solves=solved, final_trans=final, final_labels=labels)
     return st
+
+
+# --------------------------------------------------------------------------------------------------
+# validation forward: no 'testing' key, module in eval() mode (reference models/PointDSC.py:158-163,:176,:190-191;
+# caller libs/trainer.py:158-222).  SURVEY.md section 8 f-1.
+# --------------------------------------------------------------------------------------------------
+def feature_compat(normed: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+    """M = clamp(1 - (1 - F F^T) / sigma^2, 0, 1) with a zero diagonal, for one pair: normed [N,C] -> [N,N]."""
+    M = normed @ normed.t()
+    M = torch.clamp(1 - (1 - M) / sigma.reshape(()) ** 2, min=0, max=1)
+    n = M.shape[0]
+    M[torch.arange(n), torch.arange(n)] = 0
+    return M
+
+
+def forward_validation(sd: Dict[str, torch.Tensor], corr_pos, src_keypts, tgt_keypts, *,
+                       num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
+                       inlier_threshold=0.10, k=40, nms_radius=0.10, return_stages=False):
+    """Batched: corr_pos [bs,N,6].  Differences from the testing forward: M is built, seeds are the top int(N*ratio)
+    correspondences by confidence (no NMS; equal logits by ascending index), the power iteration's early exit is
+    taken over the seeds of ALL pairs of the batch (one torch.allclose over [bs*S, k]), there is no refinement and
+    the returned labels are the logits."""
+    sd = {k_: v.detach().float().cpu() for k_, v in sd.items()}
+    bs, N = corr_pos.shape[0], corr_pos.shape[1]
+    num_seeds = int(N * ratio)
+    kk = min(k, N - 1)
+    per = []
+    for b in range(bs):
+        corr, src, tgt = corr_pos[b].float().cpu(), src_keypts[b].float().cpu(), tgt_keypts[b].float().cpu()
+        _, compat = spatial_compat(src, tgt, sd["sigma_spat"])
+        feat = encoder(sd, corr, compat, num_layers, num_channels)
+        normed = l2_normalize(feat)
+        conf = classify(sd, feat)
+        M = feature_compat(normed, sd["sigma"])
+        seeds = torch.sort(conf, descending=True, stable=True).indices[:num_seeds]
+        knn_idx = knn_of_seeds(normed, seeds, kk)
+        seed_M = seed_matrices(normed, src, tgt, knn_idx, sd["sigma"], sd["sigma_spat"])
+        per.append(dict(src=src, tgt=tgt, feat=feat, normed=normed, confidence=conf, M=M, seeds=seeds, knn_idx=knn_idx, seed_M=seed_M))
+    vec_all, iters = power_iteration(torch.cat([p["seed_M"] for p in per], dim=0), num_iterations)   # global early exit
+    outs_T, outs_L, outs_M = [], [], []
+    for b, p in enumerate(per):
+        vec = vec_all[b * num_seeds:(b + 1) * num_seeds]
+        w = vec / (vec.sum(-1, keepdim=True) + 1e-6)
+        seed_trans = rigid_transform_3d(p["src"][p["knn_idx"]], p["tgt"][p["knn_idx"]], w)
+        counts, best, _ = score_hypotheses(seed_trans, p["src"], p["tgt"], inlier_threshold)
+        p.update(eigvec=vec, seed_trans=seed_trans, counts=counts, best=best, power_iters=iters)
+        outs_T.append(seed_trans[best]); outs_L.append(p["confidence"]); outs_M.append(p["M"])
+    res = {"final_trans": torch.stack(outs_T), "final_labels": torch.stack(outs_L), "M": torch.stack(outs_M)}
+    if return_stages:
+        res["stages"] = per
+    return res
 
 
 # --------------------------------------------------------------------------------------------------

@@ -236,10 +236,12 @@ extern "C" int pdsc_profile_read(int kind, double* total_ms, int* launches) {
         if (rc__ != PDSC_OK) return rc__; \
     } while (0)
 
-extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
-                                    const float* src, const float* tgt, int bs, int N, int num_seeds,
-                                    float* final_trans, float* final_labels, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+// mode 0 = testing forward; mode 1 = validation forward (no 'testing' key, module in eval mode): feature similarity
+// matrix M, seeds = top-S by confidence (no NMS), batch-wide power-iteration exit, no refinement, labels = logits
+static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                       const float* src, const float* tgt, int bs, int N, int num_seeds,
+                       float* final_trans, float* final_labels, float* Mout, long long ldM, void* workspace,
+                       size_t workspace_bytes, void* stream) {
     if (!config_ok(cfg)) return PDSC_ERR_ARG;
     PDSC_REQUIRE(wpack && corr_pos && src && tgt && final_trans && final_labels && workspace,
                  "pdsc_forward_testing: null pointer");
@@ -362,19 +364,51 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
     PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), nullptr, 0, h1, 32, M, C, 32, 1, stream));
     PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
     PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
-    PDSC_TRY(pdsc_nms_keys(src, conf, cfg->nms_radius, keys, bs, N, stream));
-    PDSC_TRY(pdsc_rank_select(keys, seeds, bs, N, S, stream));
+    if (mode == 0) {
+        PDSC_TRY(pdsc_nms_keys(src, conf, cfg->nms_radius, keys, bs, N, stream));
+        PDSC_TRY(pdsc_rank_select(keys, seeds, bs, N, S, stream));
+    } else {
+        // models/PointDSC.py:158-163 and :176
+        PDSC_TRY(pdsc_feature_compat(normed, W(PDSC_W_SIGMA, 0), Mout, ldM, bs, N, stream));
+        PDSC_TRY(pdsc_rank_select(conf, seeds, bs, N, S, stream));
+    }
     // Step 3 & 4 (:182 -> :234-336): per-seed hypotheses, scoring, best
     PDSC_TRY(pdsc_knn_seeds(normed, seeds, knn_dist, knn_idx, bs, N, S, k, stream));
     PDSC_TRY(pdsc_seed_power_iteration(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig,
                                        conv_mask, nullptr, bs, N, S, k, cfg->num_iterations, stream));
+    if (mode == 1 && bs > 1) PDSC_TRY(pdsc_conv_mask_all_pairs(conv_mask, bs, stream));
     PDSC_TRY(pdsc_seed_transforms(src, tgt, knn_idx, eig, conv_mask, seed_trans, seed_w, bs, N, S, k,
                                   cfg->num_iterations, stream));
     PDSC_TRY(pdsc_score_hypotheses(seed_trans, src, tgt, cfg->inlier_threshold, counts, bs, N, S, stream));
-    PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S,
-                              stream));
-    // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
-    PDSC_TRY(pdsc_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N,
+    if (mode == 0) {
+        PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S,
                                   stream));
+        // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
+        PDSC_TRY(pdsc_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N,
+                                      stream));
+    } else {
+        // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
+        PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,
+                                  bs, N, S, stream));
+        if (hipMemcpyAsync(final_labels, conf, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return check_launch("pdsc_forward_validation(copy logits)");
+    }
     return PDSC_OK;
+}
+
+extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                                    const float* src, const float* tgt, int bs, int N, int num_seeds,
+                                    float* final_trans, float* final_labels, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, final_labels, nullptr, 0,
+                       workspace, workspace_bytes, stream);
+}
+
+extern "C" int pdsc_forward_validation(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                                       const float* src, const float* tgt, int bs, int N, int num_seeds,
+                                       float* final_trans, float* logits, float* Mout, long long ldM, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    PDSC_REQUIRE(Mout && ldM >= N, "pdsc_forward_validation: M matrix [bs][N][ldM >= N] required");
+    return run_forward(1, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, logits, Mout, ldM,
+                       workspace, workspace_bytes, stream);
 }

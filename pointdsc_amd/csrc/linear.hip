@@ -21,6 +21,7 @@ struct LinearArgs {
     const float* R; long long ldr;
     float* Y; long long ldy; long long y_batch;
     int M, K, Nout, relu;
+    const float* sigma;                                      // MODE 2: learned feature-compatibility sigma (device)
 };
 
 template <int NT, int MODE>
@@ -85,6 +86,8 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
         const int n = n0 + (wn * NT + nt) * 32 + l31;
         if (n >= a.Nout) continue;
         const float bval = (MODE == 0 && a.bias) ? a.bias[n] : 0.f;
+        float sig2 = 1.f;
+        if (MODE == 2) { const float sg = a.sigma[0]; sig2 = sg * sg; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -95,8 +98,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
                 v = v + bval;
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (a.R) v = a.R[(size_t)m * a.ldr + n] + v;
-            } else {
+            } else if (MODE == 1) {
                 v = 2.0f - 2.0f * v;       // == reference `2 - 2*matmul` (one rounding)
+            } else {
+                // feature similarity matrix of the training/validation forward (models/PointDSC.py:158-163):
+                // clamp(1 - (1 - <f_m, f_n>) / sigma^2, 0, 1), zero diagonal
+                v = fminf(fmaxf(1.0f - (1.0f - v) / sig2, 0.0f), 1.0f);
+                if (m == n) v = 0.0f;
             }
             Y[(size_t)m * a.ldy + n] = v;
         }
@@ -154,6 +162,18 @@ int knn_dist_rows(const float* normed, const int* seeds, float* dist, long long 
 }
 
 }  // namespace pdsc
+
+extern "C" int pdsc_feature_compat(const float* normed, const float* sigma, float* Mout, long long ld, int bs, int N,
+                                   void* stream) {
+    PDSC_REQUIRE(normed && sigma && Mout, "pdsc_feature_compat: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && ld >= N, "pdsc_feature_compat: bs=%d N=%d ld=%lld", bs, N, ld);
+    pdsc::LinearArgs a{};
+    a.X = normed; a.ldx = PDSC_CHANNELS; a.x_batch = (long long)N * PDSC_CHANNELS;
+    a.W = normed; a.w_batch = (long long)N * PDSC_CHANNELS;
+    a.Y = Mout; a.ldy = ld; a.y_batch = (long long)N * ld;
+    a.M = N; a.K = PDSC_CHANNELS; a.Nout = N; a.relu = 0; a.sigma = sigma;
+    return pdsc::launch_linear<2, 2>(a, bs, (hipStream_t)stream);
+}
 
 extern "C" int pdsc_linear(const float* X, long long ldx, const float* W, const float* bias, const float* residual,
                            long long ldr, float* Y, long long ldy, int M, int K, int Nout, int relu, void* stream) {

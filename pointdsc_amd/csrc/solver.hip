@@ -191,7 +191,23 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float* __res
     if (t == 0) kabsch_from_covariance(H, cA, cB, T + (size_t)b * 16);
 }
 
+// The reference's power iteration stops ALL matrices of a call at the first iteration where every one of them passes
+// allclose (models/PointDSC.py:347-358).  In testing mode a call is one pair; the validation forward is batched, so
+// there the masks of all pairs are AND-ed.
+__global__ void conv_mask_all_pairs_kernel(unsigned int* conv_mask, int bs) {
+    unsigned int m = 0xffffffffu;
+    for (int b = 0; b < bs; ++b) m &= conv_mask[b];
+    __syncthreads();
+    for (int b = threadIdx.x; b < bs; b += blockDim.x) conv_mask[b] = m;
+}
+
 }  // namespace pdsc
+
+extern "C" int pdsc_conv_mask_all_pairs(unsigned int* conv_mask, int bs, void* stream) {
+    PDSC_REQUIRE(conv_mask && bs > 0, "pdsc_conv_mask_all_pairs: bad argument");
+    hipLaunchKernelGGL(pdsc::conv_mask_all_pairs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, conv_mask, bs);
+    return pdsc::check_launch("pdsc_conv_mask_all_pairs");
+}
 
 extern "C" int pdsc_seed_power_iteration(const float* normed, const float* src, const float* tgt, const int* knn_idx,
                                          const float* sigma, const float* sigma_spat, float* eig_iters,

@@ -4,7 +4,8 @@ Mirrors reference ``models/PointDSC.py``:
   * constructor signature and defaults                               (:81-91)
   * parameter / buffer tree, hence the 358-entry ``state_dict`` of the released snapshots
     (``load_state_dict(torch.load(...), strict=False)`` works unchanged, evaluation/test_3DMatch.py:225)
-  * ``forward(data: dict) -> {'final_trans', 'final_labels', 'M'}``   (:128-197) in testing mode
+  * ``forward(data: dict) -> {'final_trans', 'final_labels', 'M'}``   (:128-197) in testing mode and, without the
+    'testing' key on an eval() module, the validation forward (M matrix + logits; forward only)
 so the reference's callers (evaluation/test_3DMatch.py:53, demo_registration.py:117) only swap the import.
 
 The sub-modules below are weight containers only; the arithmetic runs in libpointdsc_hip.so through
@@ -213,16 +214,17 @@ class PointDSC(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, Optional[torch.Tensor]]:
-        """data: corr_pos [bs,N,in_dim], src_keypts [bs,N,3], tgt_keypts [bs,N,3], key 'testing' present.
-        Returns final_trans [bs,4,4], final_labels [bs,N] (0/1 float), M None."""
+        """data: corr_pos [bs,N,in_dim], src_keypts [bs,N,3], tgt_keypts [bs,N,3].
+        With the key 'testing' (reference :145): final_trans [bs,4,4] (refined), final_labels [bs,N] (0/1 float), M None.
+        Without it (validation forward, reference :158-163,:176,:190-191): final_trans = best seed hypothesis,
+        final_labels = confidence logits, M [bs,N,N] feature similarity matrix.  Forward only, eval() mode."""
         corr_pos, src_keypts, tgt_keypts = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
-        if "testing" not in data.keys():
-            raise NotImplementedError(
-                "pointdsc_amd implements the test-time hot path (data['testing'] present); the training-mode "
-                "forward (M matrix + logits, reference models/PointDSC.py:158-163,176,190-191) is out of scope "
-                "(SURVEY.md section 8 f-1).")
+        testing = "testing" in data.keys()
         if self.training:
-            raise RuntimeError("call .eval() first: BatchNorm is folded with its running statistics")
+            raise RuntimeError(
+                "call .eval() first: BatchNorm is folded with its running statistics.  The train()-mode forward (batch "
+                "statistics + autograd, reference libs/trainer.py:68-156) is out of scope; the validation forward "
+                "(eval() mode without the 'testing' key, libs/trainer.py:158-222) is supported.")
         lib = _lib.load()
         if not corr_pos.is_cuda:
             raise RuntimeError("pointdsc_amd has no CPU path: move the model and data to the GPU (model.cuda())")
@@ -244,14 +246,19 @@ class PointDSC(nn.Module):
             ws = self._get_workspace(nbytes, dev)
             final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
             final_labels = torch.empty(bs, n, device=dev, dtype=torch.float32)
-            rc = lib.pdsc_forward_testing(C.byref(cfg), C.c_void_p(wpack.data_ptr()), C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None,
-                                          C.c_void_p(corr_pos.data_ptr()),
-                                          C.c_void_p(src_keypts.data_ptr()), C.c_void_p(tgt_keypts.data_ptr()),
-                                          bs, n, num_seeds, C.c_void_p(final_trans.data_ptr()),
-                                          C.c_void_p(final_labels.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
-                                          torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pdsc_forward_testing")
-        return {"final_trans": final_trans, "final_labels": final_labels, "M": None}
+            wsp = C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None
+            common = (C.byref(cfg), C.c_void_p(wpack.data_ptr()), wsp, C.c_void_p(corr_pos.data_ptr()),
+                      C.c_void_p(src_keypts.data_ptr()), C.c_void_p(tgt_keypts.data_ptr()), bs, n, num_seeds,
+                      C.c_void_p(final_trans.data_ptr()), C.c_void_p(final_labels.data_ptr()))
+            stream = torch.cuda.current_stream().cuda_stream
+            if testing:
+                M = None
+                rc = lib.pdsc_forward_testing(*common, C.c_void_p(ws.data_ptr()), nbytes, stream)
+            else:
+                M = torch.empty(bs, n, n, device=dev, dtype=torch.float32)
+                rc = lib.pdsc_forward_validation(*common, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
+        _lib.check(rc, "pdsc_forward_testing" if testing else "pdsc_forward_validation")
+        return {"final_trans": final_trans, "final_labels": final_labels, "M": M}
 
     def workspace_view(self, name: str, bs: int, n: int, dtype=torch.float32) -> torch.Tensor:
         """Intermediate of the LAST forward (parity tests): flat view into the workspace from `name` on."""

@@ -217,6 +217,15 @@ def layer_fused_x3(msg, res, feat_in, tail_w, head_w, bs: int, n: int, partials=
     return feat, featB, qkv, qs, kv
 
 
+def feature_compat(normed: torch.Tensor, sigma: torch.Tensor, bs: int, n: int) -> torch.Tensor:
+    """normed [bs*N,128] -> M [bs,N,N] = clamp(1 - (1 - F F^T)/sigma^2, 0, 1), zero diagonal (models/PointDSC.py:158-163)."""
+    lib = _lib.load()
+    normed, sig = _chk(normed, "normed"), _chk(sigma.reshape(-1), "sigma")
+    m = torch.empty(bs, n, n, device=normed.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_feature_compat(_p(normed), _p(sig), _p(m), n, bs, n, _stream()), "pdsc_feature_compat")
+    return m
+
+
 def normalize_confidence(feat, h2, w3, b3) -> Tuple[torch.Tensor, torch.Tensor]:
     lib = _lib.load()
     feat, h2, w3, b3 = _chk(feat, "feat"), _chk(h2, "h2"), _chk(w3.reshape(-1), "w3"), _chk(b3.reshape(-1), "b3")

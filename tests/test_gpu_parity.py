@@ -739,6 +739,61 @@ def test_inputs_are_not_mutated_and_errors_are_loud():
 
 
 # ------------------------------------------------------------------------------------------------------
+# validation forward (no 'testing' key, eval() mode): SURVEY.md section 8 f-1
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,bs", [(257, 1), (1000, 2), (65, 3)])
+def test_feature_compat_matches_oracle(n, bs):
+    gen = torch.Generator().manual_seed(n)
+    f = torch.randn(bs, n, 128, generator=gen)
+    f[:, 1] = f[:, 0]                                         # an exact duplicate: similarity 1 -> clamps at 1
+    normed = O.l2_normalize(f.reshape(-1, 128)).reshape(bs, n, 128)
+    for sigma in (1.0, 0.37):
+        got = ops.feature_compat(g(normed.reshape(-1, 128)), g(torch.tensor([sigma])), bs, n).cpu()
+        for b in range(bs):
+            want = O.feature_compat(normed[b], torch.tensor([sigma]))
+            assert (got[b] - want).abs().max() < 2e-6 / sigma ** 2      # fp32 dot-product order, amplified by 1/sigma^2
+            assert bool((torch.diagonal(got[b]) == 0).all()) and float(got[b].min()) >= 0 and float(got[b].max()) <= 1
+            assert torch.equal(got[b], got[b].T)                        # symmetric bit for bit
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name", ["val_n257_b1", "val_n1000_b3", "val_n2053_b2"])
+def test_validation_forward_matches_reference_golden(name, precision):
+    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    kw = json.loads(str(fx["model_json"]))
+    model = PointDSC(**kw)
+    model.load_state_dict(synthetic.make_state_dict(model.state_dict(), seed=int(fx["wseed"])))
+    model = model.eval().to(DEV)
+    model.attention_precision = precision
+    data = {k: g(torch.from_numpy(fx[k])) for k in ("corr_pos", "src_keypts", "tgt_keypts")}      # no 'testing' key
+    with torch.no_grad():
+        res = model(data)
+    torch.cuda.synchronize()
+    bs, n = fx["corr_pos"].shape[:2]
+    assert res["M"].shape == (bs, n, n) and res["final_labels"].shape == (bs, n) and res["final_trans"].shape == (bs, 4, 4)
+    scale = max(1.0, float(np.abs(fx["ref_logits"]).max()))
+    assert (res["final_labels"].cpu() - torch.from_numpy(fx["ref_logits"])).abs().max() < 3e-5 * scale      # logits
+    assert (res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().max() < 1e-4          # R/t
+    rows = torch.from_numpy(fx["M_rows"])
+    M = res["M"].cpu()
+    assert (M[:, rows] - torch.from_numpy(fx["ref_M_rows"])).abs().max() < 3e-5                             # features enter M directly
+    assert bool((torch.diagonal(M, dim1=1, dim2=2) == 0).all()) and float(M.min()) >= 0 and float(M.max()) <= 1
+    if "ref_M" in fx.files:
+        assert (M - torch.from_numpy(fx["ref_M"])).abs().max() < 3e-5
+
+
+def test_validation_forward_needs_eval_mode():
+    c = case(257)
+    data = {k: g(c["pair"][k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    c["model"].train()
+    with pytest.raises(RuntimeError, match="eval"):
+        c["model"](data)
+    c["model"].eval()
+    res = c["model"](data)
+    assert res["M"] is not None and not torch.equal(res["final_labels"], res["final_labels"].round())       # logits, not 0/1
+
+
+# ------------------------------------------------------------------------------------------------------
 # BASELINE.json size (N=5000, 4 pairs per GPU): size-independent properties
 # ------------------------------------------------------------------------------------------------------
 def test_full_size_batch_properties():
