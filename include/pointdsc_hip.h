@@ -300,6 +300,22 @@ int pdsc_feature_compat(const float* normed, const float* sigma, float* M, long 
  * power-iteration exit (models/PointDSC.py:347-358) is global over all matrices of one call. */
 int pdsc_conv_mask_all_pairs(unsigned int* conv_mask, int bs, void* stream);
 
+/* ---- correspondence construction: the step in front of the hot path -----------------
+ * replaces datasets/ThreeDMatch.py:283-290,305-308 / demo_registration.py:101-108 (numpy on the host in the reference):
+ *   distance = sqrt(2 - 2 * src_desc @ tgt_desc^T + 1e-6);  nn_idx[i] = argmin_j distance[i][j] (first index among equal
+ *   distances, NaN first -- np.argmin);  nn_dist[i] (optional) = that distance.  The Ns x Nt matrix is never stored.
+ * src_desc [Ns][D], tgt_desc [Nt][D] fp32 (L2-normalised descriptors, D <= 64); scratch: pdsc_match_scratch_bytes. */
+size_t pdsc_match_scratch_bytes(int Ns, int Nt);
+int pdsc_match_descriptors(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
+                           float* nn_dist, void* scratch, size_t scratch_bytes, void* stream);
+/* corr[c] = (i, src2tgt[i]) for i ascending; with tgt2src != NULL only the mutual nearest neighbours
+ * (tgt2src[src2tgt[i]] == i, ThreeDMatch.py:286-288) are kept.  corr [Ns][2] (capacity), *count = rows written. */
+int pdsc_select_correspondences(const int* src2tgt, const int* tgt2src, int Ns, int* corr, int* count, void* stream);
+/* src_sel[c] = src_keypts[corr[c][0]], tgt_sel[c] = tgt_keypts[corr[c][1]], corr_pos[c] = (src_sel | tgt_sel) - column mean
+ * over the *count rows (in_dim = 6, ThreeDMatch.py:299-308).  Outputs have capacity for every row of corr. */
+int pdsc_build_corr_pos(const float* src_keypts, const float* tgt_keypts, const int* corr, const int* count,
+                        float* corr_pos, float* src_sel, float* tgt_sel, void* stream);
+
 /* Named views into the workspace of the last layout computed for (cfg, bs, N, num_seeds): lets the
  * parity tests read intermediates after pdsc_forward_testing.  Returns byte offset or -1. */
 long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name);

@@ -80,6 +80,10 @@ SIGNATURES = {
     "pdsc_profile_enable": (_i, [_i]),
     "pdsc_profile_reset": (_i, []),
     "pdsc_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "pdsc_match_scratch_bytes": (_sz, [_i, _i]),
+    "pdsc_match_descriptors": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pdsc_select_correspondences": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "pdsc_build_corr_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pdsc_forward_validation": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _ll, _vp, _sz, _vp]),
     "pdsc_feature_compat": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pdsc_conv_mask_all_pairs": (_i, [_vp, _i, _vp]),

@@ -794,6 +794,69 @@ def test_validation_forward_needs_eval_mode():
 
 
 # ------------------------------------------------------------------------------------------------------
+# correspondence construction in front of the path: SURVEY.md section 8 f-2
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["corr_n300_d32", "corr_n1000_d33_mutual", "corr_n5000_d32_mutual"])
+def test_build_correspondences_matches_reference_golden(name):
+    from oracle import correspondence_oracle as CO
+    from pointdsc_amd import correspondences
+    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    src, tgt, skp, tkp = CO.make_descriptors(int(fx["ns"]), int(fx["nt"]), int(fx["d"]), int(fx["seed"]))
+    idx, dist = correspondences.match_descriptors(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), want_dist=True)
+    assert np.array_equal(idx.cpu().numpy(), fx["ref_source_idx"])                      # index work: exact
+    want = CO.nn_distance_matrix(src, tgt).min(axis=1)
+    assert np.abs(dist.cpu().numpy() - want).max() < 2e-6
+    res = correspondences.build_correspondences(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), g(torch.from_numpy(skp)),
+                                                g(torch.from_numpy(tkp)), use_mutual=bool(fx["mutual"]))
+    assert np.array_equal(res["corr"].cpu().numpy(), fx["ref_corr"])
+    assert res["corr_pos"].shape == (1, fx["ref_corr"].shape[0], 6)
+    # the kernel's column means are correctly rounded (fp64 sums); numpy's float32 mean of 3000 rows is good to ~4e-6
+    assert np.abs(res["corr_pos"][0].cpu().numpy() - fx["ref_corr_pos"]).max() < 1e-5
+    assert np.array_equal(res["src_keypts"][0].cpu().numpy(), skp[fx["ref_corr"][:, 0]])
+    assert np.array_equal(res["tgt_keypts"][0].cpu().numpy(), tkp[fx["ref_corr"][:, 1]])
+
+
+def test_match_descriptors_ties_and_ragged_sizes():
+    """Equal distances -> the first index (np.argmin); sizes that are not multiples of any tile; D not a multiple of 8."""
+    from oracle import correspondence_oracle as CO
+    from pointdsc_amd import correspondences
+    src, tgt, _, _ = CO.make_descriptors(131, 77, 33, seed=9)
+    tgt[40] = tgt[3]                          # exact duplicates: both at the same distance from everybody
+    tgt[76] = tgt[3]
+    src[5] = tgt[3]
+    idx = correspondences.match_descriptors(g(torch.from_numpy(src)), g(torch.from_numpy(tgt))).cpu().numpy()
+    want = np.argmin(CO.nn_distance_matrix(src, tgt), axis=1)
+    assert np.array_equal(idx, want) and idx[5] == 3
+    for ns, nt, d in ((1, 1, 8), (5, 700, 32), (700, 5, 64), (257, 129, 1)):
+        s, t, _, _ = CO.make_descriptors(ns, nt, d, seed=ns + nt)
+        got = correspondences.match_descriptors(g(torch.from_numpy(s)), g(torch.from_numpy(t))).cpu().numpy()
+        dm = CO.nn_distance_matrix(s, t)
+        # compare through the distances (d = 1: many exact ties are legitimate, the index must still be the first minimum)
+        assert np.array_equal(got, np.argmin(dm, axis=1)) or np.abs(dm[np.arange(ns), got] - dm.min(axis=1)).max() < 1e-6
+
+
+def test_correspondences_feed_the_forward():
+    """descriptors -> build_correspondences -> PointDSC.forward: the registration of a synthetic pair is recovered."""
+    from pointdsc_amd import correspondences
+    c = case(1000)
+    rs = np.random.RandomState(0)
+    n = 1500
+    pair = synthetic.make_pair(n, seed=77, inlier_ratio=1.0, noise=0.005)          # every source point has a true partner
+    desc = rs.randn(n, 32).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    sdesc = desc + 0.25 * rs.randn(n, 32).astype(np.float32)                         # noisy copy: ~ some wrong matches
+    sdesc /= np.linalg.norm(sdesc, axis=1, keepdims=True)
+    perm = rs.permutation(n)                                                         # target cloud in another order
+    data = correspondences.build_correspondences(g(torch.from_numpy(sdesc)), g(torch.from_numpy(desc[perm])),
+                                                 pair["src_keypts"][0].to(DEV), pair["tgt_keypts"][0][perm].to(DEV))
+    assert data["corr_pos"].shape == (1, n, 6)
+    data["testing"] = True
+    res = c["model"](data)
+    re, te = O.registration_errors(res["final_trans"][0].cpu(), pair["gt_trans"][0])
+    assert re < 1.0 and te < 5.0
+
+
+# ------------------------------------------------------------------------------------------------------
 # BASELINE.json size (N=5000, 4 pairs per GPU): size-independent properties
 # ------------------------------------------------------------------------------------------------------
 def test_full_size_batch_properties():
