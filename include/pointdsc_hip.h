@@ -316,6 +316,19 @@ int pdsc_select_correspondences(const int* src2tgt, const int* tgt2src, int Ns, 
 int pdsc_build_corr_pos(const float* src_keypts, const float* tgt_keypts, const int* corr, const int* count,
                         float* corr_pos, float* src_sel, float* tgt_sel, void* stream);
 
+/* ---- spectral-matching baseline: the N x N power iteration ------------------------------
+ * replaces SM() of baseline_scripts/baseline_3DMatch.py:19-53:  M = max(0, 4.5 - d^2 / 2 / sigma^2) (zero diagonal,
+ * d = |corr_i[0:3] - corr_j[0:3]| - |corr_i[3:6] - corr_j[3:6]|, sigma = inlier_threshold / 3);  v = 1, num_iterations x
+ * { v = M v; v /= |v| + 1e-6 };  pred_labels = 1 for the num_top = int(N * top_ratio) largest entries of v (equal
+ * entries by ascending index);  pred_trans = rigid_transform_3d(src_keypts, tgt_keypts, v * pred_labels).
+ * corr_pos [bs][N][6] (the centred coordinates the reference passes as `corr`), src/tgt [bs][N][3];
+ * pred_trans [bs][16], pred_labels [bs][N], leading_eig (optional) [bs][N]; workspace: pdsc_sm_workspace_bytes
+ * (holds M: 4 N ld bytes per pair).  bs > 1 = independent pairs (the reference asserts bs == 1). */
+size_t pdsc_sm_workspace_bytes(int bs, int N);
+int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
+                     int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
+                     void* workspace, size_t workspace_bytes, int bs, int N, void* stream);
+
 /* Named views into the workspace of the last layout computed for (cfg, bs, N, num_seeds): lets the
  * parity tests read intermediates after pdsc_forward_testing.  Returns byte offset or -1. */
 long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name);

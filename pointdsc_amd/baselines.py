@@ -1,0 +1,41 @@
+"""Classical baselines of the reference that share the hot path's kernels.
+
+``SM`` mirrors ``baseline_scripts/baseline_3DMatch.py:19-53`` (spectral matching: N x N compatibility matrix + 10 power
+iterations + top-10 % selection + weighted Procrustes) with the reference's argument meaning; the arithmetic runs in
+``csrc/spectral.hip`` (matrix written once, one HBM-bound mat-vec launch per iteration).  GPU only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def SM(corr: torch.Tensor, src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, inlier_threshold: float, top_ratio: float = 0.1,
+       num_iterations: int = 10, return_eig: bool = False):
+    """corr [N,6] (or [bs,N,6]) centred correspondence coordinates, src/tgt_keypts [bs,N,3] ->
+    (pred_trans [bs,4,4], pred_labels [bs,N]) like the reference's SM(corr, src_keypts, tgt_keypts, args, top_ratio)
+    with ``args.inlier_threshold`` passed explicitly; bs > 1 = independent pairs."""
+    lib = _lib.load()
+    if not corr.is_cuda:
+        raise RuntimeError("pointdsc_amd has no CPU path: move the tensors to the GPU")
+    src = src_keypts.detach().to(torch.float32).contiguous()
+    tgt = tgt_keypts.detach().to(torch.float32).contiguous()
+    bs, n = src.shape[0], src.shape[1]
+    c = corr.detach().to(torch.float32).reshape(bs, n, 6).contiguous()
+    dev = c.device
+    num_top = int(n * top_ratio)                               # python double arithmetic, as the reference (:47)
+    trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
+    labels = torch.empty(bs, n, device=dev, dtype=torch.float32)
+    eig = torch.empty(bs, n, device=dev, dtype=torch.float32)
+    nb = int(lib.pdsc_sm_workspace_bytes(bs, n))
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        rc = lib.pdsc_sm_baseline(C.c_void_p(c.data_ptr()), C.c_void_p(src.data_ptr()), C.c_void_p(tgt.data_ptr()),
+                                  float(inlier_threshold), num_top, int(num_iterations), C.c_void_p(trans.data_ptr()),
+                                  C.c_void_p(labels.data_ptr()), C.c_void_p(eig.data_ptr()), C.c_void_p(ws.data_ptr()), nb,
+                                  bs, n, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pdsc_sm_baseline")
+    return (trans, labels, eig) if return_eig else (trans, labels)

@@ -857,6 +857,46 @@ def test_correspondences_feed_the_forward():
 
 
 # ------------------------------------------------------------------------------------------------------
+# spectral-matching baseline (N x N power iteration): SURVEY.md section 8 f-3
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["sm_n257", "sm_n2000", "sm_n5000", "sm_kitti_n1500"])
+def test_sm_baseline_matches_reference_golden(name):
+    from oracle import sm_oracle
+    from pointdsc_amd import baselines
+    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    pair = synthetic.make_pair(int(fx["N"]), seed=int(fx["seed"]), inlier_ratio=float(fx["inlier_ratio"]),
+                               scale=float(fx["scale"]), noise=float(fx["noise"]))
+    thr = float(fx["thr"])
+    trans, labels, eig = baselines.SM(g(pair["corr_pos"]), g(pair["src_keypts"]), g(pair["tgt_keypts"]), thr, return_eig=True)
+    n = int(fx["N"])
+    assert trans.shape == (1, 4, 4) and labels.shape == (1, n) and int(labels.sum()) == int(n * 0.1)
+    _, want_labels, want_eig = sm_oracle.sm_baseline(pair["corr_pos"][0], pair["src_keypts"][0], pair["tgt_keypts"][0], thr)
+    eig = eig[0].cpu()
+    assert (eig - want_eig).abs().max() < 2e-6 * float(want_eig.abs().max()) + 1e-9         # 10 mat-vecs in another order
+    # the cut sits inside the inlier block, where neighbouring eigenvector entries can be closer than fp32 round-off:
+    # labels must agree everywhere except within that margin of the cut value
+    ref_labels = torch.from_numpy(fx["ref_pred_labels"][0])
+    cut = float(torch.sort(want_eig, descending=True).values[int(n * 0.1) - 1])
+    decided = (want_eig - cut).abs() > 4e-6 * float(want_eig.abs().max())
+    assert torch.equal(labels[0].cpu()[decided], ref_labels[decided])
+    flips = int((labels[0].cpu() != ref_labels).sum())
+    assert flips <= 2 * int((~decided).sum())
+    tol = 1e-4 if flips == 0 else 3e-3                                                      # another inlier subset moves the pose
+    assert (trans[0].cpu() - torch.from_numpy(fx["ref_pred_trans"][0])).abs().max() < tol * max(1.0, float(fx["scale"]) / 3.0)
+
+
+def test_sm_baseline_batched_equals_per_pair():
+    from pointdsc_amd import baselines
+    batch = synthetic.make_batch(3, 700, seed=60, inlier_ratio=0.35)
+    T, L = baselines.SM(g(batch["corr_pos"]), g(batch["src_keypts"]), g(batch["tgt_keypts"]), 0.10)
+    for i in range(3):
+        t1, l1 = baselines.SM(g(batch["corr_pos"][i:i + 1]), g(batch["src_keypts"][i:i + 1]), g(batch["tgt_keypts"][i:i + 1]), 0.10)
+        assert torch.equal(L[i], l1[0]) and torch.equal(T[i], t1[0])
+        re, te = O.registration_errors(T[i].cpu(), batch["gt_trans"][i])
+        assert re < 1.0 and te < 5.0
+
+
+# ------------------------------------------------------------------------------------------------------
 # BASELINE.json size (N=5000, 4 pairs per GPU): size-independent properties
 # ------------------------------------------------------------------------------------------------------
 def test_full_size_batch_properties():
