@@ -329,6 +329,15 @@ int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float
                      int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
                      void* workspace, size_t workspace_bytes, int bs, int N, void* stream);
 
+/* ---- evaluation row on the device -----------------------------------------------------------
+ * replaces libs/loss.py:44-51 (RE / TE / recall of TransformationLoss), :96-100 (precision / recall / F1, sklearn on the
+ * host) and the stats row of evaluation/test_3DMatch.py:90-98, per pair, without a device -> host copy:
+ *   stats[b][0..8] = success (RE < re_thre && TE < te_thre), RE [deg], TE [cm], #gt inliers, gt inlier ratio,
+ *                    #gt inliers among the predicted inliers, precision, recall, F1       (pred > 0 is "predicted inlier")
+ * trans, gt_trans [bs][16]; pred_labels, gt_labels [bs][N]; stats [bs][9]. */
+int pdsc_eval_stats(const float* trans, const float* gt_trans, const float* pred_labels, const float* gt_labels,
+                    float re_thre, float te_thre, float* stats, int bs, int N, void* stream);
+
 /* Named views into the workspace of the last layout computed for (cfg, bs, N, num_seeds): lets the
  * parity tests read intermediates after pdsc_forward_testing.  Returns byte offset or -1. */
 long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name);

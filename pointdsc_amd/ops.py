@@ -217,6 +217,22 @@ def layer_fused_x3(msg, res, feat_in, tail_w, head_w, bs: int, n: int, partials=
     return feat, featB, qkv, qs, kv
 
 
+STATS_COLUMNS = ("success", "RE_deg", "TE_cm", "num_gt_inliers", "gt_inlier_ratio", "num_true_positives", "precision", "recall", "f1")
+
+
+def eval_stats(trans, gt_trans, pred_labels, gt_labels, re_thre: float = 15.0, te_thre: float = 30.0) -> torch.Tensor:
+    """[bs,9] evaluation rows on the device (columns: STATS_COLUMNS) -- libs/loss.py:44-51,96-100 and the stats row of
+    evaluation/test_3DMatch.py:90-98 without the per-pair device->host copies."""
+    lib = _lib.load()
+    T, G = _chk(trans, "trans"), _chk(gt_trans, "gt_trans")
+    p, g = _chk(pred_labels, "pred_labels"), _chk(gt_labels.to(torch.float32), "gt_labels")
+    bs, n = p.shape
+    stats = torch.empty(bs, 9, device=p.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_eval_stats(_p(T), _p(G), _p(p), _p(g), float(re_thre), float(te_thre), _p(stats), bs, n, _stream()),
+               "pdsc_eval_stats")
+    return stats
+
+
 def feature_compat(normed: torch.Tensor, sigma: torch.Tensor, bs: int, n: int) -> torch.Tensor:
     """normed [bs*N,128] -> M [bs,N,N] = clamp(1 - (1 - F F^T)/sigma^2, 0, 1), zero diagonal (models/PointDSC.py:158-163)."""
     lib = _lib.load()

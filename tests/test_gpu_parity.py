@@ -897,6 +897,23 @@ def test_sm_baseline_batched_equals_per_pair():
 
 
 # ------------------------------------------------------------------------------------------------------
+# evaluation row on the device: SURVEY.md section 8 f-4
+# ------------------------------------------------------------------------------------------------------
+def test_eval_stats_match_reference_losses():
+    """24 seeded (pose, labels) cases through the reference's TransformationLoss / ClassificationLoss (fixture written by
+    oracle/check_metrics_against_reference.py) vs pdsc_eval_stats."""
+    fx = np.load(GOLDEN / "metrics.npz", allow_pickle=False)
+    stats = ops.eval_stats(g(torch.from_numpy(fx["trans"])), g(torch.from_numpy(fx["gt_trans"])),
+                           g(torch.from_numpy(fx["pred_labels"])), g(torch.from_numpy(fx["gt_labels"]))).cpu().double().numpy()
+    ref = fx["ref_stats"]
+    assert np.array_equal(stats[:, 0], ref[:, 0])                                  # success flags
+    assert np.array_equal(stats[:, 3], ref[:, 3]) and np.array_equal(stats[:, 5], ref[:, 5])      # counts: exact
+    assert np.abs(stats[:, 1] - ref[:, 1]).max() < 2e-2                            # RE [deg]: acos is ill-conditioned near 0
+    assert np.abs(stats[:, 2] - ref[:, 2]).max() < 1e-3                            # TE [cm]
+    assert np.abs(stats[:, [4, 6, 7, 8]] - ref[:, [4, 6, 7, 8]]).max() < 1e-6      # ratios
+
+
+# ------------------------------------------------------------------------------------------------------
 # BASELINE.json size (N=5000, 4 pairs per GPU): size-independent properties
 # ------------------------------------------------------------------------------------------------------
 def test_full_size_batch_properties():
