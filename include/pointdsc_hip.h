@@ -208,6 +208,10 @@ int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const 
  * NULL (default) switches it off.  Used by tools/attention_trace.py only. */
 int pdsc_attention_trace(long long* device_buffer);
 
+/* Same for the fused layer kernel: buffer of (#workgroups * 4 waves * 16) int64 receiving raw shader-clock stamps at the
+ * stage boundaries of layer_fused_kernel (tools/layer_trace.py); NULL switches it off. */
+int pdsc_layer_trace(long long* device_buffer);
+
 /* ---- a-4  L2 normalisation + last classifier layer --------------------------------------------
  * replaces F.normalize (models/PointDSC.py:156) and classification.4 (:112,171).
  *   normed[m][:] = feat[m][:] / max(||feat[m]||_2, 1e-12);  conf[m] = <h2[m][0:32], w3> + b3 */

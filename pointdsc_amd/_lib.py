@@ -63,6 +63,7 @@ SIGNATURES = {
     "pdsc_attention_split_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_split_default_split": (_i, [_i, _i]),
     "pdsc_attention_trace": (_i, [_vp]),
+    "pdsc_layer_trace": (_i, [_vp]),
     "pdsc_sc_attention_split": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "pdsc_attention_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_default_split": (_i, [_i, _i]),

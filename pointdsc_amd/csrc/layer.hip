@@ -37,7 +37,11 @@ struct LayerArgs {
     __bf16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
     unsigned char* kv;       // head, optional: K/V tile stream  [bs][tiles][32 KiB]  (split_layout.h)
     int N, bs;               // rows are bs pairs of N points; a workgroup's 32-point tile never straddles two pairs
+    long long* trace;        // diagnostics (pdsc_layer_trace): [workgroup][wave][16] shader-clock stamps, else NULL
 };
+
+#define LF_STAMP(k)                                                                                   \
+    if (a.trace && lane == 0) a.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (k)] = __builtin_readcyclecounter();
 
 template <int K>
 __device__ __forceinline__ void load_w(const float* __restrict__ W, int n0, int l31, int h, f32x4 (&w)[K / 8]) {
@@ -163,12 +167,18 @@ __device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs
         global_to_tile(a.msg, Xs, m0, M, t);
         return;
     }
+    MergeLoads L[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
         const int m = min(m0 + row, M - 1);
         const size_t slot0 = (size_t)b * a.nsplit * a.Npad + (size_t)(m - b * a.N);
-        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_chunk(a.part_o, a.part_ml, slot0, (size_t)a.Npad, a.nsplit, c4);
+        merge_partials_load(L[i], a.part_o, a.part_ml, slot0, (size_t)a.Npad, a.nsplit, c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_finish(L[i], a.nsplit);
     }
 }
 
@@ -176,7 +186,7 @@ constexpr int LF_XLD16 = PDSC_CHANNELS + 8;          // bf16 elements per row of
 constexpr int LF_XB_FLOATS = LF_ROWS * LF_XLD16;     // Xb doubles as the bf16 hi|lo image of featB: 2 * 32 * 136 * 2 B
 
 template <bool HAS_TAIL, bool HAS_HEAD, bool QKV_X3>
-__global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
+__global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) float Xa[LF_TILE];
     __shared__ __attribute__((aligned(16))) float Xb[LF_XB_FLOATS > LF_TILE ? LF_XB_FLOATS : LF_TILE];
     const int t = threadIdx.x, lane = t & 63;
@@ -185,12 +195,16 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
     const int m0 = blockIdx.y * a.N + blockIdx.x * LF_ROWS;     // first row of this tile
     const int M = (blockIdx.y + 1) * a.N;                        // end of this pair's rows
 
+    LF_STAMP(0)
+    f32x4 wpre[16];                                                  // PointCN weight tile of this wave (prefetched early)
     if (HAS_TAIL) {
         f32x4 w128[16], w64[8];
         // ---- fc1: 128 -> 64 (+BN, ReLU): tiles {0,1} on waves {0,1} ----
         if (wave < 2) load_w<128>(a.w1, 32 * wave, l31, h, w128);
         msg_to_tile(a, blockIdx.y, Xa, m0, M, t);
+        LF_STAMP(1)
         __syncthreads();
+        LF_STAMP(2)
         if (wave < 2) {
             f32x4 x[16];
             load_x<128>(Xa, l31, h, x);
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
             const f32x16 acc = mma_tile<128>(w128, x);
             store_tile<true, false>(acc, a.b1, 32 * wave, Xb, 32 * wave, l31, h, nullptr);
         }
+        LF_STAMP(3)
         __syncthreads();
         // ---- fc2: 64 -> 64 (+BN, ReLU) ----
         f32x4 w3r[8];
@@ -208,8 +223,10 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
             const f32x16 acc = mma_tile<64>(w64, x);
             store_tile<true, false>(acc, a.b2, 32 * wave, Xa, 32 * wave, l31, h, nullptr);
         }
+        LF_STAMP(4)
         __syncthreads();
         // ---- fc3: 64 -> 128, + residual featB: tile = wave ----
+        if (HAS_HEAD) load_w<128>(a.wp, 32 * wave, l31, h, wpre);      // PointCN weights of the head: under fc3's MFMAs
         {
             f32x4 x[8];
             load_x<64>(Xa, l31, h, x);
@@ -217,9 +234,12 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
             const float* res_row = a.res + (size_t)min(m0 + l31, M - 1) * PDSC_CHANNELS;
             store_tile<false, true>(acc, a.b3, 32 * wave, Xb, 32 * wave, l31, h, res_row);
         }
+        LF_STAMP(5)
         __syncthreads();
+        LF_STAMP(6)
         if (a.feat_out) tile_to_global(Xb, a.feat_out, PDSC_CHANNELS, m0, M, t);
     } else {
+        if (HAS_HEAD) load_w<128>(a.wp, 32 * wave, l31, h, wpre);
         global_to_tile(a.feat_in, Xb, m0, M, t);
         __syncthreads();
     }
@@ -227,10 +247,9 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
     if (HAS_HEAD && !QKV_X3) {
         // ---- PointCN: 128 -> 128 (+BN, ReLU): tile = wave; input Xb, output Xa ----
         f32x4 w[16], x[16];
-        load_w<128>(a.wp, 32 * wave, l31, h, w);
         load_x<128>(Xb, l31, h, x);
         {
-            const f32x16 acc = mma_tile<128>(w, x);
+            const f32x16 acc = mma_tile<128>(wpre, x);
             load_w<128>(a.wq, 32 * wave, l31, h, w);                  // prefetch first qkv tile
             store_tile<true, false>(acc, a.bp, 32 * wave, Xa, 32 * wave, l31, h, nullptr);
         }
@@ -262,10 +281,8 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
         __bf16* Xl = Xh + LF_ROWS * LF_XLD16;
         bf16x8 wh[8], wl[8];
         {
-            f32x4 w[16], x[16];
-            load_w<128>(a.wp, 32 * wave, l31, h, w);
+            f32x4 x[16];
             load_x<128>(Xb, l31, h, x);
-            const f32x16 acc = mma_tile<128>(w, x);
             // prefetch the first split qkv tile: lane (row l31, half h), step kk holds k = 16kk+8h..+7
             {
                 const __bf16* p = a.wq_split + (size_t)(32 * wave + l31) * PDSC_CHANNELS + 8 * h;
@@ -275,6 +292,9 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
                     wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
                 }
             }
+            const f32x16 acc = mma_tile<128>(wpre, x);
+            // (the first split qkv tile was requested above, under these MFMAs)
+            LF_STAMP(7)
             __syncthreads();                                          // every wave holds its copy of Xb: Xb may be rewritten
             // ... stored twice: fp32 -> Xa (featB_out), bf16 hi|lo -> Xb (operand of the split-precision q|k|v GEMM)
 #pragma unroll
@@ -293,8 +313,10 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
                 *reinterpret_cast<bf16x4*>(Xl + l31 * LF_XLD16 + col) = lo;
             }
         }
+        LF_STAMP(8)
         __syncthreads();
         tile_to_global(Xa, a.featB_out, PDSC_CHANNELS, m0, M, t);
+        LF_STAMP(9)
         // ---- q|k|v: 128 -> 384, three 128-column chunks, hi*hi + hi*lo + lo*hi on the bf16 matrix cores, staged via Xa ----
         unsigned char* img = a.kv ? a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_BYTES : nullptr;
         const int valid = min(LF_ROWS, M - m0);
@@ -320,16 +342,20 @@ __global__ __launch_bounds__(256, 2) void layer_fused_kernel(LayerArgs a) {
                     wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
                 }
             }
+            if (c == 0) { LF_STAMP(10) }
             __syncthreads();                                          // previous readers of Xa are done
             store_tile<false, false>(acc, a.bq, n0, Xa, 32 * wave, l31, h, nullptr);
             __syncthreads();
+            if (c == 0) { LF_STAMP(11) }
             if (a.qkv_out) tile_to_global(Xa, a.qkv_out + 128 * c, 3 * PDSC_CHANNELS, m0, M, t);
             if (a.qs) {
                 if (c == 0) tile_to_split<0>(Xa, a.qs + (size_t)m0 * SPL_Q_LD, img, valid, t);
                 else if (c == 1) tile_to_split<1>(Xa, nullptr, img, valid, t);
                 else { tile_to_split<2>(Xa, nullptr, img, valid, t); spl_zero_pads(img, t); }
             }
+            if (c == 0) { LF_STAMP(12) }
         }
+        LF_STAMP(13)
     }
 }
 
@@ -343,6 +369,12 @@ static int launch_layer(const LayerArgs& a, hipStream_t st) {
 }
 
 }  // namespace pdsc
+
+static long long* g_layer_trace = nullptr;
+extern "C" int pdsc_layer_trace(long long* device_buffer) {       // diagnostics: see include/pointdsc_hip.h
+    g_layer_trace = device_buffer;
+    return PDSC_OK;
+}
 
 extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
                                       const float* res, const float* feat_in, float* feat_out,
@@ -362,7 +394,7 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
-                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs};
+                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, g_layer_trace};
     hipStream_t st = (hipStream_t)stream;
     if (tail && head) return pdsc::launch_layer<true, true>(a, st);
     if (tail) return pdsc::launch_layer<true, false>(a, st);

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Stage timeline of layer_fused_kernel<tail, head, split qkv> (pdsc_layer_trace stamps), in shader clocks."""
+import argparse
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from pointdsc_amd import _lib, ops, synthetic  # noqa: E402
+
+NAMES = ["start", "partials merged+stored", "barrier", "fc1 done", "fc2 done", "fc3 done", "barrier", "pcn mma done", "pcn stored",
+         "featB written", "qkv0 mma done", "qkv0 staged", "qkv0 streams written", "end"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=5000)
+    ap.add_argument("--bs", type=int, default=4)
+    args = ap.parse_args()
+    lib = _lib.load()
+    n, bs, dev = args.n, args.bs, "cuda:0"
+    gen = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)  # noqa: E731
+    m = n * bs
+    batch = synthetic.make_batch(bs, n, seed=1)
+    compat = ops.spatial_compat(batch["src_keypts"].to(dev), batch["tgt_keypts"].to(dev), torch.tensor([0.1], device=dev))
+    qs, kv = ops.pack_qkv_split(rnd(m, 384) * 0.3, bs, n)
+    partials = ops.sc_attention_split(qs, kv, compat, bs, n, merge=False)
+    res = rnd(m, 128)
+    tail_w = [rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128)]
+    head_w = [rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384)]
+    run = lambda: ops.layer_fused_split(None, res, None, tail_w, head_w, bs, n, partials=partials, qkv_split=True)  # noqa: E731
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"layer_fused (merge of {partials[1]} splits + tail + head, split qkv): {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per call (incl. weight split + allocs)")
+    nwg = ((n + 31) // 32) * bs
+    trace = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device=dev)
+    _lib.check(lib.pdsc_layer_trace(C.c_void_p(trace.data_ptr())), "trace")
+    run()
+    torch.cuda.synchronize()
+    _lib.check(lib.pdsc_layer_trace(None), "trace off")
+    t = trace.cpu().reshape(nwg, 4, 16)[:, :, :14].double()
+    t0 = t[:, :, 0].min()
+    print(f"{nwg} workgroups; kernel span {float(t[:, :, 13].max() - t0):.0f} clocks; workgroup start spread {float(t[:, 0, 0].max() - t0):.0f}")
+    for w in (0, 3):
+        d = t[:, w, 1:] - t[:, w, :-1]
+        life = t[:, w, 13] - t[:, w, 0]
+        print(f"wave {w}: lifetime mean {float(life.mean()):.0f}  min {float(life.min()):.0f}  max {float(life.max()):.0f}")
+        for k in range(13):
+            print(f"   {NAMES[k]:26s} -> {NAMES[k + 1]:26s} mean {float(d[:, k].mean()):8.0f}  max {float(d[:, k].max()):8.0f}")
+
+
+if __name__ == "__main__":
+    main()
