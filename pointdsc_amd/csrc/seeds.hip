@@ -136,6 +136,7 @@ __device__ __forceinline__ unsigned int float_order_bits(float f) {
 }
 
 constexpr int KNN_THREADS = 256;
+constexpr int KNN_FAST_CAP = 1024;
 
 __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __restrict__ dist, long long ldd,
                                                                  int* __restrict__ knn_idx, int N, int S, int k,
@@ -149,10 +150,53 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __
     __shared__ int cand_n;
     const int s = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* row = dist + ((size_t)b * S + s) * ldd;
-    for (int j = t; j < N; j += KNN_THREADS) keys[j] = float_order_bits(row[j]);
-    if (t == 0) cand_n = 0;
-
     const int want = k + 1;
+    const unsigned long long idx_mask = (1ULL << idx_bits) - 1ULL;
+
+    // ---- fast path: a cheap upper bound on the (k+1)-th smallest composite, then an exact ranking of the few survivors.
+    // Every thread finds the minimum of its strided share; the (k+1)-th smallest of the 256 thread minima bounds the
+    // (k+1)-th smallest of the row from above (those k+1 minima are k+1 distinct elements), so only elements <= bound can
+    // belong to the answer -- typically ~2(k+1) of them.  Composites are unique (index in the low bits): no ties anywhere.
+    __shared__ unsigned long long tmin[KNN_THREADS];
+    __shared__ unsigned long long fcand[KNN_FAST_CAP];
+    __shared__ unsigned long long bound;
+    __shared__ int fcand_n;
+    unsigned long long mymin = ~0ULL;
+    for (int j = t; j < N; j += KNN_THREADS) {
+        const unsigned int kb = float_order_bits(row[j]);
+        keys[j] = kb;
+        const unsigned long long v = ((unsigned long long)kb << idx_bits) | (unsigned)j;
+        mymin = v < mymin ? v : mymin;
+    }
+    tmin[t] = mymin;
+    if (t == 0) { cand_n = 0; fcand_n = 0; }
+    __syncthreads();
+    if (N >= KNN_THREADS && want <= KNN_THREADS) {           // every thread owns at least one element
+        int r = 0;
+        for (int u = 0; u < KNN_THREADS; ++u) r += tmin[u] < mymin;
+        if (r == want - 1) bound = mymin;                     // exactly one thread: minima are distinct
+        __syncthreads();
+        const unsigned long long ub = bound;
+        for (int j = t; j < N; j += KNN_THREADS) {
+            const unsigned long long v = ((unsigned long long)keys[j] << idx_bits) | (unsigned)j;
+            if (v <= ub) {
+                const int slot = atomicAdd(&fcand_n, 1);
+                if (slot < KNN_FAST_CAP) fcand[slot] = v;
+            }
+        }
+        __syncthreads();
+        const int nc = fcand_n;
+        if (nc <= KNN_FAST_CAP) {                             // block-uniform
+            for (int c = t; c < nc; c += KNN_THREADS) {
+                const unsigned long long mine = fcand[c];
+                int rank = 0;
+                for (int u = 0; u < nc; ++u) rank += fcand[u] < mine;
+                if (rank >= 1 && rank < want) knn_idx[((size_t)b * S + s) * k + (rank - 1)] = (int)(mine & idx_mask);
+            }
+            return;
+        }
+    }
+    // ---- general path (tiny rows, or more than KNN_FAST_CAP survivors -- e.g. thousands of equal distances) -----------
     int remaining = want;
     unsigned long long prefix = 0;                  // digits fixed so far (the bits above `shift + 8`)
     const int top = (32 + idx_bits + 7) / 8 * 8;    // composite width rounded up to whole digits
@@ -272,7 +316,7 @@ extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist
     PDSC_REQUIRE(normed && seeds && dist_scratch && knn_idx, "pdsc_knn_seeds: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 1 && S > 0, "pdsc_knn_seeds: bs=%d N=%d S=%d", bs, N, S);
     PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K && k <= N - 1, "pdsc_knn_seeds: k=%d (N=%d, max %d)", k, N, PDSC_MAX_K);
-    PDSC_REQUIRE((size_t)N * 4 <= 150 * 1024, "pdsc_knn_seeds: N=%d exceeds the single-workgroup LDS row (38400)", N);
+    PDSC_REQUIRE((size_t)N * 4 <= 144 * 1024, "pdsc_knn_seeds: N=%d exceeds the single-workgroup LDS row (36864)", N);
     hipStream_t st = (hipStream_t)stream;
     const long long ldd = pdsc_compat_ld(N);
     int rc = pdsc::knn_dist_rows(normed, seeds, dist_scratch, ldd, bs, N, S, st);
@@ -283,7 +327,7 @@ extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::knn_select_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   // + ~12 KiB static <= 160 KiB
         attr_done = true;
     }
     hipLaunchKernelGGL(pdsc::knn_select_kernel, dim3(S, bs), dim3(pdsc::KNN_THREADS), lds_bytes, st, dist_scratch, ldd,
