@@ -121,19 +121,21 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const int kt0 = sp * per + min(sp, rem);
     const int kt1 = kt0 + per + (sp < rem ? 1 : 0);
 
-    // buffer descriptors of this pair's K/V tile stream and compat matrix (both < 4 GiB per pair)
+    // buffer descriptor of this pair's K/V tile stream (< 4 GiB)
     const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.kv + (size_t)b * a.num_tiles * SPL_TILE_BYTES), 0, a.num_tiles * SPL_TILE_BYTES, 0x00020000);
+    // compat: the descriptor covers only this workgroup's query rows, so every offset fits 32 bits whatever N is
+    const int q_first = qb * (NW * 32);
+    const int q_rows = min(NW * 32, N - q_first);
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.compat + (size_t)b * N * a.ld), 0, (int)((unsigned)N * (unsigned)a.ld * 4u), 0x00020000);
+        (void*)(a.compat + ((size_t)b * N + q_first) * a.ld), 0, (int)((unsigned)q_rows * (unsigned)a.ld * 4u), 0x00020000);
     const unsigned lane16 = lane * 16;
     unsigned coff[4];                            // byte offset of this lane's 16-B compat chunk per DMA piece, tile 0
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int row = wave * 32 + 8 * u + (lane >> 3);             // row inside the workgroup's query block
         const int c = (lane & 7) ^ ((row >> 1) & 7);                 // logical 16-B chunk (4 keys) this lane fetches
-        const int q = min(qb * (NW * 32) + row, N - 1);
-        coff[u] = (unsigned)q * (unsigned)a.ld * 4u + 16u * c;
+        coff[u] = (unsigned)min(row, q_rows - 1) * (unsigned)a.ld * 4u + 16u * c;
     }
     // DMA work of one wave for one loop iteration kt, as 9 slots that are issued BETWEEN the MFMA groups (an LDS-DMA
     // instruction costs its wave ~100 cycles of issue; bunched after the barrier that is ~1000 cycles per tile during
