@@ -150,15 +150,132 @@ static int launch_linear(const LinearArgs& a, int batches, hipStream_t st) {
     return check_launch("pdsc_linear");
 }
 
+// ---- row-block x all-columns Gram of L2-normalised features: the S x N distance rows of the seeds' kNN
+//      (MODE 1: 2 - 2 <x_s, x_j>, models/common.py:58-60) and the N x N feature similarity matrix of the validation
+//      forward (MODE 2: clamp(1 - (1 - <x_i, x_j>) / sigma^2, 0, 1), zero diagonal, models/PointDSC.py:158-163).
+// A workgroup keeps 128 rows (32 per wave, gathered through `row_idx` in MODE 1) in registers as MFMA A fragments for its
+// whole life and streams a range of 64-column tiles through a double-buffered LDS stage: the row operand is read once,
+// the column operand once per row block (the generic linear_kernel re-reads both per 64 x 128 output tile and fits one
+// workgroup per CU).  Accumulator lane = column, so each of the 16 stores of a tile writes 128 contiguous bytes per half
+// wave.  Exact fp32 MFMA; bound: MFMA (256 flop per output element) with the 4-byte output stream behind it.
+constexpr int GR_ROWS = 128, GR_COLS = 64, GR_LD = PDSC_CHANNELS + 4;
+
+struct GramArgs {
+    const float* X;          // [bs][N][128]
+    const int* row_idx;      // MODE 1: [bs][R] rows of X; MODE 2: NULL (rows = 0..N-1)
+    const float* sigma;      // MODE 2
+    float* Y; long long ldy;
+    int R, N, tiles_per_split;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gram_rows_kernel(GramArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x [GR_COLS][GR_LD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const float* X = a.X + (size_t)b * a.N * PDSC_CHANNELS;
+    const int r0 = blockIdx.y * GR_ROWS + wave * 32;
+    const int num_tiles = ceil_div_dev(a.N, GR_COLS);
+    const int t0 = blockIdx.x * a.tiles_per_split, t1 = min(num_tiles, t0 + a.tiles_per_split);
+    if (t0 >= t1) return;
+
+    // A fragments of this lane's row: k-slot (4q+e, half h) <-> channel 8q+4h+e
+    f32x4 af[16];
+    {
+        int row = min(r0 + l31, a.R - 1);
+        if (MODE == 1) row = a.row_idx[(size_t)b * a.R + row];
+        const float* p = X + (size_t)row * PDSC_CHANNELS + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+    }
+    float sig2 = 1.f;
+    if (MODE == 2) { const float sg = a.sigma[0]; sig2 = sg * sg; }
+
+    // stage loader: thread -> 8 float4 of a 64 x 128 tile
+    f32x4 stage[8];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = t + 256 * i, r = f >> 5, c4 = (f & 31) * 4;
+            const int col = min(tile * GR_COLS + r, a.N - 1);
+            stage[i] = *reinterpret_cast<const f32x4*>(X + (size_t)col * PDSC_CHANNELS + c4);
+        }
+    };
+    auto store_tile = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = t + 256 * i, r = f >> 5, c4 = (f & 31) * 4;
+            *reinterpret_cast<f32x4*>(buf + r * GR_LD + c4) = stage[i];
+        }
+    };
+    load_tile(t0);
+    store_tile(lds);
+    __syncthreads();
+    float* Yb = a.Y + (size_t)b * a.R * a.ldy;
+    for (int tile = t0; tile < t1; ++tile) {
+        const float* cur = lds + ((tile - t0) & 1) * GR_COLS * GR_LD;
+        if (tile + 1 < t1) load_tile(tile + 1);                     // in flight under the MFMAs
+#pragma unroll
+        for (int sub = 0; sub < GR_COLS / 32; ++sub) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* brow = cur + (32 * sub + l31) * GR_LD + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][e], bf[e], acc, 0, 0, 0);
+            }
+            const int col = tile * GR_COLS + 32 * sub + l31;
+            if (col < a.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < a.R) {
+                        float v;
+                        if (MODE == 1) v = 2.0f - 2.0f * acc[r];      // == reference `2 - 2*matmul` (one rounding)
+                        else {
+                            v = fminf(fmaxf(1.0f - (1.0f - acc[r]) / sig2, 0.0f), 1.0f);
+                            if (row == col) v = 0.0f;
+                        }
+                        Yb[(size_t)row * a.ldy + col] = v;
+                    }
+                }
+            }
+        }
+        if (tile + 1 < t1) {
+            store_tile(lds + ((tile + 1 - t0) & 1) * GR_COLS * GR_LD);   // the other buffer: its readers finished a barrier ago
+            __syncthreads();
+        }
+    }
+}
+
+template <int MODE>
+static int launch_gram(GramArgs a, int bs, hipStream_t st) {
+    const size_t lds_bytes = 2 * (size_t)GR_COLS * GR_LD * sizeof(float);     // 67 584 B
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_rows_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes);
+        attr_done = true;
+    }
+    const int row_blocks = ceil_div(a.R, GR_ROWS), tiles = ceil_div(a.N, GR_COLS);
+    int splits = ceil_div(768, row_blocks * bs);                   // ~3 workgroups per CU in flight
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    a.tiles_per_split = ceil_div(tiles, splits);
+    splits = ceil_div(tiles, a.tiles_per_split);
+    hipLaunchKernelGGL((gram_rows_kernel<MODE>), dim3(splits, row_blocks, bs), dim3(256), lds_bytes, st, a);
+    return check_launch("gram_rows_kernel");
+}
+
 int knn_dist_rows(const float* normed, const int* seeds, float* dist, long long ldd, int bs, int N, int S,
                   hipStream_t st) {
-    LinearArgs a{};
-    a.X = normed; a.ldx = PDSC_CHANNELS; a.x_batch = (long long)N * PDSC_CHANNELS;
-    a.row_idx = seeds; a.idx_batch = S;
-    a.W = normed; a.w_batch = (long long)N * PDSC_CHANNELS;
-    a.Y = dist; a.ldy = ldd; a.y_batch = (long long)S * ldd;
-    a.M = S; a.K = PDSC_CHANNELS; a.Nout = N; a.relu = 0;
-    return launch_linear<2, 1>(a, bs, st);
+    GramArgs a{};
+    a.X = normed; a.row_idx = seeds; a.Y = dist; a.ldy = ldd; a.R = S; a.N = N;
+    return launch_gram<1>(a, bs, st);
 }
 
 }  // namespace pdsc
@@ -167,12 +284,9 @@ extern "C" int pdsc_feature_compat(const float* normed, const float* sigma, floa
                                    void* stream) {
     PDSC_REQUIRE(normed && sigma && Mout, "pdsc_feature_compat: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && ld >= N, "pdsc_feature_compat: bs=%d N=%d ld=%lld", bs, N, ld);
-    pdsc::LinearArgs a{};
-    a.X = normed; a.ldx = PDSC_CHANNELS; a.x_batch = (long long)N * PDSC_CHANNELS;
-    a.W = normed; a.w_batch = (long long)N * PDSC_CHANNELS;
-    a.Y = Mout; a.ldy = ld; a.y_batch = (long long)N * ld;
-    a.M = N; a.K = PDSC_CHANNELS; a.Nout = N; a.relu = 0; a.sigma = sigma;
-    return pdsc::launch_linear<2, 2>(a, bs, (hipStream_t)stream);
+    pdsc::GramArgs a{};
+    a.X = normed; a.sigma = sigma; a.Y = Mout; a.ldy = ld; a.R = N; a.N = N;
+    return pdsc::launch_gram<2>(a, bs, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_linear(const float* X, long long ldx, const float* W, const float* bias, const float* residual,

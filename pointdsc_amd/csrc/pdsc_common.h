@@ -27,6 +27,7 @@ void profile_mark_end(int kind, hipStream_t st);
 
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers ----------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
