@@ -44,50 +44,56 @@ __global__ __launch_bounds__(64 * SP_WAVES) void seed_power_kernel(const float* 
     }
     __syncthreads();
 
-    float own[PDSC_CHANNELS];
-    {
-        const float* fr = Fs + (valid ? lane : 0) * FS_LD;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(fr + c * 4);
-            own[4 * c] = v[0]; own[4 * c + 1] = v[1]; own[4 * c + 2] = v[2]; own[4 * c + 3] = v[3];
-        }
-    }
     const float sg = sigma[0], sig2 = sg * sg;
     const float sd = sigma_spat[0], sd2 = sd * sd;
-    const int me = valid ? lane : 0;
-    const float ax = pts[me][0], ay = pts[me][1], az = pts[me][2];
-    const float bx = pts[me][4], by = pts[me][5], bz = pts[me][6];
-    for (int j = wave; j < k; j += SP_WAVES) {       // columns dealt round-robin to the waves
-        const float* fj = Fs + j * FS_LD;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // k x k feature Gram on the exact fp32 MFMA: wave w owns the 32 x 32 tile (rows 32(w>>1).., columns 32(w&1)..) of the
+    // k <= 64 neighbours; rows >= k of Fs are never written, their products land in rows / columns >= k that are skipped.
+    // Accumulator lane = column j, register r = row i: the spatial term is evaluated in the same layout (the points of
+    // row i are LDS broadcasts) and the finished M goes to LDS row-major for the power iteration.
+    {
+        const int rb = wave >> 1, cb = wave & 1;
+        const int jcol = 32 * cb + (lane & 31), hh = lane >> 5;
+        if (32 * rb < k && 32 * cb < k) {              // wave-uniform: tiles entirely beyond k have nothing to do
+            const float* arow = Fs + min(32 * rb + (lane & 31), k - 1) * FS_LD + 4 * hh;
+            const float* brow = Fs + min(jcol, k - 1) * FS_LD + 4 * hh;
+            f32x16 acc;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const f32x4 f = *reinterpret_cast<const f32x4*>(fj + c * 4);   // same address in every lane: broadcast
-            a0 = fmaf(own[4 * c], f[0], a0);
-            a1 = fmaf(own[4 * c + 1], f[1], a1);
-            a2 = fmaf(own[4 * c + 2], f[2], a2);
-            a3 = fmaf(own[4 * c + 3], f[3], a3);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+            }
+            const int jc = min(jcol, k - 1);
+            const float jx = pts[jc][0], jy = pts[jc][1], jz = pts[jc][2];
+            const float kx = pts[jc][4], ky = pts[jc][5], kz = pts[jc][6];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (i < k && jcol < k) {
+                    const float fm = fmaxf(1.0f - (1.0f - acc[r]) / sig2, 0.0f);
+                    const float dx = pts[i][0] - jx, dy = pts[i][1] - jy, dz = pts[i][2] - jz;
+                    const float ex = pts[i][4] - kx, ey = pts[i][5] - ky, ez = pts[i][6] - kz;
+                    const float ds = sqrtf((dx * dx + dy * dy) + dz * dz);          // ((a-b)**2).sum(-1) ** 0.5
+                    const float dt = sqrtf((ex * ex + ey * ey) + ez * ez);
+                    const float df = ds - dt;
+                    const float sm = fmaxf(1.0f - (df * df) / sd2, 0.0f);
+                    const float m = (i == jcol) ? 0.0f : fm * sm;
+                    Ms[i * MS_LD + jcol] = m;
+                    if (seed_M) seed_M[(((size_t)b * S + s) * k + i) * k + jcol] = m;
+                }
+            }
         }
-        const float dot = (a0 + a1) + (a2 + a3);
-        const float fm = fmaxf(1.0f - (1.0f - dot) / sig2, 0.0f);
-        const float dx = ax - pts[j][0], dy = ay - pts[j][1], dz = az - pts[j][2];
-        const float ex = bx - pts[j][4], ey = by - pts[j][5], ez = bz - pts[j][6];
-        const float ds = sqrtf((dx * dx + dy * dy) + dz * dz);          // ((a-b)**2).sum(-1) ** 0.5
-        const float dt = sqrtf((ex * ex + ey * ey) + ez * ez);
-        const float df = ds - dt;
-        const float sm = fmaxf(1.0f - (df * df) / sd2, 0.0f);
-        const float m = (j == lane) ? 0.0f : fm * sm;
-        Ms[lane * MS_LD + j] = m;
-        if (seed_M && valid) seed_M[(((size_t)b * S + s) * k + lane) * k + j] = m;
     }
+    __syncthreads();                                 // Ms complete
+    if (wave != 0) return;                           // the power iteration is one wave's work
     // power iteration: v <- M v / (||M v|| + 1e-6), every iterate kept, allclose flag per iteration
-    // (tiny: every wave runs it redundantly on identical values, wave 0 publishes)
     float v = valid ? 1.0f : 0.0f;
     float last = v;
     unsigned int bits = 0;
     float* out = eig_iters + ((size_t)b * S + s) * num_iter * PDSC_MAX_K;
-    __syncthreads();                                 // Ms complete
     float mrow[PDSC_MAX_K];                          // this lane's row of M, in registers for all iterations
     {
         const float* mr = Ms + lane * MS_LD;
@@ -103,12 +109,12 @@ __global__ __launch_bounds__(64 * SP_WAVES) void seed_power_kernel(const float* 
         nv = valid ? nv : 0.f;
         const float nrm = sqrtf(wave_sum(nv * nv));
         v = nv / (nrm + 1e-6f);
-        if (wave == 0) out[it * PDSC_MAX_K + lane] = v;
+        out[it * PDSC_MAX_K + lane] = v;
         const bool close = fabsf(v - last) <= (1e-8f + 1e-5f * fabsf(last));   // torch.allclose(v, last)
         if (__all(close || !valid)) bits |= (1u << it);
         last = v;
     }
-    if (threadIdx.x == 0) atomicAnd(conv_mask + b, bits);
+    if (lane == 0) atomicAnd(conv_mask + b, bits);
 }
 
 // chosen iterate = first iteration at which EVERY seed of the pair passed allclose (the reference breaks
