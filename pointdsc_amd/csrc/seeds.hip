@@ -7,6 +7,7 @@
 // Ordering rules (ties): equal NMS keys -> ascending index; equal kNN distances -> ascending index
 // (DESIGN.md "tie semantics"; torch.argsort / torch.topk leave both unspecified).
 #include <math.h>
+#include <stdlib.h>
 #include "pdsc_common.h"
 
 namespace pdsc {
@@ -37,67 +38,41 @@ __global__ __launch_bounds__(256) void normalize_conf_kernel(const float* __rest
 // `radius2` = the smallest fp32 x with sqrt_rn(x) >= radius (computed on the host): since the correctly rounded square
 // root is monotone, `sqrt(x) >= radius` and `x >= radius2` are the same predicate bit for bit -- without the ~20
 // instructions of an IEEE sqrt per pair.
-__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ src, const float* __restrict__ conf,
-                                                       float radius2, float* __restrict__ keys, int N) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    if (i >= N) return;
+// Row-per-lane formulation: a thread owns TWO rows (i, i + 256), the columns of the
+// workgroup's slice come as LDS broadcasts, so a pair evaluation is 3 packed subtracts, 1 packed multiply, 2 packed fmas
+// and two compares -- no cross-lane traffic, no per-element bounds checks.  The column range is split over workgroups
+// (blockIdx.y); keys start as a copy of conf and a slice that suppresses row i stores conf[i] * 0 (every writer stores the
+// same value, so the plain stores need no ordering).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int NMS2_ROWS = 512;           // rows per workgroup (2 per thread)
+constexpr int NMS2_MAX_SLICE = 2048;     // columns per workgroup slice (32 KiB of LDS)
+
+__global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ src, const float* __restrict__ conf,
+                                                        float radius2, float* __restrict__ keys, int N, int slice) {
+    __shared__ __attribute__((aligned(16))) float4 rec[NMS2_MAX_SLICE];
+    const int t = threadIdx.x, b = blockIdx.z;
     const float* s = src + (size_t)b * N * 3;
     const float* c = conf + (size_t)b * N;
-    const float ci = c[i];
-    const float xi = s[i * 3], yi = s[i * 3 + 1], zi = s[i * 3 + 2];
-    bool ok = true;
-    for (int j0 = 0; j0 < N; j0 += 256) {               // 4 independent chunks per early-exit test
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 64 * u + lane;
-            const int jc = min(j, N - 1);
-            const float dx = xi - s[jc * 3], dy = yi - s[jc * 3 + 1], dz = zi - s[jc * 3 + 2];
-            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));            // norm3's radicand, same rounding
-            ok = ok && ((j >= N) || (ci >= c[jc]) || (d2 >= radius2));
-        }
-        if (__any(!ok)) break;
-    }
-    const bool is_max = !__any(!ok);
-    if (lane == 0) keys[(size_t)b * N + i] = ci * (is_max ? 1.0f : 0.0f);   // -0.0 for suppressed negatives, like torch
-}
-
-// Same predicate with the pair's (x, y, z, conf) records staged once per workgroup in LDS (16 B per correspondence):
-// a workgroup owns NMS_ROWS_PER_WG rows, each wave walks its rows with the lanes striding the columns
-// (one conflict-free ds_read_b128 per pair instead of four cached global loads).  N <= NMS_LDS_MAX_N.
-constexpr int NMS_ROWS_PER_WG = 32;
-constexpr int NMS_LDS_MAX_N = 10000;                 // 160 000 B of the 160 KiB LDS
-
-__global__ __launch_bounds__(256) void nms_keys_lds_kernel(const float* __restrict__ src, const float* __restrict__ conf,
-                                                           float radius2, float* __restrict__ keys, int N) {
-    extern __shared__ __attribute__((aligned(16))) float4 rec[];      // [N] x, y, z, conf
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = blockIdx.y;
-    const float* s = src + (size_t)b * N * 3;
-    const float* c = conf + (size_t)b * N;
-    for (int j = t; j < N; j += 256) rec[j] = make_float4(s[j * 3], s[j * 3 + 1], s[j * 3 + 2], c[j]);
+    const int j_begin = blockIdx.y * slice, j_end = min(N, j_begin + slice);
+    for (int j = j_begin + t; j < j_end; j += 256) rec[j - j_begin] = make_float4(s[j * 3], s[j * 3 + 1], s[j * 3 + 2], c[j]);
     __syncthreads();
-    const int row0 = blockIdx.x * NMS_ROWS_PER_WG;
-    for (int r = wave; r < NMS_ROWS_PER_WG; r += 4) {
-        const int i = row0 + r;
-        if (i >= N) break;                              // wave-uniform
-        const float4 me = rec[i];
-        bool ok = true;
-        for (int j0 = 0; j0 < N; j0 += 256) {           // 4 independent chunks per early-exit test
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + 64 * u + lane;
-                const float4 o = rec[min(j, N - 1)];
-                const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));        // norm3's radicand, same rounding
-                ok = ok && ((j >= N) || (me.w >= o.w) || (d2 >= radius2));
-            }
-            if (__any(!ok)) break;
-        }
-        const bool is_max = !__any(!ok);
-        if (lane == 0) keys[(size_t)b * N + i] = me.w * (is_max ? 1.0f : 0.0f);   // -0.0 for suppressed negatives, like torch
+    const int i0 = blockIdx.x * NMS2_ROWS + t, i1 = i0 + 256;
+    const int r0 = min(i0, N - 1), r1 = min(i1, N - 1);
+    const f32x2 mx = {s[r0 * 3], s[r1 * 3]}, my = {s[r0 * 3 + 1], s[r1 * 3 + 1]}, mz = {s[r0 * 3 + 2], s[r1 * 3 + 2]};
+    const float c0 = c[r0], c1 = c[r1];
+    bool ok0 = true, ok1 = true;
+    const int n = j_end - j_begin;
+    for (int j = 0; j < n; ++j) {
+        if ((j & 63) == 0 && !__any(ok0 || ok1)) break;          // every row of the wave is already suppressed
+        const float4 o = rec[j];                       // same address in every lane: LDS broadcast
+        const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const f32x2 dx = mx - ox, dy = my - oy, dz = mz - oz;
+        const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));   // norm3's radicand
+        ok0 = ok0 && ((c0 >= o.w) || (d2[0] >= radius2));
+        ok1 = ok1 && ((c1 >= o.w) || (d2[1] >= radius2));
     }
+    if (!ok0 && i0 < N) keys[(size_t)b * N + i0] = c0 * 0.0f;       // -0.0 for suppressed negatives, like torch
+    if (!ok1 && i1 < N) keys[(size_t)b * N + i1] = c1 * 0.0f;
 }
 
 // ---- stable descending rank by counting; seeds[rank] = index for rank < num_seeds -------------------
@@ -287,19 +262,20 @@ extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, 
     } else if (radius != radius) {
         radius2 = radius;                                                    // NaN radius: every comparison is false
     }
-    if (N <= pdsc::NMS_LDS_MAX_N) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::nms_keys_lds_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, pdsc::NMS_LDS_MAX_N * 16);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(pdsc::nms_keys_lds_kernel, dim3(pdsc::ceil_div(N, pdsc::NMS_ROWS_PER_WG), bs), dim3(256),
-                           (size_t)N * 16, (hipStream_t)stream, src, conf, radius2, keys, N);
-    } else
-    hipLaunchKernelGGL(pdsc::nms_keys_kernel, dim3(pdsc::ceil_div(N, 4), bs), dim3(256), 0, (hipStream_t)stream, src, conf,
-                       radius2, keys, N);
-    return pdsc::check_launch("pdsc_nms_keys");
+    {
+        hipStream_t st = (hipStream_t)stream;
+        if (hipMemcpyAsync(keys, conf, (size_t)bs * N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return pdsc::check_launch("pdsc_nms_keys(copy)");
+        const int row_blocks = pdsc::ceil_div(N, pdsc::NMS2_ROWS);
+        int splits = pdsc::ceil_div(1024, row_blocks * bs);             // ~1024 workgroups
+        const int min_splits = pdsc::ceil_div(N, pdsc::NMS2_MAX_SLICE);
+        if (splits < min_splits) splits = min_splits;
+        if (splits > N) splits = N;
+        const int slice = pdsc::ceil_div(N, splits);
+        splits = pdsc::ceil_div(N, slice);
+        hipLaunchKernelGGL(pdsc::nms_flags_kernel, dim3(row_blocks, splits, bs), dim3(256), 0, st, src, conf, radius2, keys, N, slice);
+        return pdsc::check_launch("pdsc_nms_keys");
+    }
 }
 
 extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream) {
