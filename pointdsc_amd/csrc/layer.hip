@@ -9,6 +9,7 @@
 // MFMA orientation: D = W_tile (A, rows = output channels) x X^T (B, columns = points), so the accumulator
 // lane is a point and register r = 4g+e holds output channel n0+8g+4h+e: one float4 per (g) goes to LDS / HBM.
 // Bound: MFMA (172 kFLOP per point per layer on v_mfma_f32_32x32x2_f32); weights stream from L2 (336 KB per tile).
+#include <type_traits>
 #include "pdsc_common.h"
 #include "split_layout.h"
 #include "merge_partials.h"
@@ -167,18 +168,28 @@ __device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs
         global_to_tile(a.msg, Xs, m0, M, t);
         return;
     }
-    MergeLoads L[4];
+    // split count as a compile-time constant (wave-uniform switch): registers for exactly that many partials
+    auto run = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        MergeLoads<NS> L[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
-        const int m = min(m0 + row, M - 1);
-        const size_t slot0 = (size_t)b * a.nsplit * a.Npad + (size_t)(m - b * a.N);
-        merge_partials_load(L[i], a.part_o, a.part_ml, slot0, (size_t)a.Npad, a.nsplit, c4);
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+            const int m = min(m0 + row, M - 1);
+            const size_t slot0 = (size_t)b * NS * a.Npad + (size_t)(m - b * a.N);
+            merge_partials_load<NS>(L[i], a.part_o, a.part_ml, slot0, (size_t)a.Npad, c4);
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
-        *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_finish(L[i], a.nsplit);
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+            *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_finish<NS>(L[i]);
+        }
+    };
+    switch (a.nsplit) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        default: run(std::integral_constant<int, 4>{}); break;
     }
 }
 

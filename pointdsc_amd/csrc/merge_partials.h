@@ -42,37 +42,39 @@ __device__ __forceinline__ f32x4 merge_partials_chunk(const float* __restrict__ 
 
 
 // Two-phase form for callers that merge several chunks per thread: issue the loads of ALL chunks first (one round trip
-// of latency instead of one per chunk), then do the arithmetic.
+// of latency instead of one per chunk), then do the arithmetic.  NS = compile-time split count (registers for exactly
+// NS splits, no duplicate loads).
+template <int NS>
 struct MergeLoads {
-    float mx[MERGE_MAX_SPLIT], ls[MERGE_MAX_SPLIT];
-    f32x4 pv[MERGE_MAX_SPLIT];
+    float mx[NS], ls[NS];
+    f32x4 pv[NS];
 };
 
-__device__ __forceinline__ void merge_partials_load(MergeLoads& L, const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                    size_t slot0, size_t sp_stride, int ns, int c4) {
+template <int NS>
+__device__ __forceinline__ void merge_partials_load(MergeLoads<NS>& L, const float* __restrict__ part_o,
+                                                    const float* __restrict__ part_ml, size_t slot0, size_t sp_stride, int c4) {
 #pragma unroll
-    for (int sp = 0; sp < MERGE_MAX_SPLIT; ++sp) {
-        const size_t slot = slot0 + (size_t)min(sp, ns - 1) * sp_stride;
+    for (int sp = 0; sp < NS; ++sp) {
+        const size_t slot = slot0 + (size_t)sp * sp_stride;
         const float2 ml = *reinterpret_cast<const float2*>(part_ml + slot * 2);
         L.mx[sp] = ml.x; L.ls[sp] = ml.y;
         L.pv[sp] = *reinterpret_cast<const f32x4*>(part_o + slot * PDSC_CHANNELS + c4);
     }
 }
 
-__device__ __forceinline__ f32x4 merge_partials_finish(const MergeLoads& L, int ns) {
+template <int NS>
+__device__ __forceinline__ f32x4 merge_partials_finish(const MergeLoads<NS>& L) {
     float mmax = L.mx[0];
 #pragma unroll
-    for (int sp = 1; sp < MERGE_MAX_SPLIT; ++sp) mmax = fmaxf(mmax, L.mx[sp]);
+    for (int sp = 1; sp < NS; ++sp) mmax = fmaxf(mmax, L.mx[sp]);
     float den = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int sp = 0; sp < MERGE_MAX_SPLIT; ++sp) {
-        if (sp < ns) {
-            const float w = __builtin_amdgcn_exp2f(L.mx[sp] - mmax);
-            den = fmaf(L.ls[sp], w, den);
+    for (int sp = 0; sp < NS; ++sp) {
+        const float w = __builtin_amdgcn_exp2f(L.mx[sp] - mmax);
+        den = fmaf(L.ls[sp], w, den);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(L.pv[sp][e], w, acc[e]);
-        }
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(L.pv[sp][e], w, acc[e]);
     }
     f32x4 v;
 #pragma unroll
