@@ -62,14 +62,17 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
     const float c0 = c[r0], c1 = c[r1];
     bool ok0 = true, ok1 = true;
     const int n = j_end - j_begin;
-    for (int j = 0; j < n; ++j) {
-        if ((j & 63) == 0 && !__any(ok0 || ok1)) break;          // every row of the wave is already suppressed
-        const float4 o = rec[j];                       // same address in every lane: LDS broadcast
-        const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-        const f32x2 dx = mx - ox, dy = my - oy, dz = mz - oz;
-        const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));   // norm3's radicand
-        ok0 = ok0 && ((c0 >= o.w) || (d2[0] >= radius2));
-        ok1 = ok1 && ((c1 >= o.w) || (d2[1] >= radius2));
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        if (!__any(ok0 || ok1)) break;                  // every row of the wave is already suppressed
+        const int jn = min(64, n - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            const float4 o = rec[j0 + jj];              // same address in every lane: LDS broadcast
+            const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+            const f32x2 dx = mx - ox, dy = my - oy, dz = mz - oz;
+            const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));   // norm3's radicand
+            ok0 = ok0 && ((c0 >= o.w) || (d2[0] >= radius2));
+            ok1 = ok1 && ((c1 >= o.w) || (d2[1] >= radius2));
+        }
     }
     if (!ok0 && i0 < N) keys[(size_t)b * N + i0] = c0 * 0.0f;       // -0.0 for suppressed negatives, like torch
     if (!ok1 && i1 < N) keys[(size_t)b * N + i1] = c1 * 0.0f;
