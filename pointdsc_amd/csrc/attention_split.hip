@@ -35,7 +35,6 @@ struct AttSplitArgs {
     float* part_ml;              // [bs][nsplit][Npad][2]
     int N, Npad, nsplit, num_tiles, nq, bs;
     long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
-    int prio;                    // tuning knob: 1 = s_setprio 1 for the second half of the waves
 };
 
 // LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, descriptor + scalar offset + one 32-bit lane
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         for (int r = 0; r < 16; ++r) tl[r] -= m_run;
     }
 
-    if (a.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     PDSC_TRACE_STAMP(1)                          // 1: first tile (wait + QK + logits)
     for (int kt = kt0; kt < kt1; ++kt) {
         const int st = (kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
@@ -508,9 +506,6 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("PDSC_ATT_PRIO"); prio = e ? atoi(e) : 0; }
-    a.prio = prio;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 4096);   // 2 stages x (K 17 KiB + V 20 KiB + compat nw*4 KiB)
     static bool attr_set = false;

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=5000)
     ap.add_argument("--bs", type=int, default=4)
+    ap.add_argument("--zeros", action="store_true", help="all-zero q/k/v: same instruction stream, minimal data toggling (DVFS probe)")
     args = ap.parse_args()
     lib = _lib.load()
     n, bs = args.n, args.bs
@@ -28,7 +29,7 @@ def main():
     batch = synthetic.make_batch(bs, n, seed=1)
     compat = ops.spatial_compat(batch["src_keypts"].to(dev), batch["tgt_keypts"].to(dev), torch.tensor([0.1], device=dev))
     gen = torch.Generator().manual_seed(0)
-    qkv = (torch.randn(bs * n, 384, generator=gen) * 0.3).to(dev)
+    qkv = (torch.randn(bs * n, 384, generator=gen) * (0.0 if args.zeros else 0.3)).to(dev)
     qs, kv = ops.pack_qkv_split(qkv, bs, n)
     for _ in range(3):
         ops.sc_attention_split(qs, kv, compat, bs, n)
