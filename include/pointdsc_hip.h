@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 2
+#define PDSC_VERSION 3
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32
@@ -175,6 +175,26 @@ int pdsc_layer_fused_x3(const float* msg, const float* part_o, const float* part
                         void* q_split, void* kv_tiles,
                         const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
                         const void* wp, const float* bp, const void* wq, const float* bq, int bs, int N, void* stream);
+
+/* The same chain (tail of layer i, head of layer i+1, q|k|v projection in split precision) with the weights supplied as
+ * MFMA-fragment-ordered streams: 8 KiB chunks in exactly the order the wavefront-resident kernel consumes them, so every
+ * weight load of a wave is 1 KiB of consecutive memory.  This is the entry pdsc_forward_* uses by default.
+ *   tail stream: pdsc_wfrag_tail_bytes() bytes from (fc1 [C/2][C], fc2 [C/2][C/2], fc3 [C][C/2]) fp32 and their biases;
+ *   head stream: pdsc_wfrag_head_bytes() bytes from (pcn [C][C] fp32 kept fp32, qkv [3C][C] fp32 -> bf16 hi / lo) and
+ *                their biases (the bias of an output tile is one more k-step of its GEMM: A = bias, B = 1).
+ * pdsc_wsplit_build also stores both per layer inside the split-weight buffer, at bf16 element
+ * pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_TAIL / PDSC_WS_FRAG_HEAD, layer). */
+#define PDSC_WS_FRAG_TAIL 100
+#define PDSC_WS_FRAG_HEAD 101
+size_t pdsc_wfrag_tail_bytes(void);
+size_t pdsc_wfrag_head_bytes(void);
+int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                          const float* b3, void* out, void* stream);
+int pdsc_wfrag_build_head(const float* wp, const float* bp, const float* wq, const float* bq, void* out, void* stream);
+int pdsc_layer_fused_frag(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                          const float* res, const float* feat_in, float* feat_out, float* featB_out, float* qkv_out,
+                          void* q_split, void* kv_tiles, const void* wfrag_tail, const void* wfrag_head, int bs, int N,
+                          void* stream);
 
 /* ---- a-3  spatial-consistency guided non-local attention ---------------------------------------
  * replaces models/PointDSC.py:39-42 (both einsums and the softmax; N x N scores never materialised).

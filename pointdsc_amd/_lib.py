@@ -57,6 +57,11 @@ SIGNATURES = {
     "pdsc_wsplit_offset": (_ll, [_cfgp, _i, _i]),
     "pdsc_wsplit_build": (_i, [_cfgp, _vp, _vp, _vp]),
     "pdsc_layer_fused_x3": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 17 + [_i, _i, _vp]),
+    "pdsc_wfrag_tail_bytes": (_sz, []),
+    "pdsc_wfrag_head_bytes": (_sz, []),
+    "pdsc_wfrag_build_tail": (_i, [_vp] * 8),
+    "pdsc_wfrag_build_head": (_i, [_vp] * 6),
+    "pdsc_layer_fused_frag": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 9 + [_i, _i, _vp]),
     "pdsc_split_q_bytes": (_sz, [_i, _i]),
     "pdsc_split_kv_bytes": (_sz, [_i, _i]),
     "pdsc_pack_qkv_split": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -117,7 +122,7 @@ def load() -> C.CDLL:
             raise PointDSCLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.pdsc_version() != 2:
+    if lib.pdsc_version() != 3:
         raise PointDSCLibraryError(f"unexpected library version {lib.pdsc_version()}")
     _lib = lib
     return lib

@@ -298,10 +298,20 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const bool fuse_merge = fuse_env && ns > 1 && ns <= 4;   // the layer kernels merge up to 4 splits while loading (merge_partials.h)
         const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;
         const float* part_ml = fuse_merge ? part_o + (size_t)bs * ns * Npad * C : nullptr;
+        static int frag_env = -1;
+        if (frag_env < 0) {
+            const char* env = getenv("PDSC_LAYER_FRAG");          // tuning/A-B knob: 0 = natural-layout weights (pdsc_layer_fused_split)
+            const char* var = getenv("PDSC_LAYER_VARIANT");
+            frag_env = (env ? atoi(env) : 1) && !(var && var[0] == 'b');
+        }
+        const bool frag = frag_env && !x3_gemm;                   // default: wavefront-resident layer kernel on fragment streams
         if (x3_gemm)
             PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
                                          WS(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
+        else if (frag)
+            PDSC_TRY(pdsc_layer_fused_frag(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
+                                           nullptr, WS(PDSC_WS_FRAG_HEAD, 0), bs, N, stream));
         else
             PDSC_TRY(pdsc_layer_fused_split(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
@@ -319,6 +329,11 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                              last ? nullptr : WS(PDSC_W_PCN_W, i + 1), last ? nullptr : W(PDSC_W_PCN_B, i + 1),
                                              last ? nullptr : WS(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
                                              bs, N, stream));
+            else if (frag)
+                PDSC_TRY(pdsc_layer_fused_frag(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
+                                               last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,
+                                               last ? nullptr : kv_tiles, WS(PDSC_WS_FRAG_TAIL, i),
+                                               last ? nullptr : WS(PDSC_WS_FRAG_HEAD, i + 1), bs, N, stream));
             else
                 PDSC_TRY(pdsc_layer_fused_split(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
                                                 last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[c], w, acc[c]);
     }
-    f32x4 out = {acc[0] / L, acc[1] / L, acc[2] / L, acc[3] / L};
+    const float rL = 1.0f / L;             // as merge_partials.h
+    f32x4 out = {acc[0] * rL, acc[1] * rL, acc[2] * rL, acc[3] * rL};
     *reinterpret_cast<f32x4*>(a.msg + ((size_t)b * a.N + query) * ATT_C + c4) = out;
 }
 

@@ -9,10 +9,12 @@
 // MFMA orientation: D = W_tile (A, rows = output channels) x X^T (B, columns = points), so the accumulator
 // lane is a point and register r = 4g+e holds output channel n0+8g+4h+e: one float4 per (g) goes to LDS / HBM.
 // Bound: MFMA (172 kFLOP per point per layer on v_mfma_f32_32x32x2_f32); weights stream from L2 (336 KB per tile).
+#include <stdlib.h>
 #include <type_traits>
 #include "pdsc_common.h"
 #include "split_layout.h"
 #include "merge_partials.h"
+#include "layer_args.h"
 
 namespace pdsc {
 
@@ -20,26 +22,6 @@ constexpr int LF_ROWS = 32;                  // points per workgroup
 constexpr int LF_LD = PDSC_CHANNELS + 4;     // padded LDS row (floats)
 constexpr int LF_TILE = LF_ROWS * LF_LD;
 
-struct LayerArgs {
-    const float* msg;        // [M][128]  attention output            (tail), or NULL when the partials below are given
-    const float* part_o;     // [bs][nsplit][Npad][128] un-normalised partial outputs of the attention key splits
-    const float* part_ml;    // [bs][nsplit][Npad][2]   (reference exponent (log2), partial sum)
-    int nsplit, Npad;
-    const float* res;        // [M][128]  featB of this layer         (tail residual)
-    const float* feat_in;    // [M][128]  used when there is no tail  (first head)
-    float* feat_out;         // [M][128]  tail result, written when non-null
-    float* featB_out;        // [M][128]  head
-    float* qkv_out;          // [M][384]  head
-    const float *w1, *b1, *w2, *b2, *w3, *b3;      // fc1 [64][128], fc2 [64][64], fc3 [128][64]
-    const float *wp, *bp, *wq, *bq;                // pcn [128][128], qkv [384][128]
-    const __bf16* wq_split;  // optional: qkv weights as bf16 hi [384][128] | lo [384][128] -> the q|k|v projection runs in
-                             // split precision (three bf16 MFMAs per operand pair); its error is of the order the attention's
-                             // operand split already has, and q, k, v never touch the residual stream
-    __bf16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
-    unsigned char* kv;       // head, optional: K/V tile stream  [bs][tiles][32 KiB]  (split_layout.h)
-    int N, bs;               // rows are bs pairs of N points; a workgroup's 32-point tile never straddles two pairs
-    long long* trace;        // diagnostics (pdsc_layer_trace): [workgroup][wave][16] shader-clock stamps, else NULL
-};
 
 #define LF_STAMP(k)                                                                                   \
     if (a.trace && lane == 0) a.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (k)] = __builtin_readcyclecounter();
@@ -382,6 +364,7 @@ static int launch_layer(const LayerArgs& a, hipStream_t st) {
 }  // namespace pdsc
 
 static long long* g_layer_trace = nullptr;
+long long* pdsc_layer_trace_buffer(void) { return g_layer_trace; }      // shared with layer_wave.hip
 extern "C" int pdsc_layer_trace(long long* device_buffer) {       // diagnostics: see include/pointdsc_hip.h
     g_layer_trace = device_buffer;
     return PDSC_OK;
@@ -405,8 +388,11 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
-                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, g_layer_trace};
+                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, g_layer_trace};
     hipStream_t st = (hipStream_t)stream;
+    // default: the wavefront-resident implementation (layer_wave.hip); PDSC_LAYER_VARIANT=block selects this file's
+    static const bool block_variant = [] { const char* e = getenv("PDSC_LAYER_VARIANT"); return e && e[0] == 'b'; }();
+    if (!block_variant) return pdsc::launch_layer_wave(a, tail, head, st);
     if (tail && head) return pdsc::launch_layer<true, true>(a, st);
     if (tail) return pdsc::launch_layer<true, false>(a, st);
     return pdsc::launch_layer<false, true>(a, st);

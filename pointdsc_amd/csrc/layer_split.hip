@@ -303,8 +303,14 @@ static long long wsplit_layer_elems() {
     return n;
 }
 
+// after the hi|lo matrices of all layers: the fragment-ordered streams of layer_wave.hip, per layer [tail][head]
+static long long wsplit_frag_layer_elems() { return (long long)(pdsc_wfrag_tail_bytes() + pdsc_wfrag_head_bytes()) / 2; }
+
 extern "C" long long pdsc_wsplit_offset(const pdsc_config* cfg, int section, int layer) {
     if (!cfg || layer < 0 || layer >= cfg->num_layers) return -1;
+    if (section == PDSC_WS_FRAG_TAIL || section == PDSC_WS_FRAG_HEAD)
+        return (long long)cfg->num_layers * wsplit_layer_elems() + (long long)layer * wsplit_frag_layer_elems() +
+               (section == PDSC_WS_FRAG_HEAD ? (long long)pdsc_wfrag_tail_bytes() / 2 : 0);
     long long off = (long long)layer * wsplit_layer_elems();
     for (int i = 0; i < 5; ++i) {
         if (kWsplitSection[i] == section) return off;
@@ -315,12 +321,12 @@ extern "C" long long pdsc_wsplit_offset(const pdsc_config* cfg, int section, int
 
 extern "C" size_t pdsc_wsplit_bytes(const pdsc_config* cfg) {
     if (!cfg || cfg->num_layers < 0) return 0;
-    return (size_t)cfg->num_layers * wsplit_layer_elems() * sizeof(__bf16);
+    return (size_t)cfg->num_layers * (wsplit_layer_elems() + wsplit_frag_layer_elems()) * sizeof(__bf16);
 }
 
 extern "C" int pdsc_wsplit_build(const pdsc_config* cfg, const float* wpack, void* wsplit, void* stream) {
     PDSC_REQUIRE(cfg && wpack && wsplit, "pdsc_wsplit_build: null pointer");
-    for (int layer = 0; layer < cfg->num_layers; ++layer)
+    for (int layer = 0; layer < cfg->num_layers; ++layer) {
         for (int i = 0; i < 5; ++i) {
             const long long src = pdsc_wpack_offset(cfg, kWsplitSection[i], layer), dst = pdsc_wsplit_offset(cfg, kWsplitSection[i], layer);
             PDSC_REQUIRE(src >= 0 && dst >= 0, "pdsc_wsplit_build: bad section");
@@ -328,6 +334,14 @@ extern "C" int pdsc_wsplit_build(const pdsc_config* cfg, const float* wpack, voi
             hipLaunchKernelGGL(wsplit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpack + src,
                                (__bf16*)wsplit + dst, n);
         }
+        auto W = [&](int section) { return wpack + pdsc_wpack_offset(cfg, section, layer); };
+        int rc = pdsc_wfrag_build_tail(W(PDSC_W_FC1_W), W(PDSC_W_FC1_B), W(PDSC_W_FC2_W), W(PDSC_W_FC2_B), W(PDSC_W_FC3_W), W(PDSC_W_FC3_B),
+                                       (__bf16*)wsplit + pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_TAIL, layer), stream);
+        if (rc != PDSC_OK) return rc;
+        rc = pdsc_wfrag_build_head(W(PDSC_W_PCN_W), W(PDSC_W_PCN_B), W(PDSC_W_QKV_W), W(PDSC_W_QKV_B),
+                                   (__bf16*)wsplit + pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_HEAD, layer), stream);
+        if (rc != PDSC_OK) return rc;
+    }
     return check_launch("pdsc_wsplit_build");
 }
 

@@ -1,0 +1,556 @@
+// a-2 fused, wavefront-resident: the whole point-wise chain between two attention calls for one 32-point tile runs in
+// ONE wavefront, with every activation in registers.
+//   tail of layer i   : feat  = featB + fc3( relu(fc2'( relu(fc1'(msg)) )) )         (reference models/PointDSC.py:43-45)
+//   head of layer i+1 : featB = relu(pcn'(feat)) ; (q|k|v) = Wqkv featB + b            (models/PointDSC.py:75, :36-38)
+// Why one wave per tile: with D = W_tile (A operand, rows = output channels) x X^T (B operand, columns = points) on
+// v_mfma_f32_32x32x2_f32 the accumulator register r = 4g+e of lane (point p, half h) holds output channel n0+8g+4h+e, and
+// the B operand of the NEXT GEMM wants, in k-step 4q+e, channel 8q+4h+e of point p in the same lane: the accumulator of
+// output tile n0 IS the next stage's operand for k-steps q = n0/8 .. n0/8+3.  So a wave that computes all output tiles
+// of a stage feeds the next stage without LDS, without barriers, and waves never wait for each other: a CU holds 8
+// independent chains (2 per SIMD) that hide each other's weight-fetch latency.  (layer.hip, the previous design, spreads
+// the tiles of a stage over 4 waves and pays 13 workgroup barriers per tile; it measured 3 x the MFMA time.)
+// Weights stream from L2 straight into registers in 32-register chunks (8 k-steps), one chunk ahead of the MFMAs.
+// The q|k|v projection runs in split precision (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16) when wq_split is
+// given; its 16-wide k-step takes channels 16kk+8h..+7 from lane-half h, i.e. two lanes' worth of the fp32 layout, which
+// one v_permlane32_swap per register pair rearranges.  The same swap turns the (4 channels per lane-half) accumulator
+// layout into the 16-byte (8 channels) chunks of the Q rows / K image (split_layout.h); only V^T needs a transpose
+// through a wave-private 4.5 KiB LDS patch.
+// Bound: MFMA, 46k matrix-pipe cycles per tile (fp32 stages 36.9k + split q|k|v 9.2k).
+#include <stdlib.h>
+#include <type_traits>
+#include "pdsc_common.h"
+#include "split_layout.h"
+#include "merge_partials.h"
+#include "layer_args.h"
+
+namespace pdsc {
+
+constexpr int LW_WAVES = 4;      // independent wavefronts per workgroup
+constexpr int LW_VLD = 36;       // floats per key row of the V transpose patch (32 channels + 4 pad)
+constexpr int LW_QKV_BUFS = 4;   // weight-chunk buffers (32 registers each) during the split q|k|v projection
+
+struct WChunk {
+    f32x4 v[8];      // 8 fp32 k-steps (q) of a weight tile, or 4 bf16 k-steps as (hi, lo) pairs
+    float bias;      // first chunk of a tile only: bias of output channel n0 + l31 in lane-half 0, zero in lane-half 1
+};
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+enum { ST_FC1 = 0, ST_FC2, ST_FC3, ST_PCN, ST_QKV };
+struct ChunkDesc { int stage, tile, chunk, nchunks; };
+
+template <bool T, bool H>
+constexpr int num_chunks() { return (T ? 10 : 0) + (H ? 32 : 0); }
+
+template <bool T>
+constexpr ChunkDesc chunk_desc(int i) {
+    if (T) {
+        if (i < 4) return {ST_FC1, i / 2, i % 2, 2};
+        i -= 4;
+        if (i < 2) return {ST_FC2, i, 0, 1};
+        i -= 2;
+        if (i < 4) return {ST_FC3, i, 0, 1};
+        i -= 4;
+    }
+    if (i < 8) return {ST_PCN, i / 2, i % 2, 2};
+    i -= 8;
+    return {ST_QKV, i / 2, i % 2, 2};
+}
+
+// ordinal of the output tile inside its stream (tail: fc1 0..1, fc2 2..3, fc3 4..7; head: pcn 0..3, q|k|v 4..15)
+constexpr int tile_ordinal(const ChunkDesc d) {
+    return d.stage == ST_FC1 ? d.tile : d.stage == ST_FC2 ? 2 + d.tile : d.stage == ST_FC3 ? 4 + d.tile : d.stage == ST_PCN ? d.tile : 4 + d.tile;
+}
+constexpr int LW_TAIL_CHUNKS = 10, LW_HEAD_CHUNKS = 32, LW_TAIL_TILES = 8, LW_HEAD_TILES = 16;
+
+__device__ __forceinline__ void load_rows_f32(WChunk& w, const float* __restrict__ p) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w.v[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+}
+
+constexpr int LW_CHUNK_BYTES = 8192;      // one WChunk for all 64 lanes
+
+// chunk `idx` of a fragment-ordered stream (pdsc_wfrag_build_*): slot s of lane l is the 16 bytes at s*1024 + l*16, i.e.
+// every load instruction of the wave reads 1 KiB of consecutive memory (8 cache lines).  The natural [out][in] layout
+// below makes the same instruction touch 64 different lines (row stride 256..512 B), which serialises in the L1.
+// The bias fragments (256 B per output tile) follow the chunks of the stream.
+__device__ __forceinline__ void load_chunk_frag(WChunk& w, const unsigned char* __restrict__ stream, int idx, int nchunks,
+                                                int bias_tile /* -1: not the first chunk of a tile */, int lane) {
+    const unsigned char* p = stream + (size_t)idx * LW_CHUNK_BYTES + lane * 16;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w.v[s] = *reinterpret_cast<const f32x4*>(p + 1024 * s);
+    if (bias_tile >= 0) w.bias = *reinterpret_cast<const float*>(stream + (size_t)nchunks * LW_CHUNK_BYTES + bias_tile * 256 + lane * 4);
+}
+
+template <bool T, bool X3, bool FRAG>
+__device__ __forceinline__ void load_chunk(WChunk& w, const LayerArgs& a, const int i, int lane) {
+    const ChunkDesc d = chunk_desc<T>(i);
+    const int bias_tile = d.chunk == 0 ? tile_ordinal(d) : -1;
+    if (FRAG) {
+        if (T && i < LW_TAIL_CHUNKS) load_chunk_frag(w, a.wf_tail, i, LW_TAIL_CHUNKS, bias_tile, lane);
+        else load_chunk_frag(w, a.wf_head, i - (T ? LW_TAIL_CHUNKS : 0), LW_HEAD_CHUNKS, bias_tile, lane);
+        return;
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = 32 * d.tile + l31;
+    if (d.chunk == 0) {
+        const float* b = d.stage == ST_FC1 ? a.b1 : d.stage == ST_FC2 ? a.b2 : d.stage == ST_FC3 ? a.b3 : d.stage == ST_PCN ? a.bp : a.bq;
+        const float bv = b[n];
+        w.bias = h ? 0.f : bv;
+    }
+    switch (d.stage) {
+        case ST_FC1: load_rows_f32(w, a.w1 + (size_t)n * 128 + 64 * d.chunk + 4 * h); break;
+        case ST_FC2: load_rows_f32(w, a.w2 + (size_t)n * 64 + 4 * h); break;
+        case ST_FC3: load_rows_f32(w, a.w3 + (size_t)n * 64 + 4 * h); break;
+        case ST_PCN: load_rows_f32(w, a.wp + (size_t)n * 128 + 64 * d.chunk + 4 * h); break;
+        default:
+            if (X3) {
+                const __bf16* p = a.wq_split + (size_t)n * PDSC_CHANNELS + 64 * d.chunk + 8 * h;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w.v[2 * k] = *reinterpret_cast<const f32x4*>(p + 16 * k);
+                    w.v[2 * k + 1] = *reinterpret_cast<const f32x4*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * k);
+                }
+            } else {
+                load_rows_f32(w, a.wq + (size_t)n * 128 + 64 * d.chunk + 4 * h);
+            }
+    }
+}
+
+__device__ __forceinline__ void mma_f32(f32x16& acc, const WChunk& w, const f32x4* x) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[q][e], x[q][e], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mma_x3(f32x16& acc, const WChunk& w, const bf16x8* xh, const bf16x8* xl) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w.v[2 * i]), wl = __builtin_bit_cast(bf16x8, w.v[2 * i + 1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[i], acc, 0, 0, 0);
+    }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack2(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed bf16 hi pair and lo pair, the arithmetic of split_bf16 (split_layout.h) with packed conversions:
+// 6 VALU operations per pair
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const bf16x2 hv = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+    hi = __builtin_bit_cast(unsigned, hv);
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const bf16x2 lv = __builtin_convertvector(f32x2{x0 - h0, x1 - h1}, bf16x2);
+    lo = __builtin_bit_cast(unsigned, lv);
+}
+
+// fp32 x4 -> packed bf16 hi (2 registers) and lo (2 registers)
+__device__ __forceinline__ void split4(const f32x4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    split2(v[0], v[1], hi[0], lo[0]);
+    split2(v[2], v[3], hi[1], lo[1]);
+}
+
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
+// afterwards, per lane: lower half (a, b) = (own a, partner's a);  upper half (a, b) = (partner's b, own b).
+__device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+// Lane-half h holds 4 consecutive channels (c0+4h..+3) of a value as packed hi[2] / lo[2].  Returns the 16-byte chunk
+// this lane stores: lower half -> the 8 hi values of channels c0..c0+7, upper half -> the 8 lo values.
+__device__ __forceinline__ u32x4 chunk_for_store(const unsigned (&hi)[2], const unsigned (&lo)[2]) {
+    unsigned a0 = hi[0], b0 = lo[0], a1 = hi[1], b1 = lo[1];
+    half_swap(a0, b0);        // lower: (own hi0, partner hi0); upper: (partner lo0, own lo0)
+    half_swap(a1, b1);
+    // lower half: own = channels 0..3, partner = 4..7 -> (a0, a1, b0, b1); upper: partner = 0..3 (a), own = 4..7 (b)
+    return u32x4{a0, a1, b0, b1};
+}
+
+// diagnostics (pdsc_layer_trace): 64 shader-clock stamps per wave: 0 start, 1 input in registers, 2+i chunk i done, 63 end
+#define LW_STAMP(k) \
+    if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
+
+template <bool T, bool H, bool X3, bool FRAG, bool TRACE = false>
+__global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float Vs_all[LW_WAVES][32 * LW_VLD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tpp = ceil_div_dev(a.N, 32);                          // tiles per pair
+    const int gw = blockIdx.x * LW_WAVES + wave;                    // one wave = one tile
+    if (gw >= a.bs * tpp) return;                                    // (no workgroup barriers anywhere below)
+    const int b = gw / tpp, tile = gw - b * tpp;
+    const int m0 = b * a.N + tile * 32;
+    const int valid = min(32, a.N - tile * 32);
+    const bool live = l31 < valid;
+    const size_t row = (size_t)m0 + min(l31, valid - 1);
+    float* Vs = Vs_all[wave];
+
+    LW_STAMP(0)
+    constexpr int NCH = num_chunks<T, H>();
+    // weight ring: the fp32 chunks (2048 matrix-pipe cycles each) are fetched one chunk ahead in two buffers; the split
+    // q|k|v chunks (384 cycles each, far less than an L2 round trip) NQB-1 chunks ahead in NQB buffers
+    constexpr int Q0 = (H && X3) ? (T ? 10 : 0) + 8 : NCH;           // first split q|k|v chunk
+    constexpr int NQB = (H && X3) ? (FRAG ? LW_QKV_BUFS : LW_QKV_BUFS - 1) : 2;     // (natural layout: more address registers)
+    WChunk w[NQB];
+    auto buf_of = [](int i) constexpr { return i < Q0 ? (i & 1) : (i - Q0) % NQB; };
+    load_chunk<T, X3, FRAG>(w[0], a, 0, lane);
+
+    f32x4 x0[16], x1[8], x2[8], y3[16], x4[16];
+    bf16x8 xh[8], xl[8];
+    if (T) {
+        if (a.msg) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x0[q] = *reinterpret_cast<const f32x4*>(a.msg + row * PDSC_CHANNELS + 8 * q + 4 * h);
+        } else {
+            // merge of the attention's key-split partials, the arithmetic of merge_partials_finish (merge_partials.h)
+            auto run = [&](auto ns_tag) {
+                constexpr int NS = decltype(ns_tag)::value;
+                constexpr int GQ = NS <= 2 ? 16 : 8;                 // k-steps per batch of loads (up to 128 registers in flight)
+                const size_t slot0 = (size_t)b * NS * a.Npad + (row - (size_t)b * a.N);
+                float wsp[NS], ls[NS];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) {
+                    const float2 ml = *reinterpret_cast<const float2*>(a.part_ml + (slot0 + (size_t)sp * a.Npad) * 2);
+                    wsp[sp] = ml.x; ls[sp] = ml.y;
+                }
+                float mmax = wsp[0];
+#pragma unroll
+                for (int sp = 1; sp < NS; ++sp) mmax = fmaxf(mmax, wsp[sp]);
+                float den = 0.f;
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) {
+                    wsp[sp] = __builtin_amdgcn_exp2f(wsp[sp] - mmax);
+                    den = fmaf(ls[sp], wsp[sp], den);
+                }
+                const float rden = 1.0f / den;
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += GQ) {
+                    f32x4 pv[GQ][NS];
+#pragma unroll
+                    for (int q = 0; q < GQ; ++q)
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp)
+                            pv[q][sp] = *reinterpret_cast<const f32x4*>(a.part_o + (slot0 + (size_t)sp * a.Npad) * PDSC_CHANNELS +
+                                                                        8 * (q0 + q) + 4 * h);
+#pragma unroll
+                    for (int q = 0; q < GQ; ++q) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[q][sp][e], wsp[sp], acc[e]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x0[q0 + q][e] = acc[e] * rden;
+                            asm volatile("" : "+v"(x0[q0 + q][e]));     // materialise here (else the compiler sinks the arithmetic
+                        }                                               // to the first MFMA and keeps every batch of loads live)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);               // keep the next batch's loads behind this batch's use
+                }
+            };
+            switch (a.nsplit) {
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                case 2: run(std::integral_constant<int, 2>{}); break;
+                case 3: run(std::integral_constant<int, 3>{}); break;
+                default: run(std::integral_constant<int, 4>{}); break;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y3[q] = *reinterpret_cast<const f32x4*>(a.feat_in + row * PDSC_CHANNELS + 8 * q + 4 * h);
+    }
+    LW_STAMP(1)
+
+    unsigned char* img = (H && a.kv) ? a.kv + (size_t)gw * SPL_TILE_BYTES : nullptr;
+    f32x16 acc;
+
+    static_for<0, NCH>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr ChunkDesc d = chunk_desc<T>(i);
+        constexpr int n0 = 32 * d.tile;
+        if constexpr (i < Q0) {
+            if constexpr (i + 1 < NCH) load_chunk<T, X3, FRAG>(w[buf_of(i + 1)], a, i + 1, lane);
+        } else if constexpr (i == Q0) {
+            static_for<1, NQB>([&](auto jc) {
+                constexpr int j = Q0 + decltype(jc)::value;
+                if constexpr (j < NCH) load_chunk<T, X3, FRAG>(w[buf_of(j)], a, j, lane);
+            });
+        } else if constexpr (i + NQB - 1 < NCH) {
+            load_chunk<T, X3, FRAG>(w[buf_of(i + NQB - 1)], a, i + NQB - 1, lane);
+        }
+        if constexpr (T && d.stage == ST_FC2 && d.tile == 0) {
+            // residual rows for fc3's epilogue, two chunks early (x0 is dead, its registers are free): they come from HBM
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y3[q] = *reinterpret_cast<const f32x4*>(a.res + row * PDSC_CHANNELS + 8 * q + 4 * h);
+        }
+        const WChunk& wc = w[buf_of(i)];
+        if constexpr (d.chunk == 0) {
+            // accumulator := bias, on the matrix pipe: one extra k-step whose A operand is the bias fragment (zero in the
+            // second k slot) and whose B operand is 1 -- no VALU work, and C = 0 is an inline constant
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.bias, 1.0f, zero, 0, 0, 0);
+        }
+        if constexpr (d.stage == ST_FC1) mma_f32(acc, wc, x0 + 8 * d.chunk);
+        else if constexpr (d.stage == ST_FC2) mma_f32(acc, wc, x1);
+        else if constexpr (d.stage == ST_FC3) mma_f32(acc, wc, x2);
+        else if constexpr (d.stage == ST_PCN) mma_f32(acc, wc, y3 + 8 * d.chunk);
+        else if constexpr (X3) mma_x3(acc, wc, xh + 4 * d.chunk, xl + 4 * d.chunk);
+        else mma_f32(acc, wc, x4 + 8 * d.chunk);
+
+        if constexpr (d.chunk == d.nchunks - 1) {
+            // ---- epilogue of output tile n0: lane (point l31, half h) holds channels n0 + 8g + 4h + e ----
+            f32x4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[g][e] = acc[4 * g + e];
+            if constexpr (d.stage == ST_FC1 || d.stage == ST_FC2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) (d.stage == ST_FC1 ? x1 : x2)[4 * d.tile + g][e] = fmaxf(v[g][e], 0.f);
+            } else if constexpr (d.stage == ST_FC3) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y3[4 * d.tile + g][e] = y3[4 * d.tile + g][e] + v[g][e];
+                    if (a.feat_out && live)
+                        *reinterpret_cast<f32x4*>(a.feat_out + row * PDSC_CHANNELS + n0 + 8 * g + 4 * h) = y3[4 * d.tile + g];
+                }
+            } else if constexpr (d.stage == ST_PCN) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x4[4 * d.tile + g][e] = fmaxf(v[g][e], 0.f);
+                    if (live) *reinterpret_cast<f32x4*>(a.featB_out + row * PDSC_CHANNELS + n0 + 8 * g + 4 * h) = x4[4 * d.tile + g];
+                }
+                if constexpr (X3 && d.tile == 3) {
+                    // featB -> bf16 hi / lo operands of the 16-wide k-steps: step kk, lane-half h <- channels 16kk+8h..+7
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        unsigned ha[2], la[2], hb[2], lb[2];
+                        split4(x4[2 * kk], ha, la);              // channels 16kk + 4h + e
+                        split4(x4[2 * kk + 1], hb, lb);          // channels 16kk + 8 + 4h + e
+                        half_swap(ha[0], hb[0]); half_swap(ha[1], hb[1]);
+                        half_swap(la[0], lb[0]); half_swap(la[1], lb[1]);
+                        xh[kk] = __builtin_bit_cast(bf16x8, u32x4{ha[0], ha[1], hb[0], hb[1]});
+                        xl[kk] = __builtin_bit_cast(bf16x8, u32x4{la[0], la[1], lb[0], lb[1]});
+                    }
+                }
+            } else {
+                // q | k | v, output tile d.tile of 12: tiles 0..3 = q, 4..7 = k, 8..11 = v
+                if (a.qkv_out && live) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(a.qkv_out + row * (3 * PDSC_CHANNELS) + n0 + 8 * g + 4 * h) = v[g];
+                }
+                if (a.qs) {
+                    if constexpr (d.tile < 4) {
+                        __bf16* dst = a.qs + row * SPL_Q_LD + h * PDSC_CHANNELS + n0;       // lower half: hi plane, upper: lo
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            unsigned hi[2], lo[2];
+                            split4(v[g], hi, lo);
+                            const u32x4 c = chunk_for_store(hi, lo);
+                            if (live) *reinterpret_cast<u32x4*>(dst + 8 * g) = c;
+                        }
+                    } else if constexpr (d.tile < 8) {
+                        unsigned char* dst = img + (h ? SPL_KL : SPL_KH) + spl_k_offset(l31, 4 * (d.tile - 4));
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 z = v[g];
+                            if (valid < 32) {                                                    // wave-uniform: last tile of a pair
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) z[e] = live ? z[e] : 0.f;            // keys beyond N are zero
+                            }
+                            unsigned hi[2], lo[2];
+                            split4(z, hi, lo);
+                            *reinterpret_cast<u32x4*>(dst + 16 * g) = chunk_for_store(hi, lo);
+                        }
+                    } else {
+                        // V^T image: transpose 32 keys x 32 channels through the wave-private LDS patch
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 z = v[g];
+                            if (valid < 32) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) z[e] = live ? z[e] : 0.f;
+                            }
+                            *reinterpret_cast<f32x4*>(Vs + l31 * LW_VLD + 8 * g + 4 * h) = z;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int cl = l31, jh = h + 2 * it;                                 // (channel, key chunk) of this lane
+                            unsigned chi[4], clo[4];
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2)
+                                split2(Vs[spl_v_key(jh, e) * LW_VLD + cl], Vs[spl_v_key(jh, e + 1) * LW_VLD + cl], chi[e / 2], clo[e / 2]);
+                            const u32x4 ch = {chi[0], chi[1], chi[2], chi[3]}, cw = {clo[0], clo[1], clo[2], clo[3]};
+                            const int off = spl_v_offset(32 * (d.tile - 8) + cl, jh);
+                            *reinterpret_cast<u32x4*>(img + SPL_VH + off) = ch;
+                            *reinterpret_cast<u32x4*>(img + SPL_VL + off) = cw;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        LW_STAMP(2 + i)
+        __builtin_amdgcn_sched_barrier(0);      // chunks are the unit of the software pipeline: no code motion across them
+    });
+
+    if (H && a.qs) {        // pad chunks of the tile image (never read; zeroed so the stream is deterministic)
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (lane < 32) {
+            *reinterpret_cast<f32x4*>(img + SPL_KH + spl_k_offset(lane, 16)) = z;
+            *reinterpret_cast<f32x4*>(img + SPL_KL + spl_k_offset(lane, 16)) = z;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            *reinterpret_cast<f32x4*>(img + SPL_VH + spl_v_offset(lane + 64 * it, 4)) = z;
+            *reinterpret_cast<f32x4*>(img + SPL_VL + spl_v_offset(lane + 64 * it, 4)) = z;
+        }
+    }
+    LW_STAMP(63)
+}
+
+// ---- fragment-ordered weight streams -------------------------------------------------------------------------------
+// element (chunk c, slot s, lane l = (l31, h), e) of a stream <- the weight the natural-layout load_chunk puts there
+__global__ __launch_bounds__(256) void wfrag_tail_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ w3, const float* __restrict__ b3,
+                                                         float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                  // one float4 = (chunk, slot, lane)
+    if (idx < LW_TAIL_TILES * 64) {                                  // bias fragments behind the chunks
+        const int t = idx >> 6, lane = idx & 63;
+        const float* b = t < 2 ? b1 + 32 * t : t < 4 ? b2 + 32 * (t - 2) : b3 + 32 * (t - 4);
+        out[(size_t)LW_TAIL_CHUNKS * LW_CHUNK_BYTES / 4 + idx] = lane < 32 ? b[lane] : 0.f;
+    }
+    if (idx >= LW_TAIL_CHUNKS * 8 * 64) return;
+    const int c = idx >> 9, s = (idx >> 6) & 7, lane = idx & 63, l31 = lane & 31, h = lane >> 5;
+    const ChunkDesc d = chunk_desc<true>(c);
+    const int n = 32 * d.tile + l31;
+    const float* src = d.stage == ST_FC1 ? w1 + (size_t)n * 128 + 64 * d.chunk : d.stage == ST_FC2 ? w2 + (size_t)n * 64 : w3 + (size_t)n * 64;
+    *reinterpret_cast<f32x4*>(out + (size_t)idx * 4) = *reinterpret_cast<const f32x4*>(src + 8 * s + 4 * h);
+}
+
+__global__ __launch_bounds__(256) void wfrag_head_kernel(const float* __restrict__ wp, const float* __restrict__ bp,
+                                                         const float* __restrict__ wq, const float* __restrict__ bq,
+                                                         unsigned char* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < LW_HEAD_TILES * 64) {
+        const int t = idx >> 6, lane = idx & 63;
+        const float* b = t < 4 ? bp + 32 * t : bq + 32 * (t - 4);
+        reinterpret_cast<float*>(out + (size_t)LW_HEAD_CHUNKS * LW_CHUNK_BYTES)[idx] = lane < 32 ? b[lane] : 0.f;
+    }
+    if (idx >= LW_HEAD_CHUNKS * 8 * 64) return;
+    const int c = idx >> 9, s = (idx >> 6) & 7, lane = idx & 63, l31 = lane & 31, h = lane >> 5;
+    const ChunkDesc d = chunk_desc<false>(c);
+    const int n = 32 * d.tile + l31;
+    if (d.stage == ST_PCN) {
+        *reinterpret_cast<f32x4*>(out + (size_t)idx * 16) = *reinterpret_cast<const f32x4*>(wp + (size_t)n * 128 + 64 * d.chunk + 8 * s + 4 * h);
+    } else {                                                         // slot 2k = hi, 2k+1 = lo of bf16 k-step 4*chunk + k
+        const float* src = wq + (size_t)n * 128 + 64 * d.chunk + 16 * (s >> 1) + 8 * h;
+        __bf16 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 hi, lo;
+            split_bf16(src[e], hi, lo);
+            v[e] = (s & 1) ? lo : hi;
+        }
+        *reinterpret_cast<u32x4*>(out + (size_t)idx * 16) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    }
+}
+
+int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
+    const int waves = a.bs * ceil_div(a.N, 32);
+    const dim3 grid(ceil_div(waves, LW_WAVES)), block(64 * LW_WAVES);
+    const bool frag = (!tail || a.wf_tail) && (!head || a.wf_head);
+    const bool x3 = head && (a.wq_split || frag);
+    if (tail && head) {
+        if (frag && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true>), grid, block, 0, st, a);
+        else if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true>), grid, block, 0, st, a);
+        else if (x3) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((layer_wave_kernel<true, true, false, false>), grid, block, 0, st, a);
+    } else if (tail) {
+        if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((layer_wave_kernel<true, false, false, false>), grid, block, 0, st, a);
+    } else {
+        if (frag) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true>), grid, block, 0, st, a);
+        else if (x3) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((layer_wave_kernel<false, true, false, false>), grid, block, 0, st, a);
+    }
+    return check_launch("pdsc_layer_fused(wave)");
+}
+
+}  // namespace pdsc
+
+using namespace pdsc;
+
+extern "C" size_t pdsc_wfrag_tail_bytes(void) { return (size_t)LW_TAIL_CHUNKS * LW_CHUNK_BYTES + LW_TAIL_TILES * 256; }
+extern "C" size_t pdsc_wfrag_head_bytes(void) { return (size_t)LW_HEAD_CHUNKS * LW_CHUNK_BYTES + LW_HEAD_TILES * 256; }
+
+extern "C" int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                     const float* b3, void* out, void* stream) {
+    PDSC_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && out, "pdsc_wfrag_build_tail: null pointer");
+    hipLaunchKernelGGL(wfrag_tail_kernel, dim3(LW_TAIL_CHUNKS * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3,
+                       (float*)out);
+    return check_launch("pdsc_wfrag_build_tail");
+}
+
+extern "C" int pdsc_wfrag_build_head(const float* wp, const float* bp, const float* wq, const float* bq, void* out, void* stream) {
+    PDSC_REQUIRE(wp && bp && wq && bq && out, "pdsc_wfrag_build_head: null pointer");
+    hipLaunchKernelGGL(wfrag_head_kernel, dim3(LW_HEAD_CHUNKS * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream, wp, bp, wq, bq,
+                       (unsigned char*)out);
+    return check_launch("pdsc_wfrag_build_head");
+}
+
+extern long long* pdsc_layer_trace_buffer(void);
+
+extern "C" int pdsc_layer_fused_frag(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                                     const float* res, const float* feat_in, float* feat_out, float* featB_out,
+                                     float* qkv_out, void* q_split, void* kv_tiles, const void* wfrag_tail,
+                                     const void* wfrag_head, int bs, int N, void* stream) {
+    const bool tail = msg != nullptr || part_o != nullptr, head = featB_out != nullptr;
+    PDSC_REQUIRE(tail || head, "pdsc_layer_fused_frag: neither tail (msg / partials) nor head (featB_out) requested");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused_frag: bs=%d N=%d", bs, N);
+    if (tail) {
+        PDSC_REQUIRE(res && wfrag_tail, "pdsc_layer_fused_frag: tail needs res and the tail stream");
+        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= MERGE_MAX_SPLIT && Npad >= N,
+                               "pdsc_layer_fused_frag: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", MERGE_MAX_SPLIT);
+    } else PDSC_REQUIRE(feat_in, "pdsc_layer_fused_frag: head-only needs feat_in");
+    if (head) PDSC_REQUIRE((qkv_out || q_split) && wfrag_head, "pdsc_layer_fused_frag: head needs qkv_out or the split streams, and the head stream");
+    else PDSC_REQUIRE(feat_out, "pdsc_layer_fused_frag: tail-only needs feat_out");
+    PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused_frag: q_split and kv_tiles go together");
+    LayerArgs a{};
+    a.msg = msg; a.part_o = part_o; a.part_ml = part_ml; a.nsplit = nsplit; a.Npad = Npad;
+    a.res = res; a.feat_in = feat_in; a.feat_out = feat_out; a.featB_out = featB_out; a.qkv_out = qkv_out;
+    a.qs = (__bf16*)q_split; a.kv = (unsigned char*)kv_tiles;
+    a.N = N; a.bs = bs;
+    a.wf_tail = (const unsigned char*)wfrag_tail; a.wf_head = (const unsigned char*)wfrag_head;
+    a.trace = pdsc_layer_trace_buffer();
+    return launch_layer_wave(a, tail, head, (hipStream_t)stream);
+}

@@ -34,9 +34,10 @@ __device__ __forceinline__ f32x4 merge_partials_chunk(const float* __restrict__ 
             for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[sp][e], w, acc[e]);
         }
     }
+    const float r = 1.0f / L;              // one correctly-rounded reciprocal per row, then multiplies (all merge sites agree)
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[e] / L;
+    for (int e = 0; e < 4; ++e) v[e] = acc[e] * r;
     return v;
 }
 
@@ -76,9 +77,10 @@ __device__ __forceinline__ f32x4 merge_partials_finish(const MergeLoads<NS>& L) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(L.pv[sp][e], w, acc[e]);
     }
+    const float r = 1.0f / den;
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[e] / den;
+    for (int e = 0; e < 4; ++e) v[e] = acc[e] * r;
     return v;
 }
 

@@ -132,11 +132,29 @@ def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: to
     return msg if merge else (scratch, nsplit)
 
 
+def frag_weights_tail(tail_w) -> torch.Tensor:
+    """(fc1 w, b, fc2 w, b, fc3 w, b) fp32 [out][in] -> the fragment-ordered tail stream of pdsc_layer_fused_frag."""
+    lib = _lib.load()
+    out = torch.empty(int(lib.pdsc_wfrag_tail_bytes()), dtype=torch.uint8, device=tail_w[0].device)
+    _lib.check(lib.pdsc_wfrag_build_tail(*[_p(_chk(w, "tail_w")) for w in tail_w], _p(out), _stream()), "pdsc_wfrag_build_tail")
+    return out
+
+
+def frag_weights_head(head_w) -> torch.Tensor:
+    """(pcn w, b, qkv w, b): pcn kept fp32, q|k|v -> bf16 hi / lo, biases as one more k-step -> the head stream."""
+    lib = _lib.load()
+    out = torch.empty(int(lib.pdsc_wfrag_head_bytes()), dtype=torch.uint8, device=head_w[0].device)
+    _lib.check(lib.pdsc_wfrag_build_head(*[_p(_chk(w, "head_w")) for w in head_w], _p(out), _stream()), "pdsc_wfrag_build_head")
+    return out
+
+
 def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False, partials=None,
-                      qkv_split: bool = False):
+                      qkv_split: bool = False, frag: bool = False):
     """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
     partials = (scratch, nsplit) from sc_attention_split(..., merge=False) replaces msg.
     qkv_split: run the q|k|v projection in split precision (bf16 hi/lo weights).
+    frag: go through pdsc_layer_fused_frag (weights as fragment-ordered streams; implies qkv_split) -- the entry the
+    forward uses.
     Returns (feat or None, featB, qkv or None, q_split, kv_tiles)."""
     lib = _lib.load()
     src = res if res is not None else feat_in
@@ -159,6 +177,12 @@ def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_q
     args = [_p(_chk(msg, "msg")) if msg is not None else None, part_o, part_ml, nsplit, npad,
             _p(_chk(res, "res")) if res is not None else None,
             _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB), _p(qkv), _p(qs), _p(kv)]
+    if frag:
+        wf_tail = frag_weights_tail(tail) if tail_w is not None else None
+        wf_head = frag_weights_head(head)
+        args += [_p(wf_tail), _p(wf_head)]
+        _lib.check(lib.pdsc_layer_fused_frag(*args, bs, n, _stream()), "pdsc_layer_fused_frag")
+        return feat, featB, qkv, qs, kv
     args += [_p(w) for w in tail] + [_p(w) for w in head]
     wqs = split_weight(head[2]) if qkv_split else None
     _lib.check(lib.pdsc_layer_fused_split(*args, _p(wqs), bs, n, _stream()), "pdsc_layer_fused_split")

@@ -2,6 +2,7 @@
 """Stage timeline of layer_fused_kernel<tail, head, split qkv> (pdsc_layer_trace stamps), in shader clocks."""
 import argparse
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
@@ -31,7 +32,8 @@ def main():
     res = rnd(m, 128)
     tail_w = [rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128)]
     head_w = [rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384)]
-    run = lambda: ops.layer_fused_split(None, res, None, tail_w, head_w, bs, n, partials=partials, qkv_split=True)  # noqa: E731
+    frag = os.environ.get("PDSC_LAYER_FRAG", "1") != "0" and not os.environ.get("PDSC_LAYER_VARIANT", "w").startswith("b")
+    run = lambda: ops.layer_fused_split(None, res, None, tail_w, head_w, bs, n, partials=partials, qkv_split=True, frag=frag)  # noqa: E731
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -43,21 +45,33 @@ def main():
     torch.cuda.synchronize()
     print(f"layer_fused (merge of {partials[1]} splits + tail + head, split qkv): {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per call (incl. weight split + allocs)")
     nwg = ((n + 31) // 32) * bs
-    trace = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device=dev)
+    trace = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
     _lib.check(lib.pdsc_layer_trace(C.c_void_p(trace.data_ptr())), "trace")
     run()
     torch.cuda.synchronize()
     _lib.check(lib.pdsc_layer_trace(None), "trace off")
-    t = trace.cpu().reshape(nwg, 4, 16)[:, :, :14].double()
-    t0 = t[:, :, 0].min()
-    print(f"{nwg} workgroups; kernel span {float(t[:, :, 13].max() - t0):.0f} clocks; workgroup start spread {float(t[:, 0, 0].max() - t0):.0f}")
-    for w in (0, 3):
-        d = t[:, w, 1:] - t[:, w, :-1]
-        life = t[:, w, 13] - t[:, w, 0]
-        print(f"wave {w}: lifetime mean {float(life.mean()):.0f}  min {float(life.min()):.0f}  max {float(life.max()):.0f}")
-        for k in range(13):
-            print(f"   {NAMES[k]:26s} -> {NAMES[k + 1]:26s} mean {float(d[:, k].mean()):8.0f}  max {float(d[:, k].max()):8.0f}")
-
+    if os.environ.get("PDSC_LAYER_VARIANT", "w").startswith("b"):
+        t = trace.cpu().reshape(nwg, 4, 16)[:, :, :14].double()
+        t0 = t[:, :, 0].min()
+        print(f"{nwg} workgroups; kernel span {float(t[:, :, 13].max() - t0):.0f} clocks; workgroup start spread {float(t[:, 0, 0].max() - t0):.0f}")
+        for w in (0, 3):
+            d = t[:, w, 1:] - t[:, w, :-1]
+            life = t[:, w, 13] - t[:, w, 0]
+            print(f"wave {w}: lifetime mean {float(life.mean()):.0f}  min {float(life.min()):.0f}  max {float(life.max()):.0f}")
+            for k in range(13):
+                print(f"   {NAMES[k]:26s} -> {NAMES[k + 1]:26s} mean {float(d[:, k].mean()):8.0f}  max {float(d[:, k].max()):8.0f}")
+    else:       # wavefront-resident kernel: one wave per tile; stamps 0 start, 1 input in registers, 2+i chunk i done, 63 end
+        t = trace.cpu()[: nwg * 64].reshape(nwg, 64).double()
+        t0 = t[:, 0].min()
+        life = t[:, 63] - t[:, 0]
+        print(f"{nwg} waves; kernel span {float(t[:, 63].max() - t0):.0f} clocks; start spread {float(t[:, 0].max() - t0):.0f}")
+        print(f"wave lifetime mean {float(life.mean()):.0f}  min {float(life.min()):.0f}  max {float(life.max()):.0f}")
+        names = ["input"] + ["fc1"] * 4 + ["fc2"] * 2 + ["fc3"] * 4 + ["pcn"] * 8 + ["qkv"] * 24
+        mma = [0] + [2048] * 18 + [384] * 24
+        d = (t[:, 1:44] - t[:, 0:43])
+        for k in range(43):
+            print(f"   {k:2d} {names[k]:6s} mean {float(d[:, k].mean()):7.0f}  min {float(d[:, k].min()):7.0f}  max {float(d[:, k].max()):7.0f}   (mfma {mma[k]})")
+        print(f"   tail (pads, drain)  mean {float((t[:, 63] - t[:, 43]).mean()):7.0f}")
 
 if __name__ == "__main__":
     main()
