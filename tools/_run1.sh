@@ -1,5 +1,6 @@
 cd /root/repo
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r1x_pytest_gpu.txt
-timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 > gpurun_out/r1x_smoke.txt
-timeout 300 python bench.py > gpurun_out/r1x_bench.txt 2>&1
-timeout 300 python bench.py --global-batch 4 --steps 20 > gpurun_out/r1x_bench_b4.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q -k "layer or pack or split or encoder or forward" 2>&1 | tail -5 > gpurun_out/r1y_pytest_layer.txt
+timeout 120 python tools/layer_trace.py --bs 4 2>&1 | sed -n 2,4p > gpurun_out/r1y_trace.txt
+timeout 120 python tools/layer_trace.py --bs 32 2>&1 | sed -n 2,4p >> gpurun_out/r1y_trace.txt
+timeout 300 python bench.py --steps 10 --warmup 2 > gpurun_out/r1y_bench.txt 2>&1
+timeout 300 python bench.py --steps 20 --warmup 2 --global-batch 4 > gpurun_out/r1y_bench_b4.txt 2>&1
