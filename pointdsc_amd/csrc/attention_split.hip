@@ -320,33 +320,45 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead DMA of the last iterations targets this workgroup's LDS
     // ---- epilogue: o[c][4g+e] = O^T[channel 32c + 8g + 4h + e][query l31] ---------------------------------
+    // In this layout a lane owns 16 bytes of 32 different output rows: a direct store would touch 64 cache lines per
+    // instruction.  The K/V stages are dead now, so every wave transposes its 32 x 128 tile through its own 16.5 KiB of
+    // LDS (row pitch 528 B) and stores whole rows: one instruction = 2 rows = 8 full lines.
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const int query = qb * (NW * 32) + wave * 32 + l31;
-    if (query < N) {
-        if (a.nsplit == 1) {
-            float* dst = a.msg + ((size_t)b * N + query) * PDSC_CHANNELS + 4 * h;
+    const int q0 = qb * (NW * 32) + wave * 32;
+    __syncthreads();                                    // the other waves are done reading K / V
+    constexpr int OPITCH = PDSC_CHANNELS * 4 + 16;
+    unsigned char* const patch = lds + wave * (32 * OPITCH);
+    {
+        // un-split: normalised here (o / l, as before); split: the partials stay raw
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {o[c][4 * g] / l_tot, o[c][4 * g + 1] / l_tot, o[c][4 * g + 2] / l_tot, o[c][4 * g + 3] / l_tot};
-                    *reinterpret_cast<f32x4*>(dst + 32 * c + 8 * g) = v;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]};
+                if (a.nsplit == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = o[c][4 * g + e] / l_tot;
                 }
-        } else {
-            const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + query;
-            float* dst = a.part_o + slot * PDSC_CHANNELS + 4 * h;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(dst + 32 * c + 8 * g) = v;
-                }
-            if (h == 0) {
-                a.part_ml[slot * 2 + 0] = m_run;
-                a.part_ml[slot * 2 + 1] = l_tot;
+                *reinterpret_cast<f32x4*>(patch + l31 * OPITCH + 128 * c + 32 * g + 16 * h) = v;
             }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        float* const base = a.nsplit == 1 ? a.msg + (size_t)b * N * PDSC_CHANNELS
+                                          : a.part_o + ((size_t)b * a.nsplit + sp) * a.Npad * PDSC_CHANNELS;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = 2 * it + h, piece = l31;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + r * OPITCH + 16 * piece);
+            if (q0 + r < N) *reinterpret_cast<f32x4*>(base + (size_t)(q0 + r) * PDSC_CHANNELS + 4 * piece) = v;
         }
+    }
+    if (a.nsplit != 1 && h == 0 && q0 + l31 < N) {
+        const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + q0 + l31;
+        a.part_ml[slot * 2 + 0] = m_run;
+        a.part_ml[slot * 2 + 1] = l_tot;
     }
     if (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
