@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -163,7 +164,14 @@ def main():
 
     att_ms, att_n = read(0)
     cmp_ms, cmp_n = read(1)
+    lay_ms, lay_n = read(2)
     _lib.check(lib.pdsc_profile_enable(0), "pdsc_profile_enable(0)")
+    # fused layer launch (tail of layer i + head of layer i+1): 2 flop/MAC x (128*64 + 64*64 + 64*128 + 128*128 + 128*384)
+    # MACs per point; matrix-pipe cycles per 32-point tile: 600 fp32 MFMAs x 64 + 288 bf16 MFMAs x 32 (q|k|v as bf16x3)
+    lay_flops = 2.0 * 86016 * N * B
+    lay_avg = lay_ms / max(lay_n, 1) * 1e-3
+    lay_tflops = lay_flops / lay_avg / 1e12 if lay_n else None
+    lay_pipe_cycles = (600 * 64 + 288 * 32) * math.ceil(N / 32) * B / 1024.0      # per SIMD (256 CUs x 4)
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
     att_avg = att_ms / max(att_n, 1) * 1e-3
     att_tflops = att_flops / att_avg / 1e12 if att_n else None
@@ -208,6 +216,12 @@ def main():
                       "equivalent_fp32_mfma_frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                       "traffic": None, "launches": att_n,
                       "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}),
+        "roofline_layer": {"kernel": "layer_wave_kernel", "bound": "mfma",
+                           "achieved": None if lay_tflops is None else round(lay_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": None if lay_tflops is None else round(lay_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "matrix_pipe_busy_frac_at_2.4GHz": None if not lay_n else round(lay_pipe_cycles / (lay_avg * 2.4e9), 4),
+                           "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
+                           "flops_per_launch": lay_flops},
         "roofline_compat": {"kernel": "compat_sym_kernel", "bound": "hbm",
                             "achieved": None if cmp_gbs is None else round(cmp_gbs, 1), "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": None if cmp_gbs is None else round(cmp_gbs / PEAK_HBM_GBS, 4),
@@ -222,6 +236,7 @@ def main():
             if key in tj:
                 line["roofline"]["traffic"] = tj[key].get(line["roofline"]["kernel"])
                 line["roofline_compat"]["traffic"] = tj[key].get("compat_sym_kernel")
+                line["roofline_layer"]["traffic"] = tj[key].get("layer_wave_kernel")
         except Exception:
             pass
 

@@ -371,7 +371,8 @@ long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_s
  * kind 0 = sc_attention_kernel (MFMA roofline), kind 1 = compat_kernel (HBM roofline).  Disabled by
  * default: then no event is created or recorded.  pdsc_profile_read synchronises on the recorded events
  * (host side, call it after the timed region) and returns total milliseconds + number of launches. */
-enum pdsc_profile_kind { PDSC_PROF_ATTENTION = 0, PDSC_PROF_COMPAT = 1, PDSC_PROF_NUM_KINDS = 2 };
+enum pdsc_profile_kind { PDSC_PROF_ATTENTION = 0, PDSC_PROF_COMPAT = 1, PDSC_PROF_LAYER = 2 /* tail + head launches */,
+                         PDSC_PROF_NUM_KINDS = 3 };
 int pdsc_profile_enable(int max_records_per_kind);   /* 0 disables and frees the events */
 int pdsc_profile_reset(void);
 int pdsc_profile_read(int kind, double* total_ms, int* launches);

@@ -355,10 +355,12 @@ int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st) 
     const bool frag = (!tail || a.wf_tail) && (!head || a.wf_head);
     const bool x3 = head && (a.wq_split || frag);
     if (tail && head) {
+        profile_mark_begin(PDSC_PROF_LAYER, st);
         if (frag && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true>), grid, block, 0, st, a);
         else if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true>), grid, block, 0, st, a);
         else if (x3) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<true, true, false, false>), grid, block, 0, st, a);
+        profile_mark_end(PDSC_PROF_LAYER, st);
     } else if (tail) {
         if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<true, false, false, false>), grid, block, 0, st, a);

@@ -11,6 +11,9 @@ cd "$ROOT"
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6 > "$OUT/${TAG}_pytest_gpu.txt"
 timeout 300 python bench.py > "$OUT/${TAG}_bench.log" 2>&1; tail -1 "$OUT/${TAG}_bench.log" > "$OUT/${TAG}_bench_line.json"
 timeout 300 python bench.py --global-batch 4 --steps 20 > "$OUT/${TAG}_bench_b4.log" 2>&1; tail -1 "$OUT/${TAG}_bench_b4.log" > "$OUT/${TAG}_bench_line_4pairs.json"
+for B in 8 16; do   # the per-GPU shares of the 4- and 2-GPU runs of the 32-pair configuration
+  timeout 300 python bench.py --global-batch $B --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_${B}pairs.json"
+done
 cd /tmp
 for B in 32 4; do
   rm -rf /tmp/prof_$B
