@@ -186,6 +186,7 @@ int pdsc_layer_fused_x3(const float* msg, const float* part_o, const float* part
  * pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_TAIL / PDSC_WS_FRAG_HEAD, layer). */
 #define PDSC_WS_FRAG_TAIL 100
 #define PDSC_WS_FRAG_HEAD 101
+int pdsc_layer_prefers_block(int bs, int N);   /* 1: pdsc_forward_* takes the workgroup-per-tile kernel for this size */
 size_t pdsc_wfrag_tail_bytes(void);
 size_t pdsc_wfrag_head_bytes(void);
 int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pdsc_wsplit_offset": (_ll, [_cfgp, _i, _i]),
     "pdsc_wsplit_build": (_i, [_cfgp, _vp, _vp, _vp]),
     "pdsc_layer_fused_x3": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 17 + [_i, _i, _vp]),
+    "pdsc_layer_prefers_block": (_i, [_i, _i]),
     "pdsc_wfrag_tail_bytes": (_sz, []),
     "pdsc_wfrag_head_bytes": (_sz, []),
     "pdsc_wfrag_build_tail": (_i, [_vp] * 8),

@@ -304,7 +304,8 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
             const char* var = getenv("PDSC_LAYER_VARIANT");
             frag_env = (env ? atoi(env) : 1) && !(var && var[0] == 'b');
         }
-        const bool frag = frag_env && !x3_gemm;                   // default: wavefront-resident layer kernel on fragment streams
+        // default: wavefront-resident layer kernel on fragment streams; small problems: the workgroup-per-tile kernel (layer.hip)
+        const bool frag = frag_env && !x3_gemm && !pdsc_layer_prefers_block(bs, N);
         if (x3_gemm)
             PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),

@@ -370,6 +370,13 @@ extern "C" int pdsc_layer_trace(long long* device_buffer) {       // diagnostics
     return PDSC_OK;
 }
 
+// Size rule, measured at N = 5000 (fused layer launch, us; tiles = pairs x 157): 1 pair block 19 / wave 46 .. 3 pairs
+// (471 tiles) block faster by 13 us, 4 pairs (628) block 48 / wave 52, 6 pairs (942) block 70 / wave 56, 8 pairs equal,
+// 12+ pairs wave (32 pairs: 250 vs 347).  The step is this kernel's residency: 3 workgroups per CU x 256 CUs.
+extern "C" int pdsc_layer_prefers_block(int bs, int N) {
+    return (long long)bs * pdsc::ceil_div(N, pdsc::LF_ROWS) <= 3 * 256;
+}
+
 extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
                                       const float* res, const float* feat_in, float* feat_out,
                                       float* featB_out, float* qkv_out, void* q_split, void* kv_tiles,
@@ -390,10 +397,19 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
                       wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, g_layer_trace};
     hipStream_t st = (hipStream_t)stream;
-    // default: the wavefront-resident implementation (layer_wave.hip); PDSC_LAYER_VARIANT=block selects this file's
-    static const bool block_variant = [] { const char* e = getenv("PDSC_LAYER_VARIANT"); return e && e[0] == 'b'; }();
+    // Two implementations.  layer_wave.hip (one wavefront per 32-point tile) wins once the tiles fill the chip; with few
+    // tiles its serial 46k matrix-pipe cycles per tile are the launch time, and this file's kernel, which spreads a tile
+    // over the four SIMDs of a CU, is faster (N = 1000, one pair: 0.68 vs 1.10 ms per forward).
+    // PDSC_LAYER_VARIANT = block | wave overrides the size rule.
+    static const int variant = [] { const char* e = getenv("PDSC_LAYER_VARIANT"); return !e ? 0 : e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0; }();
+    const bool block_variant = variant == 1 || (variant == 0 && pdsc_layer_prefers_block(bs, N));
     if (!block_variant) return pdsc::launch_layer_wave(a, tail, head, st);
-    if (tail && head) return pdsc::launch_layer<true, true>(a, st);
+    if (tail && head) {
+        pdsc::profile_mark_begin(PDSC_PROF_LAYER, st);
+        const int rc = pdsc::launch_layer<true, true>(a, st);
+        pdsc::profile_mark_end(PDSC_PROF_LAYER, st);
+        return rc;
+    }
     if (tail) return pdsc::launch_layer<true, false>(a, st);
     return pdsc::launch_layer<false, true>(a, st);
 }

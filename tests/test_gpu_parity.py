@@ -323,10 +323,12 @@ def test_layer_fused_split_precision_qkv_projection(n, bs):
     assert torch.equal(fb2, fb1) and torch.equal(q2, q1) and torch.equal(qs2, qs1) and torch.equal(kv2, kv1)
 
 
-@pytest.mark.parametrize("n,bs", [(1, 1), (33, 2), (1000, 3)])
-def test_layer_fused_frag_streams_equal_natural_weights(n, bs):
-    """pdsc_layer_fused_frag (the forward's entry: weights as MFMA-fragment-ordered streams) does the arithmetic of
-    pdsc_layer_fused_split with split q|k|v weights, bit for bit: tail+head, head only, tail only."""
+@pytest.mark.parametrize("n,bs", [(1, 1), (33, 2), (1000, 3), (3000, 3)])
+def test_layer_fused_frag_streams_match_natural_weights(n, bs):
+    """pdsc_layer_fused_frag (the forward's entry for large problems: wavefront-resident kernel, weights as
+    MFMA-fragment-ordered streams, bias as one more k-step) against pdsc_layer_fused_split on natural-layout weights
+    (which takes the workgroup-per-tile kernel for small problems: other summation order, so fp32 round-off apart)
+    and against the fp64 chain; its streams are exactly the packing of its own q|k|v; head-only reproduces it."""
     gen = torch.Generator().manual_seed(200 + n)
     rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
     m = bs * n
@@ -335,15 +337,20 @@ def test_layer_fused_frag_streams_equal_natural_weights(n, bs):
     head_w = [g(x) for x in (rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384))]
     f0, fb0, q0, qs0, kv0 = ops.layer_fused_split(g(msg), g(res), None, tail_w, head_w, bs, n, want_qkv=True, qkv_split=True)
     f1, fb1, q1, qs1, kv1 = ops.layer_fused_split(g(msg), g(res), None, tail_w, head_w, bs, n, want_qkv=True, frag=True)
-    assert torch.equal(f0, f1) and torch.equal(fb0, fb1) and torch.equal(q0, q1)
-    assert torch.equal(qs0, qs1) and torch.equal(kv0, kv1)
-    _, fb2, q2, qs2, kv2 = ops.layer_fused_split(None, None, f0, None, head_w, bs, n, want_qkv=True, frag=True)
-    assert torch.equal(fb2, fb0) and torch.equal(q2, q0) and torch.equal(qs2, qs0) and torch.equal(kv2, kv0)
-    # the fp64 chain, for an absolute anchor
+    for got, ref in ((f1, f0), (fb1, fb0), (q1, q0)):
+        assert (got - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+    want_qs, want_kv = _pack_reference(q1.cpu(), bs, n)
+    assert torch.equal(qs1.cpu(), want_qs) and torch.equal(kv1.cpu(), want_kv)
+    _, fb2, q2, qs2, kv2 = ops.layer_fused_split(None, None, f1, None, head_w, bs, n, want_qkv=True, frag=True)
+    assert torch.equal(fb2, fb1) and torch.equal(q2, q1) and torch.equal(qs2, qs1) and torch.equal(kv2, kv1)
     d = lambda t: t.cpu().double()  # noqa: E731
     feat = d(res) + (torch.relu(torch.relu(d(msg) @ d(tail_w[0]).T + d(tail_w[1])) @ d(tail_w[2]).T + d(tail_w[3])) @ d(tail_w[4]).T
                      + d(tail_w[5]))
     assert (d(f1) - feat).abs().max() < 2e-5 * max(1.0, float(feat.abs().max()))
+    featB = torch.relu(feat @ d(head_w[0]).T + d(head_w[1]))
+    assert (d(fb1) - featB).abs().max() < 2e-5 * max(1.0, float(featB.abs().max()))
+    qkv = featB @ d(head_w[2]).T + d(head_w[3])
+    assert (d(q1) - qkv).abs().max() < 4e-5 * max(1.0, float(qkv.abs().max()))
 
 
 @pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 2), (1000, 2, 3), (300, 3, 4)])
