@@ -370,11 +370,11 @@ extern "C" int pdsc_layer_trace(long long* device_buffer) {       // diagnostics
     return PDSC_OK;
 }
 
-// Size rule, measured at N = 5000 (fused layer launch, us; tiles = pairs x 157): 1 pair block 19 / wave 46 .. 3 pairs
-// (471 tiles) block faster by 13 us, 4 pairs (628) block 48 / wave 52, 6 pairs (942) block 70 / wave 56, 8 pairs equal,
-// 12+ pairs wave (32 pairs: 250 vs 347).  The step is this kernel's residency: 3 workgroups per CU x 256 CUs.
+// Size rule, from the hipEvent-timed fused layer launch at N = 5000 (us, block / wave; tiles = pairs x 157): 2 pairs 37 / 55,
+// 3 pairs (471 tiles) 43 / 61, 4 pairs (628) 56 / 53, 6 pairs (942) 70 / 56, 8 pairs 93 / 94, 16 pairs 190 / 163,
+// 32 pairs 347 / 250.  Block up to two workgroups per CU.
 extern "C" int pdsc_layer_prefers_block(int bs, int N) {
-    return (long long)bs * pdsc::ceil_div(N, pdsc::LF_ROWS) <= 3 * 256;
+    return (long long)bs * pdsc::ceil_div(N, pdsc::LF_ROWS) <= 2 * 256;
 }
 
 extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
