@@ -29,11 +29,17 @@ def main():
     batch = synthetic.make_batch(args.bs, args.n, seed=args.seed)
     data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
 
+    initial = {}
+
     def run(sl):
         d = {k: v[sl].contiguous() for k, v in data.items()}
         d["testing"] = True
         with torch.no_grad():
             r = model(d)
+        n_pairs = d["corr_pos"].shape[0]
+        init = model.workspace_view("initial_trans", n_pairs, args.n)[: n_pairs * 16].reshape(n_pairs, 4, 4).cpu().clone()
+        for k, i in enumerate(range(sl.start, sl.stop)):
+            initial[(i, n_pairs)] = init[k]          # best seed hypothesis (before refinement) of pair i in this composition
         return r["final_trans"].cpu(), r["final_labels"].cpu()
 
     whole_T, whole_L = run(slice(0, args.bs))
@@ -46,6 +52,12 @@ def main():
         rT, rL = ref["final_trans"][0], ref["final_labels"][0]
         d = lambda T: float((T - rT).abs().max())  # noqa: E731
         f = lambda L: int((L != rL).sum())  # noqa: E731
+        # where does a difference come from?  refine both best-seed hypotheses with the oracle's post_refinement
+        a, b = initial[(i, args.bs)], initial[(i, 1)]
+        ra, na = O.post_refinement(a, batch["src_keypts"][i], batch["tgt_keypts"][i], kw["inlier_threshold"])
+        rb, nb = O.post_refinement(b, batch["src_keypts"][i], batch["tgt_keypts"][i], kw["inlier_threshold"])
+        print(f"pair {i}: best-seed hypotheses differ by {float((a - b).abs().max()):.1e}; oracle refinement from each: {na} vs {nb} "
+              f"solves, results differ by {float((ra - rb).abs().max()):.1e}")
         print(f"pair {i}: |dT| vs oracle  in batch of {args.bs}: {d(whole_T[i]):.2e} ({f(whole_L[i])} flips)   of 2: {d(two_T[i - j]):.2e} "
               f"({f(two_L[i - j])})   alone: {d(one_T[0]):.2e} ({f(one_L[0])})   inliers {int(rL.sum())}")
 
