@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
 """Throughput bench of the PointDSC outlier-rejection hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config NAME]      (N>1: launched by torch.distributed.run)
 
 Metric (BASELINE.json): point-cloud pairs/sec at N=5000 correspondences.  One "step" = one pass of the whole
 hot path (pdsc_forward_testing: compat build, 12 SCNonlocal layers, seeds, per-seed solver, scoring,
-refinement) over one batch of 32 synthetic correspondence sets (BASELINE.json configs[2]) sharded over the
-GPUs (32 / N per GPU: strong scaling; `--pairs-per-gpu` fixes the per-GPU batch instead), inputs already
-resident in HBM.  Pairs are independent units: every rank processes its own shard and the only collective
-is the final all_gather of the poses (RCCL), which is inside the timed region.
+refinement) over one batch of synthetic correspondence sets sharded over the GPUs, inputs already resident in
+HBM.  Pairs are independent units: every rank processes its own shard and the only collective is the final
+all_gather of the poses (RCCL), which is inside the timed region.
+
+--config selects a BASELINE.json configuration (pointdsc_amd/workloads.py); the default n5000_b32 is configs[2], the
+one the metric is quoted on (32 pairs at N=5000: 32 / N per GPU = strong scaling; --pairs-per-gpu fixes the
+per-GPU batch instead).  n1000_b1, kitti_n5000_b16 and lomatch_n10000_b8 are configs[1], [3], [4].
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      -- the dominant kernel (sc_attention_kernel, MFMA-bound, fp32 in/fp32 acc): algorithmic
-                   flops per launch / average launch duration measured with hipEvents on the launch stream
-                   over the timed region (pdsc_profile_* in include/pointdsc_hip.h);
-  roofline_compat -- same for the compat-matrix build (HBM-write-bound), the kernel north_star names;
-  cpu_baseline  -- the CPU oracle (a torch-CPU restatement of the reference, kind "port") timed on this
-                   host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline        -- the dominant kernel (sc_attention_split_kernel, MFMA-bound: every fp32 product as three bf16
+                     MFMAs, fp32 accumulate): algorithmic flops per launch / average launch duration measured with
+                     hipEvents on the launch stream over the timed region (pdsc_profile_* in include/pointdsc_hip.h);
+  roofline_layer, roofline_compat -- the fused point-wise layer launch (matrix-pipe cycles) and the compat-matrix
+                     build (HBM-write-bound), the kernel north_star names;
+  check           -- parity of THIS run's outputs: rank 0's first pairs against the outputs of the unmodified reference
+                     on the same pairs (tests/golden/bench_<config>.npz, written by oracle/make_bench_goldens.py) and
+                     against the CPU oracle run in the cpu_baseline leg;
+  sustained       -- the same step repeated for >= --sustain-seconds after the timed region (the K timed steps of
+                     the default invocation last a fraction of a second on a power-managed chip);
+  cpu_baseline    -- the reference's CPU path timed on this host's cores on a bounded sample of the same workload
+                     (rank 0, N=1 only): the unmodified reference when /root/reference is importable (kind
+                     "reference"), else the CPU oracle in its timing mode (kind "port").
+--backend gloo runs the N>1 path with CPU-tensor collectives and all ranks on the visible GPU(s) round-robin: the
+rehearsal of the multi-GPU code path on a one-GPU box (not a scaling measurement).
 """
 from __future__ import annotations
 
@@ -35,11 +47,12 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MODEL_KW = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
-                sigma_d=0.10, k=40, nms_radius=0.10)
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
+MAX_CLOCK_GHZ = 2.4               # MI355X_MICROARCH.md: max shader clock
+ORACLE_KEYS = ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")
+REFERENCE_DIR = Path("/root/reference")      # exists in the build container only, never on the GPU box
 
 
 def log(msg):
@@ -49,114 +62,159 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline_worker(num_corr: int, pairs: int, threads: int) -> None:
-    """Child process: time the CPU oracle on `pairs` pairs of the bench workload; prints one JSON line."""
+def cpu_baseline_worker(config: str, pairs: int, threads: int, check_pairs: int) -> None:
+    """Child process: time the reference's CPU path on `pairs` pairs of the bench workload, then (untimed) run the exact
+    oracle on `check_pairs` pairs for the parity check; prints one JSON line."""
+    import warnings
+    warnings.filterwarnings("ignore")
     from oracle import pointdsc_oracle as O
-    from pointdsc_amd import PointDSC, synthetic
+    from pointdsc_amd import PointDSC, workloads
     torch.set_num_threads(threads)
-    model = PointDSC(**MODEL_KW)
-    sd = synthetic.make_state_dict(model.state_dict(), seed=6)
-    batch = synthetic.make_batch(pairs, num_corr, seed=1000, inlier_ratio=0.2)
-    okw = {k: MODEL_KW[k] for k in ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold",
-                                   "k", "nms_radius")}
+    w = workloads.WORKLOADS[config]
+    kw = dict(w["model"])
+    sd = workloads.state_dict(config, PointDSC(**kw).state_dict())
+    batch = workloads.batch(config, 0, max(pairs, check_pairs, 1))
+    okw = {k: kw[k] for k in ORACLE_KEYS}
+    kind, run = "port", None
+    if (REFERENCE_DIR / "models" / "PointDSC.py").exists():
+        try:
+            sys.path.insert(0, str(REFERENCE_DIR))
+            from models.PointDSC import PointDSC as RefPointDSC     # the unmodified reference (build container only)
+            ref = RefPointDSC(**kw).eval()
+            ref.load_state_dict(sd, strict=True)
+            kind = "reference"
+
+            def run(i):
+                return ref({"corr_pos": batch["corr_pos"][i:i + 1], "src_keypts": batch["src_keypts"][i:i + 1],
+                            "tgt_keypts": batch["tgt_keypts"][i:i + 1], "testing": True})
+        except Exception:       # noqa: BLE001
+            kind, run = "port", None
+    if run is None:
+        O.set_timing_mode(True)
+
+        def run(i):
+            return O.forward_testing(sd, batch["corr_pos"][i:i + 1], batch["src_keypts"][i:i + 1], batch["tgt_keypts"][i:i + 1], **okw)
     with torch.no_grad():
-        first = O.forward_testing(sd, batch["corr_pos"][:1], batch["src_keypts"][:1], batch["tgt_keypts"][:1], **okw)
+        run(0)                                                   # warm-up
         t1 = time.perf_counter()
         for i in range(pairs):
-            O.forward_testing(sd, batch["corr_pos"][i:i + 1], batch["src_keypts"][i:i + 1], batch["tgt_keypts"][i:i + 1], **okw)
+            run(i % batch["corr_pos"].shape[0])
         dt = time.perf_counter() - t1
-    print(json.dumps({"pairs_per_s": pairs / dt, "seconds": dt, "threads": threads,
-                      "first_trans": first["final_trans"][0].tolist()}), flush=True)
+        O.set_timing_mode(False)
+        chk = [O.forward_testing(sd, batch["corr_pos"][i:i + 1], batch["src_keypts"][i:i + 1], batch["tgt_keypts"][i:i + 1], **okw)
+               for i in range(check_pairs)]
+    print(json.dumps({"pairs_per_s": pairs / dt, "seconds": dt, "threads": threads, "kind": kind,
+                      "oracle_trans": [c["final_trans"][0].tolist() for c in chk],
+                      "oracle_labels": [torch.nonzero(c["final_labels"][0] > 0).flatten().tolist() for c in chk]}), flush=True)
 
 
 def parse():
+    from pointdsc_amd import workloads
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--num-corr", type=int, default=5000, help="N correspondences per pair (headline: 5000)")
-    ap.add_argument("--global-batch", type=int, default=32,
-                    help="pairs per step over ALL GPUs (BASELINE.json configs[2]: 32 pairs sharded over the GPUs -> strong scaling)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(workloads.WORKLOADS), default=workloads.DEFAULT,
+                    help="BASELINE.json configuration (default: configs[2], the one the metric is quoted on)")
+    ap.add_argument("--global-batch", type=int, default=0, help="override the configuration's pairs per step over ALL GPUs")
     ap.add_argument("--pairs-per-gpu", type=int, default=0,
                     help="override: fixed batch per GPU per step (weak scaling); 0 = global-batch / gpus")
     ap.add_argument("--attention-precision", choices=["bf16x3", "fp32", "bf16x3_all"], default="bf16x3",
                     help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL, one GPU per rank; gloo = rehearsal of the N>1 path with CPU-tensor collectives")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity check of this run's outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs timed on the CPU oracle (bounded sample)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="extra measured leg after the timed region (0 = off)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed on the CPU baseline (0 = sized for ~10-20 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
     ap.add_argument("--cpu-timeout", type=float, default=240.0, help="wall-clock cap for the CPU baseline leg")
-    ap.add_argument("--check", action="store_true", help="also verify rank-0's first pair against the oracle")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--check-pairs", type=int, default=2, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.num_corr, args.cpu_pairs, args.cpu_threads or (os.cpu_count() or 1))
+        cpu_baseline_worker(args.config, args.cpu_pairs, args.cpu_threads or (os.cpu_count() or 1), args.check_pairs)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    torch.cuda.set_device(local_rank)
+    if args.backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)          # rehearsal: ranks share the visible GPU(s)
     dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
-    from pointdsc_amd import PointDSC, _lib, sharding, synthetic
+    from pointdsc_amd import PointDSC, _lib, sharding, workloads
     lib = _lib.load()
+    w = workloads.WORKLOADS[args.config]
+    global_batch = args.global_batch or w["global_batch"]
     if args.pairs_per_gpu > 0:
         B, scaling = args.pairs_per_gpu, "weak"
     else:
-        if args.global_batch % world:
-            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} GPUs")
-        B, scaling = args.global_batch // world, "strong"
-    N = args.num_corr
-    model = PointDSC(**MODEL_KW)
-    sd = synthetic.make_state_dict(model.state_dict(), seed=6)
+        if global_batch % world:
+            raise SystemExit(f"global batch {global_batch} is not divisible by {world} GPUs")
+        B, scaling = global_batch // world, "strong"
+    N = w["num_corr"]
+    kw = dict(w["model"])
+    model = PointDSC(**kw)
+    sd = workloads.state_dict(args.config, model.state_dict())
     model.load_state_dict(sd)
     model = model.eval().to(dev)
     model.attention_precision = args.attention_precision
-    # each rank owns its shard of the global batch: pairs [rank*B, (rank+1)*B)
-    batch = synthetic.make_batch(B, N, seed=1000 + rank * B, inlier_ratio=0.2)
+    # each rank owns its shard of the global batch: pairs [rank*B, (rank+1)*B) of the workload's pair list
+    batch = workloads.batch(args.config, rank * B, B)
     data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     data["testing"] = True
     total_pairs = B * world
+    last = {}
 
     def step():
         with torch.no_grad():
             res = model(data)
+        last["res"] = res
+        if args.backend == "gloo" and world > 1:                 # CPU-tensor all_gather of the 64 B poses
+            return sharding.gather_results(res["final_trans"].cpu(), None, total_pairs)
         return sharding.gather_results(res["final_trans"], None, total_pairs)
 
-    log(f"rank {rank}: model + {B} pairs (N={N}) resident on {dev}; warm-up x{args.warmup}")
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}: {args.config}: model + {B} pairs (N={N}) resident on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
     log("warm-up done; timing")
 
-    n_att = args.steps * MODEL_KW["num_layers"]
-    _lib.check(lib.pdsc_profile_enable(n_att + 8), "pdsc_profile_enable")
+    n_layers = kw["num_layers"]
+    _lib.check(lib.pdsc_profile_enable(args.steps * n_layers + 8), "pdsc_profile_enable")
     _lib.check(lib.pdsc_profile_reset(), "pdsc_profile_reset")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel, from the events recorded during the timed region ----
+    # ---- roofline of the dominant kernels, from the events recorded during the timed region ----
     def read(kind):
         ms, n = C.c_double(0), C.c_int(0)
         _lib.check(lib.pdsc_profile_read(kind, C.byref(ms), C.byref(n)), "pdsc_profile_read")
@@ -166,60 +224,74 @@ def main():
     cmp_ms, cmp_n = read(1)
     lay_ms, lay_n = read(2)
     _lib.check(lib.pdsc_profile_enable(0), "pdsc_profile_enable(0)")
-    # fused layer launch (tail of layer i + head of layer i+1): 2 flop/MAC x (128*64 + 64*64 + 64*128 + 128*128 + 128*384)
-    # MACs per point; matrix-pipe cycles per 32-point tile: 600 fp32 MFMAs x 64 + 288 bf16 MFMAs x 32 (q|k|v as bf16x3)
-    lay_flops = 2.0 * 86016 * N * B
-    lay_avg = lay_ms / max(lay_n, 1) * 1e-3
-    lay_tflops = lay_flops / lay_avg / 1e12 if lay_n else None
-    lay_pipe_cycles = (600 * 64 + 288 * 32) * math.ceil(N / 32) * B / 1024.0      # per SIMD (256 CUs x 4)
-    att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
-    att_avg = att_ms / max(att_n, 1) * 1e-3
-    att_tflops = att_flops / att_avg / 1e12 if att_n else None
-    cmp_bytes = (4.0 * N * N + 24.0 * N) * B                  # SURVEY.md section 8(d): compat write + keypoint reads
-    cmp_avg = cmp_ms / max(cmp_n, 1) * 1e-3
-    cmp_gbs = cmp_bytes / cmp_avg / 1e9 if cmp_n else None
+
+    # ---- sustained leg: the same step for >= sustain_seconds (same step count on every rank) ----
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, min(2000, int(math.ceil(args.sustain_seconds / max(elapsed / args.steps, 1e-6)))))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            out = step()
+        fence()
+        sus = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([sus], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sus = float(t.item())
+        sustained = {"steps": n_sus, "seconds": round(sus, 3), "value": round(total_pairs * n_sus / sus, 3), "unit": "pairs/s"}
+        log(f"sustained leg done: {sus:.3f}s for {n_sus} steps")
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    # fused layer launch (tail of layer i + head of layer i+1): matrix-pipe cycles per 32-point tile = 600 fp32 MFMAs x 64
+    # + 288 bf16 MFMAs x 32 (q|k|v as bf16x3); 2 flop/MAC x (128*64 + 64*64 + 64*128 + 128*128 + 128*384) MACs per point
+    lay_flops = 2.0 * 86016 * N * B
+    lay_avg = lay_ms / max(lay_n, 1) * 1e-3
+    lay_pipe_cycles = (600 * 64 + 288 * 32) * math.ceil(N / 32) * B / 1024.0      # per SIMD (256 CUs x 4)
+    lay_ghz = lay_pipe_cycles / lay_avg / 1e9 if lay_n else None
+    att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
+    att_avg = att_ms / max(att_n, 1) * 1e-3
+    att_tflops = att_flops / att_avg / 1e12 if att_n else None
+    cmp_bytes = (4.0 * N * N + 24.0 * N) * B                  # SURVEY.md section 8(d): compat write + keypoint reads
+    cmp_avg = cmp_ms / max(cmp_n, 1) * 1e-3
+    cmp_gbs = cmp_bytes / cmp_avg / 1e9 if cmp_n else None
+    fp32 = args.attention_precision == "fp32"
+    att_peak = PEAK_FP32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
+
     value = total_pairs * args.steps / elapsed
+    roof = {"kernel": "sc_attention_kernel" if fp32 else "sc_attention_split_kernel", "bound": "mfma",
+            "achieved": None if att_tflops is None else round(att_tflops, 2), "peak": att_peak, "unit": "TFLOP/s",
+            "frac": None if att_tflops is None else round(att_tflops / att_peak, 4),
+            "traffic": None, "launches": att_n, "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}
+    if not fp32:
+        # `achieved` counts ALGORITHMIC flops (4 C N^2 per pair per launch) against the dense bf16 MFMA peak; the kernel
+        # executes 3 bf16 MFMAs per algorithmic product (hi*hi, hi*lo, lo*hi): its matrix-pipe share is 3 x frac.
+        roof["executed_tflops"] = None if att_tflops is None else round(3 * att_tflops, 2)
+        roof["executed_frac"] = None if att_tflops is None else round(3 * att_tflops / att_peak, 4)
     line = {
         "metric": "point-cloud pairs/sec @ N=%d corr" % N,
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
-        "dtype": "f32" if args.attention_precision == "fp32" else "f32 (attention products as bf16x3 split, f32 accumulate)",
+        "dtype": "f32" if fp32 else "f32 (attention products as bf16x3 split, f32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "3DMatch-like synthetic correspondences (BASELINE.json configs[2]): N=%d corr, %d pairs per "
-                               "step sharded over %d GPU(s) = %d per GPU, 12-layer PointDSC, seeded random weights"
-                               % (N, total_pairs, world, B),
-                   "num_corr": N, "pairs_per_gpu": B, "global_batch": total_pairs,
-                   "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses" % world},
-        "roofline": ({"kernel": "sc_attention_kernel", "bound": "mfma",
-                      "achieved": None if att_tflops is None else round(att_tflops, 2),
-                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                      "frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                      "traffic": None, "launches": att_n,
-                      "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}
-                     if args.attention_precision == "fp32" else
-                     # split precision: `achieved` counts ALGORITHMIC flops (4 C N^2 per pair per launch) against the
-                     # dense bf16 MFMA peak; the kernel executes 3 bf16 MFMAs per algorithmic product (hi*hi, hi*lo,
-                     # lo*hi), so its matrix-pipe utilisation is 3 x frac (`executed_frac`).
-                     {"kernel": "sc_attention_split_kernel", "bound": "mfma",
-                      "achieved": None if att_tflops is None else round(att_tflops, 2),
-                      "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                      "frac": None if att_tflops is None else round(att_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
-                      "executed_tflops": None if att_tflops is None else round(3 * att_tflops, 2),
-                      "executed_frac": None if att_tflops is None else round(3 * att_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
-                      "equivalent_fp32_mfma_frac": None if att_tflops is None else round(att_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                      "traffic": None, "launches": att_n,
-                      "avg_launch_ms": round(att_avg * 1e3, 4), "flops_per_launch": att_flops}),
-        "roofline_layer": {"kernel": "layer_wave_kernel", "bound": "mfma",
-                           "achieved": None if lay_tflops is None else round(lay_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": None if lay_tflops is None else round(lay_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                           "matrix_pipe_busy_frac_at_2.4GHz": None if not lay_n else round(lay_pipe_cycles / (lay_avg * 2.4e9), 4),
+        "config": {"workload": "%s: N=%d corr, %d pairs per step sharded over %d GPU(s) = %d per GPU, 12-layer PointDSC, "
+                               "seeded random weights" % (w["label"], N, total_pairs, world, B),
+                   "name": args.config, "num_corr": N, "pairs_per_gpu": B, "global_batch": total_pairs,
+                   "sigma_d": kw["sigma_d"], "inlier_threshold": kw["inlier_threshold"],
+                   "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s)"
+                                  % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU")},
+        "roofline": roof,
+        # matrix-pipe issue cycles the launch needs per SIMD / its duration, against a pipe that is busy every cycle at
+        # the maximum clock (the chip runs this kernel at 1.6-2.0 GHz: PMC summaries under profiles/)
+        "roofline_layer": {"kernel": "layer_wave_kernel" if not lib.pdsc_layer_prefers_block(B, N) else "layer_fused_kernel",
+                           "bound": "mfma", "achieved": None if lay_ghz is None else round(lay_ghz, 4), "peak": MAX_CLOCK_GHZ,
+                           "unit": "G matrix-pipe cycles/s per SIMD",
+                           "frac": None if lay_ghz is None else round(lay_ghz / MAX_CLOCK_GHZ, 4),
                            "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
                            "flops_per_launch": lay_flops},
         "roofline_compat": {"kernel": "compat_sym_kernel", "bound": "hbm",
@@ -228,39 +300,65 @@ def main():
                             "traffic": None, "launches": cmp_n, "avg_launch_ms": round(cmp_avg * 1e3, 4),
                             "bytes_per_launch": cmp_bytes},
     }
+    if sustained is not None:
+        line["sustained"] = sustained
     traffic_file = ROOT / "profiles" / "traffic.json"      # PMC-derived HBM bytes per launch, if collected
     if traffic_file.exists():
         try:
             tj = json.loads(traffic_file.read_text())
-            key = f"N{N}_B{B}"
+            key = f"{args.config}_B{B}"
             if key in tj:
                 line["roofline"]["traffic"] = tj[key].get(line["roofline"]["kernel"])
                 line["roofline_compat"]["traffic"] = tj[key].get("compat_sym_kernel")
-                line["roofline_layer"]["traffic"] = tj[key].get("layer_wave_kernel")
+                line["roofline_layer"]["traffic"] = tj[key].get(line["roofline_layer"]["kernel"])
         except Exception:
             pass
 
-    # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N=1 only), in a child
-    #      process with a wall-clock cap so the bench always finishes ----
+    # ---- parity of this run's outputs, part 1: against the unmodified reference's outputs on the same pairs ----
+    res = last["res"]
+    check = None
+    if not args.no_check:
+        check = {}
+        gold = ROOT / "tests" / "golden" / f"bench_{args.config}.npz"
+        if gold.exists():
+            import numpy as np
+            fx = np.load(gold, allow_pickle=False)
+            g = min(B, fx["ref_final_trans"].shape[0])
+            want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:g, :N].astype(np.float32))
+            got_T, got_lab = res["final_trans"][:g].cpu(), res["final_labels"][:g].cpu()
+            check.update(pairs_vs_reference=g, max_abs_dT_vs_reference=float((got_T - torch.from_numpy(fx["ref_final_trans"][:g])).abs().max()),
+                         label_flips_vs_reference=int((got_lab != want_lab).sum()),
+                         reference_outputs="tests/golden/bench_%s.npz (unmodified reference, oracle/make_bench_goldens.py)" % args.config)
+
+    # ---- CPU baseline: the reference's CPU path on this host's cores, bounded sample (rank 0, N=1 only), in a child
+    #      process with a wall-clock cap so the bench always finishes; the same child runs the exact oracle on the
+    #      first pairs for part 2 of the check ----
     if world == 1 and not args.no_cpu_baseline:
         import subprocess
         # 32 intra-op threads is the fastest setting measured on the 256-core GPU box (16: 0.42, 32: 0.59, 64: 0.33,
         # 128: 0.19 pairs/s; 256 threads did not finish 3 pairs in 240 s), so that is what the baseline gets
         cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
-        n_cpu = max(1, min(args.cpu_pairs, B))
-        log(f"CPU baseline: oracle on {n_cpu} pair(s), {cores} threads (cap {args.cpu_timeout:.0f}s)")
-        cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-worker", "--num-corr", str(N),
-               "--cpu-pairs", str(n_cpu), "--cpu-threads", str(cores)]
-        sample = ("%d pair(s) of the same N=%d workload after 1 warm-up, torch-CPU oracle "
-                  "(oracle/pointdsc_oracle.py), %d intra-op threads" % (n_cpu, N, cores))
+        n_cpu = args.cpu_pairs or {1000: 64, 5000: 6, 10000: 2}.get(N, 4)
+        n_chk = 0 if args.no_check else min(B, args.check_pairs if N <= 5000 else 1)
+        log(f"CPU baseline: {n_cpu} pair(s), {cores} threads (cap {args.cpu_timeout:.0f}s); exact oracle on {n_chk} pair(s) for the check")
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-worker", "--config", args.config,
+               "--cpu-pairs", str(n_cpu), "--cpu-threads", str(cores), "--check-pairs", str(n_chk)]
+        sample = "%d pair(s) of the same workload (%s, N=%d, bs=1 loop) after 1 warm-up, %d intra-op threads" % (n_cpu, args.config, N, cores)
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout)
             cj = json.loads(r.stdout.strip().splitlines()[-1])
+            what = ("unmodified reference imported from /root/reference" if cj["kind"] == "reference"
+                    else "torch-CPU oracle (oracle/pointdsc_oracle.py, timing mode = the reference's own ops)")
             line["cpu_baseline"] = {"value": round(cj["pairs_per_s"], 4), "unit": "pairs/s", "cores": cores,
-                                    "kind": "port", "sample": sample}
-            if args.check:
-                dT = float((out["final_trans"][0].cpu() - torch.tensor(cj["first_trans"])).abs().max())
-                line["check"] = {"max_abs_dT_vs_oracle": dT}
+                                    "kind": cj["kind"], "sample": sample + ", " + what}
+            if check is not None and n_chk:
+                dT, flips = 0.0, 0
+                for i in range(n_chk):
+                    dT = max(dT, float((res["final_trans"][i].cpu() - torch.tensor(cj["oracle_trans"][i])).abs().max()))
+                    lab = torch.zeros(N)
+                    lab[torch.tensor(cj["oracle_labels"][i], dtype=torch.long)] = 1.0
+                    flips += int((res["final_labels"][i].cpu() != lab).sum())
+                check.update(pairs_vs_oracle=n_chk, max_abs_dT_vs_oracle=dT, label_flips_vs_oracle=flips)
         except subprocess.TimeoutExpired:
             line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": cores, "kind": "port",
                                     "sample": sample + " -- did not finish within %.0fs" % args.cpu_timeout}
@@ -268,6 +366,11 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": cores, "kind": "port",
                                     "sample": sample + " -- failed: %r" % (e,)}
         log("CPU baseline done")
+    if check is not None:
+        dts = [check[k] for k in ("max_abs_dT_vs_reference", "max_abs_dT_vs_oracle") if k in check]
+        fl = [check[k] for k in ("label_flips_vs_reference", "label_flips_vs_oracle") if k in check]
+        check["ok"] = bool(dts) and max(dts) < 1e-4 and sum(fl) == 0       # north_star: masks bit-exact, R/t within 1e-4
+        line["check"] = check
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -50,6 +50,15 @@ CASES = [
     dict(name="kitti_n1500_s4", N=1500, pair=dict(seed=4, inlier_ratio=0.3, scale=60.0, noise=0.1), wseed=4,
          model=dict(inlier_threshold=0.6, sigma_d=1.2, nms_radius=0.6), full=False),
     dict(name="n5000_s5", N=5000, pair=dict(seed=5, inlier_ratio=0.2), wseed=5, model=dict(), full=False),
+    # BASELINE.json configs[3]: KITTI odometry, N=5000, sigma_d=1.2 m, inlier_threshold=0.6 m (evaluation/test_KITTI.py:166-170,188)
+    # (these two seeded weight sets put every logit below zero at the default shift, i.e. all seeds would come from the tied
+    #  zero keys of the non-maxima in backend-defined order -- SURVEY.md App. B probe 2; logit_shift="median" centres the
+    #  logits like a trained model's so that the seeds are local maxima with distinct positive keys)
+    dict(name="kitti_n5000_s8", N=5000, pair=dict(seed=8, inlier_ratio=0.25, scale=60.0, noise=0.1), wseed=8,
+         model=dict(inlier_threshold=0.6, sigma_d=1.2, nms_radius=0.6), full=False, logit_shift="median"),
+    # BASELINE.json configs[4]: 3DLoMatch, N=10000 (evaluation/test_3DLoMatch.py:268-277); low-overlap pairs = low inlier ratio
+    dict(name="lomatch_n10000_s7", N=10000, pair=dict(seed=7, inlier_ratio=0.15), wseed=7, model=dict(), full=False,
+         logit_shift="median"),
 ]
 BASE_MODEL = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
                   inlier_threshold=0.10, sigma_d=0.10, k=40, nms_radius=0.10)
@@ -60,8 +69,24 @@ def build_models(case):
     from models.PointDSC import PointDSC as RefPointDSC  # the unmodified reference
     kw = dict(BASE_MODEL, **case["model"])
     tmpl = AmdPointDSC(**kw)
-    sd = synthetic.make_state_dict(tmpl.state_dict(), seed=case["wseed"], randomize_bn=case.get("randomize_bn", True))
     ref = RefPointDSC(**kw)
+    shift = case.get("logit_shift", synthetic.DEFAULT_LOGIT_SHIFT)
+    if shift == "median":
+        # centre the reference's own logits on this case's inputs: shift = -median(logits at shift 0), 4 decimals
+        sd0 = synthetic.make_state_dict(tmpl.state_dict(), seed=case["wseed"], randomize_bn=case.get("randomize_bn", True),
+                                        logit_shift=0.0)
+        ref.load_state_dict(sd0, strict=True)
+        ref.eval()
+        pair = synthetic.make_pair(case["N"], **case["pair"])
+        with torch.no_grad():
+            d = torch.norm(pair["src_keypts"][:, :, None, :] - pair["src_keypts"][:, None, :, :], dim=-1)
+            c = d - torch.norm(pair["tgt_keypts"][:, :, None, :] - pair["tgt_keypts"][:, None, :, :], dim=-1)
+            c = torch.clamp(1.0 - c ** 2 / ref.sigma_spat ** 2, min=0)
+            feat = ref.encoder(pair["corr_pos"].permute(0, 2, 1), c)
+            shift = round(-float(ref.classification(feat).median()), 4)
+    case["_logit_shift"] = float(shift)
+    sd = synthetic.make_state_dict(tmpl.state_dict(), seed=case["wseed"], randomize_bn=case.get("randomize_bn", True),
+                                   logit_shift=float(shift))
     ref.load_state_dict(sd, strict=True)
     ref.eval()
     return ref, sd, kw
@@ -140,6 +165,7 @@ def run_case(case):
         corr_pos=corr.numpy(), src_keypts=src.numpy(), tgt_keypts=tgt.numpy(),
         gt_trans=pair["gt_trans"].numpy(), gt_labels=pair["gt_labels"].numpy(),
         wseed=np.int64(case["wseed"]), randomize_bn=np.bool_(case.get("randomize_bn", True)),
+        **({"logit_shift": np.float64(case["_logit_shift"])} if "logit_shift" in case else {}),
         model_json=np.array(json.dumps(kw)), tie_case=np.bool_(case.get("tie_case", False)),
         weights_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
         ref_final_trans=res["final_trans"].numpy(), ref_final_labels=res["final_labels"].numpy(),

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Reference outputs for the first pairs of every bench workload (pointdsc_amd/workloads.py).
+
+Run in the BUILD container only (imports the unmodified reference from /root/reference):
+
+    python oracle/make_bench_goldens.py            # writes tests/golden/bench_<workload>.npz + BENCH_PINNING.json
+
+For each BASELINE.json configuration it
+  1. (workloads whose logit shift is not fixed) measures the shift that centres the REFERENCE's logits on pair 0
+     and prints the line to freeze in workloads.MEASURED_LOGIT_SHIFT,
+  2. runs the reference ``PointDSC.forward`` (testing mode, CPU, bs=1 loop -- the reference's only testing mode,
+     models/PointDSC.py:210) on the first GOLDEN_PAIRS pairs of the workload,
+  3. runs the oracle on the same pairs and records the agreement (this is the oracle's pin at the bench sizes),
+  4. stores the reference outputs (poses + bit-packed labels) and input checksums.
+The GPU tests compare ``pdsc_forward_testing`` on the WHOLE bench batch (the launch plans bench.py times) with these.
+"""
+from __future__ import annotations
+
+import json
+import sys
+import time
+import warnings
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference")
+
+from oracle import pointdsc_oracle as O  # noqa: E402
+from pointdsc_amd import workloads  # noqa: E402
+from pointdsc_amd.model import PointDSC as AmdPointDSC  # noqa: E402  (state_dict template only)
+
+GOLDEN = ROOT / "tests" / "golden"
+GOLDEN_PAIRS = 4
+ORACLE_KEYS = ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(8)
+    sys.path.insert(0, str(REF))
+    from models.PointDSC import PointDSC as RefPointDSC  # the unmodified reference
+    only = sys.argv[1:]
+    report = json.loads((GOLDEN / "BENCH_PINNING.json").read_text()) if (GOLDEN / "BENCH_PINNING.json").exists() else {}
+    ok = True
+    for name, w in workloads.WORKLOADS.items():
+        if only and name not in only:
+            continue
+        kw = dict(w["model"])
+        tmpl = AmdPointDSC(**kw).state_dict()
+        ref = RefPointDSC(**kw).eval()
+        G = min(GOLDEN_PAIRS, w["global_batch"])
+        batch = workloads.batch(name, 0, G)
+        if w["logit_shift"] is None:
+            ref.load_state_dict(workloads.state_dict(name, tmpl, shift=0.0), strict=True)
+            with torch.no_grad():
+                src, tgt = batch["src_keypts"][:1], batch["tgt_keypts"][:1]
+                d = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
+                c = d - torch.norm(tgt[:, :, None, :] - tgt[:, None, :, :], dim=-1)
+                c = torch.clamp(1.0 - c ** 2 / ref.sigma_spat ** 2, min=0)
+                logits = ref.classification(ref.encoder(batch["corr_pos"][:1].permute(0, 2, 1), c))
+            shift = round(-float(logits.median()), 4)
+            frozen = workloads.MEASURED_LOGIT_SHIFT.get(name)
+            print(f'    "{name}": {shift},        # freeze in workloads.MEASURED_LOGIT_SHIFT (currently {frozen})')
+            if frozen is not None and frozen != shift:
+                raise SystemExit(f"{name}: frozen logit shift {frozen} != measured {shift}")
+        else:
+            shift = float(w["logit_shift"])
+        sd = workloads.state_dict(name, tmpl, shift=shift)
+        ref.load_state_dict(sd, strict=True)
+        trans, labels, rep = [], [], {"num_corr": w["num_corr"], "logit_shift": shift, "pairs": []}
+        for i in range(G):
+            one = {k: batch[k][i:i + 1] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                res = ref(dict(one, testing=True))
+                t_ref = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                ores = O.forward_testing(sd, one["corr_pos"], one["src_keypts"], one["tgt_keypts"],
+                                         **{k: kw[k] for k in ORACLE_KEYS})
+                t_or = time.perf_counter() - t0
+            trans.append(res["final_trans"][0].numpy())
+            labels.append(res["final_labels"][0].numpy() > 0)
+            re, te = O.registration_errors(res["final_trans"][0], batch["gt_trans"][i])
+            p = dict(pair=i, oracle_dT=float((ores["final_trans"] - res["final_trans"]).abs().max()),
+                     oracle_label_flips=int((ores["final_labels"] != res["final_labels"]).sum()),
+                     ref_inliers=int(res["final_labels"].sum()), gt_inliers=int(batch["gt_labels"][i].sum()),
+                     ref_RE_deg=re, ref_TE_cm=te, ref_seconds=round(t_ref, 2), oracle_seconds=round(t_or, 2))
+            rep["pairs"].append(p)
+            print(name, json.dumps(p), flush=True)
+            if p["oracle_label_flips"] != 0 or p["oracle_dT"] >= 1e-4 or re > 1.0:
+                ok = False
+                print("  !! pin violated")
+        np.savez_compressed(
+            GOLDEN / f"bench_{name}.npz",
+            ref_final_trans=np.stack(trans), ref_final_labels_bits=np.packbits(np.stack(labels), axis=1),
+            logit_shift=np.float64(shift), num_corr=np.int64(w["num_corr"]),
+            input_checksum=np.array([float(batch[k].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts")]),
+            weights_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
+            gt_trans=batch["gt_trans"].numpy())
+        report[name] = rep
+    (GOLDEN / "BENCH_PINNING.json").write_text(json.dumps(report, indent=1))
+    print("oracle pinned against the reference on the bench workloads" if ok else "ORACLE DISAGREES WITH THE REFERENCE")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

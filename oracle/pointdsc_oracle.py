@@ -35,6 +35,18 @@ import torch
 
 BN_EPS = 1e-5  # nn.BatchNorm1d default, used by every BN in the reference model
 
+# Timing mode (bench.py's cpu_baseline leg ONLY): the N x N distance stages call the reference's own ops
+# (torch.norm of the broadcast difference, models/PointDSC.py:151-152,327) instead of the fp64-emulated fma / sqrt
+# chain below, which exists to make thresholds bit-reproducible and costs ~1.35x the reference's run time.  Results
+# in timing mode agree with the exact mode to the last ulp or two of a distance; parity checks never use it.
+_TIMING_MODE = False
+
+
+def set_timing_mode(on: bool) -> None:
+    global _TIMING_MODE
+    _TIMING_MODE = bool(on)
+
+
 
 # --------------------------------------------------------------------------------------------------
 # a-1: pairwise distances and the spatial-consistency matrix (reference models/PointDSC.py:150-153)
@@ -59,6 +71,8 @@ def pairwise_dist(x: torch.Tensor) -> torch.Tensor:
     kernels use (``fmaf``), so distance thresholds are decided on identical bits.
     """
     d = x[:, None, :] - x[None, :, :]
+    if _TIMING_MODE:
+        return torch.norm(d, dim=-1)
     dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
     return _sqrt32(_fma32(dz, dz, _fma32(dy, dy, dx * dx)))
 
@@ -245,6 +259,8 @@ def residuals(trans: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor) -> torc
     """trans [S,4,4] -> L2 [S,N] = || R_s src + t_s - tgt ||."""
     pred = torch.einsum("snm,mk->snk", trans[:, :3, :3], src.t()) + trans[:, :3, 3:4]
     d = pred.permute(0, 2, 1) - tgt[None]
+    if _TIMING_MODE:
+        return torch.norm(d, dim=-1)
     dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
     return _sqrt32(_fma32(dz, dz, _fma32(dy, dy, dx * dx)))
 

@@ -60,8 +60,11 @@ def make_batch(batch: int, num_corr: int, seed: int = 0, **kw):
     return {k: torch.cat([p[k] for p in pairs], dim=0).contiguous() for k in pairs[0]}
 
 
+DEFAULT_LOGIT_SHIFT = 0.05
+
+
 def make_state_dict(template: dict, seed: int = 0, randomize_bn: bool = True,
-                    logit_shift: float = 0.05) -> dict:
+                    logit_shift: float = DEFAULT_LOGIT_SHIFT, logit_sign: float = 1.0) -> dict:
     """Fill a PointDSC ``state_dict`` (reference key layout) with seeded values.
 
     Conv weights: Xavier-normal like the reference initialiser (reference models/PointDSC.py:116-121);
@@ -69,7 +72,9 @@ def make_state_dict(template: dict, seed: int = 0, randomize_bn: bool = True,
     test weight).  With ``randomize_bn`` the BatchNorm affine parameters and running statistics are
     perturbed so that BN folding is actually exercised (default init makes BN the identity up to eps)
     and ``classification.4.bias`` is shifted so that logits straddle zero like a trained model's
-    (second probe).
+    (second probe).  ``logit_sign=-1`` negates the last classification layer: a random head
+    ranks the (attention-clustered) inliers either first or last; a trained one ranks them first, which is what
+    makes the confidence-ranked seeds useful -- workloads whose seeded head happens to rank them last flip it.
     """
     rs = np.random.RandomState(10_000 + seed)
     out = {}
@@ -94,5 +99,8 @@ def make_state_dict(template: dict, seed: int = 0, randomize_bn: bool = True,
             v = rs.standard_normal(shape) * 0.05
         out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32)).reshape(shape).contiguous()
     if "classification.4.bias" in out:
+        if logit_sign != 1.0:
+            out["classification.4.weight"] = out["classification.4.weight"] * logit_sign
+            out["classification.4.bias"] = out["classification.4.bias"] * logit_sign
         out["classification.4.bias"] = out["classification.4.bias"] + logit_shift
     return out

@@ -1,0 +1,77 @@
+"""The BASELINE.json configurations as seeded synthetic workloads.
+
+One table shared by ``bench.py`` (what is timed), ``oracle/make_bench_goldens.py`` (what the unmodified reference
+returns for the first pairs of each workload, committed under ``tests/golden/bench_*.npz``) and the GPU parity tests
+(the timed path is compared with those reference outputs), so that the numbers in a bench line and the parity
+claim next to it are about the same pairs, weights and launch plans.
+
+Real data and released weights are absent on both boxes: the pairs follow
+SURVEY.md section 8(d) (``synthetic.make_pair``), the weights are seeded (``synthetic.make_state_dict``) and their
+logits are centred per workload (``logit_shift``) so that seeds are picked among local maxima with distinct positive
+keys, as a trained model's are -- with every logit negative the reference takes its seeds from the tied zero keys in
+backend-defined order (probe 2).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import synthetic
+
+BASE_MODEL = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
+                  sigma_d=0.10, k=40, nms_radius=0.10)
+# reference evaluation/test_KITTI.py:166-170,188: inlier_threshold 0.6 m, sigma_d 1.2 m (nms_radius = inlier_threshold)
+KITTI_MODEL = dict(BASE_MODEL, inlier_threshold=0.6, sigma_d=1.2, nms_radius=0.6)
+
+WORKLOADS: Dict[str, dict] = {
+    # BASELINE.json configs[1]: 3DMatch test, N=1000, batch 1 on one GPU
+    "n1000_b1": dict(baseline_config=1, num_corr=1000, global_batch=1, model=BASE_MODEL, wseed=6, logit_shift=0.05,
+                     pair=dict(inlier_ratio=0.2, noise=0.01, scale=3.0), seed0=1000,
+                     label="3DMatch-like synthetic correspondences (BASELINE.json configs[1])"),
+    # BASELINE.json configs[2] (the headline metric): N=5000, 32 pairs sharded over the GPUs
+    "n5000_b32": dict(baseline_config=2, num_corr=5000, global_batch=32, model=BASE_MODEL, wseed=6, logit_shift=0.05,
+                      pair=dict(inlier_ratio=0.2, noise=0.01, scale=3.0), seed0=1000,
+                      label="3DMatch-like synthetic correspondences (BASELINE.json configs[2])"),
+    # BASELINE.json configs[3]: KITTI odometry, N=5000, sigma_d=1.2 m, 16 pairs
+    # (logit_sign=-1: this seeded head ranks the inlier cluster LAST -- 0.2 % inliers among the confidence-ranked seeds and
+    #  the reference itself fails on 3 of the first 4 pairs; negated it ranks them first, like a trained head)
+    "kitti_n5000_b16": dict(baseline_config=3, num_corr=5000, global_batch=16, model=KITTI_MODEL, wseed=8,
+                            logit_shift=None, logit_sign=-1.0, pair=dict(inlier_ratio=0.25, noise=0.1, scale=60.0), seed0=3000,
+                            label="KITTI-like synthetic correspondences (BASELINE.json configs[3]: 60 m scale, "
+                                  "sigma_d=1.2 m, inlier_threshold=0.6 m)"),
+    # BASELINE.json configs[4]: 3DLoMatch, N=10000, 8 pairs (low overlap = low inlier ratio)
+    "lomatch_n10000_b8": dict(baseline_config=4, num_corr=10000, global_batch=8, model=BASE_MODEL, wseed=7,
+                              logit_shift=None, pair=dict(inlier_ratio=0.15, noise=0.01, scale=3.0), seed0=4000,
+                              label="3DLoMatch-like synthetic correspondences (BASELINE.json configs[4])"),
+}
+DEFAULT = "n5000_b32"
+
+# logit shifts of the workloads whose table entry says None: measured once by oracle/make_bench_goldens.py with the
+# unmodified reference (shift = -median of the reference's logits over the first golden pairs at shift 0, 4 decimals)
+# and frozen here so that every box builds the same weights.
+MEASURED_LOGIT_SHIFT: Dict[str, float] = {
+    "kitti_n5000_b16": -1.8915,
+    "lomatch_n10000_b8": 0.4779,
+}
+
+
+def logit_shift(name: str) -> float:
+    w = WORKLOADS[name]
+    if w["logit_shift"] is not None:
+        return float(w["logit_shift"])
+    if name not in MEASURED_LOGIT_SHIFT:
+        raise KeyError(f"workload {name}: logit shift not measured yet (run oracle/make_bench_goldens.py)")
+    return MEASURED_LOGIT_SHIFT[name]
+
+
+def state_dict(name: str, template: dict, shift: float | None = None) -> dict:
+    w = WORKLOADS[name]
+    return synthetic.make_state_dict(template, seed=w["wseed"], logit_shift=logit_shift(name) if shift is None else shift,
+                                     logit_sign=w.get("logit_sign", 1.0))
+
+
+def batch(name: str, first: int, count: int) -> Dict[str, torch.Tensor]:
+    """Pairs [first, first+count) of the workload's global pair list (pair i is seeded seed0 + i)."""
+    w = WORKLOADS[name]
+    return synthetic.make_batch(count, w["num_corr"], seed=w["seed0"] + first, **w["pair"])

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import pointdsc_oracle as O
-from pointdsc_amd import PointDSC, ops, synthetic
+from pointdsc_amd import PointDSC, _lib, ops, synthetic, workloads
 
 pytestmark = pytest.mark.gpu
 
@@ -376,6 +376,41 @@ def test_layer_fused_x3_merges_attention_partials(n, bs, nsplit):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 2), (1000, 2, 3), (300, 3, 4), (5000, 2, 2)])
+def test_layer_fused_frag_merges_attention_partials(n, bs, nsplit):
+    """pdsc_layer_fused_frag = layer_wave_kernel (the kernel the bench times) fed the UN-MERGED key-split partials
+    (part_o / part_ml, nsplit 2..4) == the same kernel fed the merged msg of the combine kernel, and == the fp64 merge."""
+    gen = torch.Generator().manual_seed(n + 1)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    batch = synthetic.make_batch(bs, n, seed=5 + n)
+    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    qkv = torch.cat([rnd(bs * n, 128) * 0.3 * QSCALE, rnd(bs * n, 128) * 0.3, rnd(bs * n, 128)], dim=-1)
+    qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+    msg = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit)
+    partials = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit, merge=False)
+    res = rnd(bs * n, 128)
+    tail_w = [g(x) for x in (rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128))]
+    head_w = [g(x) for x in (rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384))]
+    a = ops.layer_fused_split(msg, g(res), None, tail_w, head_w, bs, n, want_qkv=True, frag=True)
+    b = ops.layer_fused_split(None, g(res), None, tail_w, head_w, bs, n, want_qkv=True, frag=True, partials=partials)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # fp64 merge of the raw partials: msg = sum_s o_s 2^(m_s - m) / sum_s l_s 2^(m_s - m)
+    scratch, ns = partials
+    npad = (n + 255) // 256 * 256
+    flat = scratch.view(torch.float32).cpu().double()
+    po = flat[: bs * ns * npad * 128].reshape(bs, ns, npad, 128)[:, :, :n]
+    ml = flat[bs * ns * npad * 128: bs * ns * npad * 130].reshape(bs, ns, npad, 2)[:, :, :n]
+    m = ml[..., 0].max(dim=1, keepdim=True).values
+    wgt = torch.exp2(ml[..., 0] - m)
+    want = ((po * wgt[..., None]).sum(1) / (ml[..., 1] * wgt).sum(1)[..., None]).reshape(bs * n, 128)
+    assert (msg.cpu().double() - want).abs().max() < 1e-6 * max(1.0, float(want.abs().max()))
+    d = lambda t: t.cpu().double()  # noqa: E731
+    feat = d(res) + (torch.relu(torch.relu(want @ d(tail_w[0]).T + d(tail_w[1])) @ d(tail_w[2]).T + d(tail_w[3])) @ d(tail_w[4]).T
+                     + d(tail_w[5]))
+    assert (d(b[0]) - feat).abs().max() < 2e-5 * max(1.0, float(feat.abs().max()))
+
+
 def _attention_split_model(q, k, v, compat):
     """fp64 evaluation of the split arithmetic: S = qh kh + qh kl + ql kh; O = (P V) with V = vh + vl."""
     (qh, ql), (kh, kl), (vh, vl) = _split(q), _split(k), _split(v)
@@ -694,21 +729,110 @@ def test_forward_matches_oracle(n, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_all"])
-@pytest.mark.parametrize("name", ["n257_s0", "n1000_s1", "n1000_s2_defaultbn", "n2053_s3", "kitti_n1500_s4", "n5000_s5"])
+@pytest.mark.parametrize("name", ["n257_s0", "n1000_s1", "n1000_s2_defaultbn", "n2053_s3", "kitti_n1500_s4", "n5000_s5",
+                                  "kitti_n5000_s8", "lomatch_n10000_s7"])
 def test_forward_matches_reference_golden(name, precision):
-    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
-    kw = json.loads(str(fx["model_json"]))
-    model = PointDSC(**kw)
-    sd = synthetic.make_state_dict(model.state_dict(), seed=int(fx["wseed"]), randomize_bn=bool(fx["randomize_bn"]))
-    model.load_state_dict(sd)
-    model = model.eval().to(DEV)
+    """Outputs of the unmodified reference (oracle/check_against_reference.py) incl. BASELINE.json configs[3] (KITTI,
+    N=5000, sigma_d=1.2, threshold 0.6: evaluation/test_KITTI.py:166-170,188) and configs[4] (N=10000) sizes."""
+    model, batch, fx = _golden_model_and_pair(name)
     model.attention_precision = precision
-    batch = {k: torch.from_numpy(fx[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     res = _forward(model, batch)
     flips = int((res["final_labels"].cpu() != torch.from_numpy(fx["ref_final_labels"])).sum())
     dT = float((res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().max())
     assert flips == 0, f"{flips} label flips vs the reference"
     assert dT < (1e-3 if bool(fx["tie_case"]) else 1e-4), dT
+
+
+def _golden_model_and_pair(name):
+    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    kw = json.loads(str(fx["model_json"]))
+    model = PointDSC(**kw)
+    shift = float(fx["logit_shift"]) if "logit_shift" in fx.files else synthetic.DEFAULT_LOGIT_SHIFT
+    sd = synthetic.make_state_dict(model.state_dict(), seed=int(fx["wseed"]), randomize_bn=bool(fx["randomize_bn"]),
+                                   logit_shift=shift)
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(fx["weights_checksum"])) < 1e-6
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    batch = {k: torch.from_numpy(fx[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    return model, batch, fx
+
+
+@pytest.mark.parametrize("name,bs,pos", [("n5000_s5", 4, 1), ("n5000_s5", 8, 7), ("n5000_s5", 16, 0), ("n5000_s5", 32, 19),
+                                         ("kitti_n5000_s8", 2, 1), ("kitti_n5000_s8", 16, 5),
+                                         ("lomatch_n10000_s7", 2, 0), ("lomatch_n10000_s7", 8, 6)])
+def test_reference_golden_pair_inside_a_batch(name, bs, pos):
+    """The golden pair (reference output known) placed at position `pos` of a batch of bs pairs: the per-GPU shares of
+    BASELINE.json configs[2..4] on 8/4/2/1 GPUs.  The batch size selects the launch plans (attention key split, layer
+    kernel variant, merge of the partials) -- the result of a pair must not depend on its neighbours beyond 1e-4."""
+    model, one, fx = _golden_model_and_pair(name)
+    n = one["corr_pos"].shape[1]
+    kw = json.loads(str(fx["model_json"]))
+    scale = 60.0 if kw["sigma_d"] > 1.0 else 3.0
+    fill = synthetic.make_batch(bs, n, seed=7000 + bs, inlier_ratio=0.25, scale=scale, noise=scale / 300.0)
+    batch = {k: fill[k].clone() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    for k in batch:
+        batch[k][pos] = one[k][0]
+    res = _forward(model, batch)
+    flips = int((res["final_labels"][pos].cpu() != torch.from_numpy(fx["ref_final_labels"])[0]).sum())
+    dT = float((res["final_trans"][pos].cpu() - torch.from_numpy(fx["ref_final_trans"])[0]).abs().max())
+    assert flips == 0, f"{flips} label flips vs the reference"
+    assert dT < 1e-4, dT
+
+
+_BENCH_MODELS = {}
+
+
+def _bench_model(name):
+    if name not in _BENCH_MODELS:
+        w = workloads.WORKLOADS[name]
+        model = PointDSC(**w["model"])
+        sd = workloads.state_dict(name, model.state_dict())
+        fx = np.load(GOLDEN / f"bench_{name}.npz", allow_pickle=False)
+        assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(fx["weights_checksum"])) < 1e-6
+        model.load_state_dict(sd)
+        _BENCH_MODELS[name] = (model.eval().to(DEV), fx)
+    return _BENCH_MODELS[name]
+
+
+@pytest.mark.parametrize("name,bs", [("n1000_b1", 1),
+                                     ("n5000_b32", 4), ("n5000_b32", 8), ("n5000_b32", 16), ("n5000_b32", 32),
+                                     ("kitti_n5000_b16", 2), ("kitti_n5000_b16", 4), ("kitti_n5000_b16", 8), ("kitti_n5000_b16", 16),
+                                     ("lomatch_n10000_b8", 1), ("lomatch_n10000_b8", 2), ("lomatch_n10000_b8", 4), ("lomatch_n10000_b8", 8)])
+def test_bench_workload_matches_reference_golden(name, bs):
+    """THE TIMED PATH: the first bs pairs of a bench workload (bs = the per-GPU share on 8/4/2/1 GPUs; bs = global batch
+    is exactly what `bench.py --config name` times on one GPU, same pairs, same weights, same launch plans) against
+    the outputs of the unmodified reference on those pairs (oracle/make_bench_goldens.py, reference
+    models/PointDSC.py:128-197 looped per pair): inlier masks bit-exact, R/t within 1e-4."""
+    model, fx = _bench_model(name)
+    w = workloads.WORKLOADS[name]
+    n = w["num_corr"]
+    batch = workloads.batch(name, 0, bs)
+    g_pairs = min(bs, fx["ref_final_trans"].shape[0])
+    chk = np.array([float(batch[k][:fx["ref_final_trans"].shape[0]].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts")])
+    if bs >= fx["ref_final_trans"].shape[0]:
+        assert np.allclose(chk, fx["input_checksum"], rtol=0, atol=1e-6), "synthetic inputs differ from the fixture's"
+    res = _forward(model, batch)
+    want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:, :n].astype(np.float32))
+    want_T = torch.from_numpy(fx["ref_final_trans"])
+    flips = int((res["final_labels"][:g_pairs].cpu() != want_lab[:g_pairs]).sum())
+    dT = float((res["final_trans"][:g_pairs].cpu() - want_T[:g_pairs]).abs().max())
+    assert flips == 0, f"{flips} label flips vs the reference"
+    assert dT < 1e-4, dT
+    # every pair of the batch, golden or not, must register (well-conditioned workload) and be a rigid motion
+    T = res["final_trans"].cpu().double()
+    assert (T[:, :3, :3] @ T[:, :3, :3].transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5
+    for i in range(bs):
+        re, te = O.registration_errors(res["final_trans"][i].cpu(), batch["gt_trans"][i])
+        assert re < 1.0 and te < (60.0 if "kitti" in name else 5.0), (i, re, te)
+
+
+def test_bench_timed_path_uses_the_wave_layer_kernel_and_fused_merge():
+    """Guards the claim above: at the headline configuration the forward goes through layer_wave_kernel and merges the
+    key-split partials inside it (csrc/api.hip:run_forward), i.e. the golden test at bs=32 covers those kernels."""
+    lib = _lib.load()
+    assert lib.pdsc_layer_prefers_block(32, 5000) == 0 and lib.pdsc_layer_prefers_block(1, 5000) == 1
+    ns = lib.pdsc_attention_split_default_split(32, 5000)
+    assert 1 < ns <= 4, ns
 
 
 def test_batched_forward_equals_per_pair_calls():
