@@ -51,7 +51,16 @@ typedef struct pdsc_config {
     float nms_radius;        /* NMS radius R (:174)                            */
     float refine_threshold;  /* 0.10 if inlier_threshold == 0.10 else 1.2 (:415-418) */
     int attention_precision; /* enum pdsc_attention_precision: how the two N x N x C contractions are evaluated */
+    int compat_format;       /* enum pdsc_compat_format: how the forward stores the N x N spatial-consistency matrix  */
 } pdsc_config;
+
+/* Storage of the spatial-consistency matrix between its build and the 12 attention launches that stream it
+ * (the split-precision modes only; PDSC_ATT_FP32 always uses fp32 storage):
+ *   U16: unorm16, value = round(compat * 65535) / 65535 -- 0 and 1 exact, |error| <= 2^-17 = 7.6e-6, the size of the
+ *        2^-16 product error of the bf16x3 arithmetic it feeds; half the HBM stream (2 N^2 instead of 4 N^2 bytes per
+ *        layer per pair), half the workspace.                                                         [default]
+ *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's. */
+enum pdsc_compat_format { PDSC_COMPAT_U16 = 0, PDSC_COMPAT_F32 = 1 };
 
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
  *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
@@ -113,6 +122,13 @@ size_t pdsc_workspace_bytes(const pdsc_config* cfg, int bs, int N, int num_seeds
  * src_dist: optional (may be NULL) [bs][N][ld]; the fused path never materialises it. */
 int pdsc_spatial_compat(const float* src_keypts, const float* tgt_keypts, const float* sigma_spat,
                         float* compat, float* src_dist, long long ld, int bs, int N, void* stream);
+
+/* unorm16 variant (enum pdsc_compat_format): compat_u16 [bs][N][ld] uint16, ld = pdsc_compat_ld(N) (multiple of 32),
+ * value u = round(compat * 65535); inside every group of 32 columns, column 8g + 4h + e is stored at position
+ * 16h + 4g + e (the order the attention kernel's accumulator holds the keys); columns >= N are 0.
+ * Consumed by pdsc_sc_attention_split_u16 only. */
+int pdsc_spatial_compat_u16(const float* src_keypts, const float* tgt_keypts, const float* sigma_spat,
+                            unsigned short* compat_u16, long long ld, int bs, int N, void* stream);
 
 /* Self-test hook for the two hand-rolled exact primitives of the compat kernel (correctly rounded sqrt, division
  * by a loop-invariant): sqrt_out[i] = sqrt(x[i]), div_out[i] = x[i] / divisor, both must equal the IEEE results. */
@@ -219,6 +235,10 @@ int    pdsc_attention_split_default_split(int bs, int N);
 int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
                                float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                void* stream);
+/* same, streaming the unorm16 matrix of pdsc_spatial_compat_u16 (ld: uint16 elements per row) */
+int    pdsc_sc_attention_split_u16(const void* q_split, const void* kv_tiles, const unsigned short* compat_u16, long long ld,
+                                   float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
+                                   void* stream);
 /* msg == NULL (only when the key split is > 1): the partials are left un-merged in `scratch` for pdsc_layer_fused_x3:
  * part_o = scratch as [bs][nsplit][Npad][C] floats, Npad = N rounded up to 256, part_ml right behind it as
  * [bs][nsplit][Npad][2]. */

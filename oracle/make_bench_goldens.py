@@ -11,7 +11,12 @@ For each BASELINE.json configuration it
   2. runs the reference ``PointDSC.forward`` (testing mode, CPU, bs=1 loop -- the reference's only testing mode,
      models/PointDSC.py:210) on the first GOLDEN_PAIRS pairs of the workload,
   3. runs the oracle on the same pairs and records the agreement (this is the oracle's pin at the bench sizes),
-  4. stores the reference outputs (poses + bit-packed labels) and input checksums.
+  4. measures the reference's OWN stability on each pair: the same forward in fp64 (default dtype switched, SURVEY.md
+     Appendix B) -- where fp32 and fp64 runs of the reference differ by more than 2e-5 the pair sits on a discrete near-tie
+     (equal inlier counts of several hypotheses, kNN sets decided at the 1e-7 level) and no implementation, the
+     reference's own GPU path included, can be expected to reproduce its pose to 1e-4; such pairs are flagged
+     `stable = False` and compared on labels + a 1e-3 pose tolerance only,
+  5. stores the reference outputs (poses + bit-packed labels), the stability flags and input checksums.
 The GPU tests compare ``pdsc_forward_testing`` on the WHOLE bench batch (the launch plans bench.py times) with these.
 """
 from __future__ import annotations
@@ -71,7 +76,12 @@ def main():
             shift = float(w["logit_shift"])
         sd = workloads.state_dict(name, tmpl, shift=shift)
         ref.load_state_dict(sd, strict=True)
-        trans, labels, rep = [], [], {"num_corr": w["num_corr"], "logit_shift": shift, "pairs": []}
+        trans, labels, stable, rep = [], [], [], {"num_corr": w["num_corr"], "logit_shift": shift, "pairs": []}
+        torch.set_default_dtype(torch.float64)
+        ref64 = RefPointDSC(**kw).eval()
+        ref64.load_state_dict(sd, strict=True)
+        ref64 = ref64.double()
+        torch.set_default_dtype(torch.float32)
         for i in range(G):
             one = {k: batch[k][i:i + 1] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
             with torch.no_grad():
@@ -82,22 +92,29 @@ def main():
                 ores = O.forward_testing(sd, one["corr_pos"], one["src_keypts"], one["tgt_keypts"],
                                          **{k: kw[k] for k in ORACLE_KEYS})
                 t_or = time.perf_counter() - t0
+                torch.set_default_dtype(torch.float64)
+                res64 = ref64(dict({k_: v_.double() for k_, v_ in one.items()}, testing=True))
+                torch.set_default_dtype(torch.float32)
+            self_dT = float((res["final_trans"].double() - res64["final_trans"]).abs().max())
+            self_flips = int((res["final_labels"].double() != res64["final_labels"]).sum())
+            stable.append(self_dT < 2e-5 and self_flips == 0)
             trans.append(res["final_trans"][0].numpy())
             labels.append(res["final_labels"][0].numpy() > 0)
             re, te = O.registration_errors(res["final_trans"][0], batch["gt_trans"][i])
             p = dict(pair=i, oracle_dT=float((ores["final_trans"] - res["final_trans"]).abs().max()),
                      oracle_label_flips=int((ores["final_labels"] != res["final_labels"]).sum()),
                      ref_inliers=int(res["final_labels"].sum()), gt_inliers=int(batch["gt_labels"][i].sum()),
-                     ref_RE_deg=re, ref_TE_cm=te, ref_seconds=round(t_ref, 2), oracle_seconds=round(t_or, 2))
+                     ref_RE_deg=re, ref_TE_cm=te, ref_seconds=round(t_ref, 2), oracle_seconds=round(t_or, 2),
+                     reference_fp32_vs_fp64_dT=self_dT, reference_fp32_vs_fp64_label_flips=self_flips, stable=stable[-1])
             rep["pairs"].append(p)
             print(name, json.dumps(p), flush=True)
-            if p["oracle_label_flips"] != 0 or p["oracle_dT"] >= 1e-4 or re > 1.0:
+            if p["oracle_label_flips"] != 0 or p["oracle_dT"] >= (1e-4 if stable[-1] else 1e-3) or re > 1.0:
                 ok = False
                 print("  !! pin violated")
         np.savez_compressed(
             GOLDEN / f"bench_{name}.npz",
             ref_final_trans=np.stack(trans), ref_final_labels_bits=np.packbits(np.stack(labels), axis=1),
-            logit_shift=np.float64(shift), num_corr=np.int64(w["num_corr"]),
+            logit_shift=np.float64(shift), num_corr=np.int64(w["num_corr"]), stable=np.array(stable, dtype=np.bool_),
             input_checksum=np.array([float(batch[k].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts")]),
             weights_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
             gt_trans=batch["gt_trans"].numpy())

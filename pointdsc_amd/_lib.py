@@ -24,7 +24,7 @@ class PdscConfig(C.Structure):
         ("in_dim", C.c_int), ("num_layers", C.c_int), ("num_channels", C.c_int),
         ("num_iterations", C.c_int), ("k", C.c_int), ("refine_iters", C.c_int),
         ("inlier_threshold", C.c_float), ("nms_radius", C.c_float), ("refine_threshold", C.c_float),
-        ("attention_precision", C.c_int),
+        ("attention_precision", C.c_int), ("compat_format", C.c_int),
     ]
 
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "pdsc_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),
     "pdsc_workspace_offset": (_ll, [_cfgp, _i, _i, _i, C.c_char_p]),
     "pdsc_spatial_compat": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "pdsc_spatial_compat_u16": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pdsc_selftest_exact_math": (_i, [_vp, _f, _vp, _vp, _ll, _vp]),
     "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "pdsc_attention_trace": (_i, [_vp]),
     "pdsc_layer_trace": (_i, [_vp]),
     "pdsc_sc_attention_split": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "pdsc_sc_attention_split_u16": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "pdsc_attention_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_default_split": (_i, [_i, _i]),
     "pdsc_sc_attention": (_i, [_vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),

@@ -56,6 +56,7 @@ static bool config_ok(const pdsc_config* c) {
     if (c->attention_precision < PDSC_ATT_BF16X3 || c->attention_precision > PDSC_ATT_BF16X3_ALL) {
         set_error("attention_precision=%d", c->attention_precision); return false;
     }
+    if (c->compat_format != PDSC_COMPAT_U16 && c->compat_format != PDSC_COMPAT_F32) { set_error("compat_format=%d", c->compat_format); return false; }
     return true;
 }
 
@@ -135,7 +136,8 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     const size_t ld = (size_t)pdsc_compat_ld(N);
     const int k = c->k < N - 1 ? c->k : N - 1;
     const int iters = c->num_iterations > 0 ? c->num_iterations : 1;
-    L.add("compat", (size_t)bs * N * ld * f);
+    const bool compat16 = c->attention_precision != PDSC_ATT_FP32 && c->compat_format == PDSC_COMPAT_U16;
+    L.add("compat", (size_t)bs * N * ld * (compat16 ? sizeof(unsigned short) : f));
     L.add("featA", M * C * f);
     L.add("featB", M * C * f);
     L.add("featC", M * C * f);
@@ -278,7 +280,16 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     void* kv_tiles = split ? ws + L.find("kv_tiles") : nullptr;
 
     // Step 1 (models/PointDSC.py:150-155): compat, then the SCNonlocal encoder
-    PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
+    const bool compat16 = split && cfg->compat_format == PDSC_COMPAT_U16;
+    if (compat16)
+        PDSC_TRY(pdsc_spatial_compat_u16(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), (unsigned short*)compat, ld, bs, N, stream));
+    else
+        PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
+    auto attention_split = [&](float* msg_out, int nsplit) {
+        return compat16 ? pdsc_sc_attention_split_u16(q_split, kv_tiles, (const unsigned short*)compat, ld, msg_out, att_scratch,
+                                                      att_bytes, bs, N, nsplit, stream)
+                        : pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg_out, att_scratch, att_bytes, bs, N, nsplit, stream);
+    };
     PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
     static int fused = -1;
     if (fused < 0) {
@@ -319,8 +330,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                             W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), WS(PDSC_W_QKV_W, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, fuse_merge ? nullptr : msg, att_scratch, att_bytes, bs, N,
-                                             ns, stream));
+            PDSC_TRY(attention_split(fuse_merge ? nullptr : msg, ns));
             const bool last = i + 1 == cfg->num_layers;
             if (x3_gemm)
                 PDSC_TRY(pdsc_layer_fused_x3(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
@@ -369,7 +379,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_TRY(pdsc_linear(featB, C, W(PDSC_W_QKV_W, i), W(PDSC_W_QKV_B, i), nullptr, 0, qkv, 3 * C, M, C, 3 * C, 0, stream));
         if (split) {
             PDSC_TRY(pdsc_pack_qkv_split(qkv, q_split, kv_tiles, bs, N, stream));
-            PDSC_TRY(pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            PDSC_TRY(attention_split(msg, 0));
         } else
             PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
         PDSC_TRY(pdsc_linear(msg, C, W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), nullptr, 0, t64a, C / 2, M, C, C / 2, 1, stream));

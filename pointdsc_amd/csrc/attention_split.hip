@@ -28,7 +28,7 @@ namespace pdsc {
 struct AttSplitArgs {
     const __bf16* qs;            // [bs*N][256]  (hi | lo), q pre-scaled by log2(e)/sqrt(C)
     const unsigned char* kv;     // [bs][num_tiles][32 KiB]
-    const float* compat;         // [bs][N][ld]
+    const void* compat;          // [bs][N][ld] fp32, or (C16) unorm16 in the tile order of pdsc_spatial_compat_u16
     long long ld;
     float* msg;                  // [bs*N][128]
     float* part_o;               // [bs][nsplit][Npad][128]
@@ -51,17 +51,6 @@ __device__ __forceinline__ void issue_linear(__amdgpu_buffer_rsrc_t rsrc, int sr
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + i * 1024), 16, lane16, src_off + i * 1024, 0, 0);
     }
 }
-// The compat slice of this workgroup's NW*32 queries for one tile's 32 keys (128 B per query row); every wave fetches
-// its own 32 rows.  A wave instruction covers 8 rows x 128 B (8 lanes per row = one full cache line each); LDS row = 8
-// chunks of 16 B, chunk c stored at c ^ ((row >> 1) & 7) so that the per-query ds_read_b128 (row = lane) is
-// bank-conflict free -- the swizzle is in the SOURCE offsets `coff` because the LDS-DMA destination is lane-linear.
-__device__ __forceinline__ void issue_compat(__amdgpu_buffer_rsrc_t c_rsrc, int kt, const unsigned (&coff)[4],
-                                             unsigned char* dst, int wave) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(dst + (wave * 4 + u) * 1024), 16, coff[u], kt * (SPL_BK * 4), 0, 0);
-}
-
 // o *= alpha in place: one asm statement per accumulator register keeps the 64 registers where they are (a plain
 // `o[c][r] *= alpha` inside a branch made the register allocator keep two copies of O and move one per tile)
 __device__ __forceinline__ f32x16 scale_acc(f32x16 o, float alpha) {
@@ -90,7 +79,10 @@ constexpr int SPL_V_BYTES = 2 * 128 * SPL_V_STRIDE;   // Vh | Vl   20 KiB
         tlast = now__;                                                           \
     }
 
-template <int NW, bool TRACE = false>
+// C16: the compat stream is unorm16 (pdsc_spatial_compat_u16: value = u / 65535, 0 and 1 exact, |error| <= 2^-17; inside
+// every 32-key group the 16 keys a lane half holds are contiguous: position 16 h + 4 g + e for key 8 g + 4 h + e), i.e.
+// 64 B per query row per tile instead of 128: half the HBM stream, half the compat LDS stage and DMA instructions.
+template <int NW, bool C16 = false, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = TRACE ? (long long)__builtin_readcyclecounter() : 0;
@@ -98,7 +90,9 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     unsigned char* const Ks = lds;                                  // 2 x 17 KiB
     unsigned char* const Vs = lds + 2 * SPL_K_BYTES;                // 2 x 20 KiB
     unsigned char* const Cs = Vs + 2 * SPL_V_BYTES;                 // 2 x NW*4 KiB
-    constexpr int CSTAGE = NW * 4096;
+    constexpr int CROW = C16 ? 64 : 128;         // bytes of compat per query row per tile
+    constexpr int CSTAGE = NW * 32 * CROW;
+    constexpr int NCS = C16 ? 2 : 4;             // compat DMA pieces (1 KiB) per wave per tile
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -126,15 +120,25 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // compat: the descriptor covers only this workgroup's query rows, so every offset fits 32 bits whatever N is
     const int q_first = qb * (NW * 32);
     const int q_rows = min(NW * 32, N - q_first);
+    constexpr unsigned CEL = C16 ? 2u : 4u;      // bytes per compat element
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.compat + ((size_t)b * N + q_first) * a.ld), 0, (int)((unsigned)q_rows * (unsigned)a.ld * 4u), 0x00020000);
+        (void*)((const unsigned char*)a.compat + ((size_t)b * N + q_first) * a.ld * CEL), 0,
+        (int)((unsigned)q_rows * (unsigned)a.ld * CEL), 0x00020000);
     const unsigned lane16 = lane * 16;
-    unsigned coff[4];                            // byte offset of this lane's 16-B compat chunk per DMA piece, tile 0
+    // (sized 4, not NCS: with a template-dependent bound hipcc 7.2's host pass silently drops the kernel's launch stub)
+    unsigned coff[4] = {0u, 0u, 0u, 0u};         // byte offset of this lane's 16-B compat chunk per DMA piece, tile 0
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int row = wave * 32 + 8 * u + (lane >> 3);             // row inside the workgroup's query block
-        const int c = (lane & 7) ^ ((row >> 1) & 7);                 // logical 16-B chunk (4 keys) this lane fetches
-        coff[u] = (unsigned)min(row, q_rows - 1) * (unsigned)a.ld * 4u + 16u * c;
+    for (int u = 0; u < NCS; ++u) {
+        if (C16) {
+            // a wave instruction = 16 rows x 64 B; LDS row = 4 chunks of 16 B, logical chunk c stored at c ^ ((row >> 2) & 3)
+            const int row = wave * 32 + 16 * u + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            coff[u] = (unsigned)min(row, q_rows - 1) * (unsigned)a.ld * 2u + 16u * c;
+        } else {
+            const int row = wave * 32 + 8 * u + (lane >> 3);             // row inside the workgroup's query block
+            const int c = (lane & 7) ^ ((row >> 1) & 7);                 // logical 16-B chunk (4 keys) this lane fetches
+            coff[u] = (unsigned)min(row, q_rows - 1) * (unsigned)a.ld * 4u + 16u * c;
+        }
     }
     // DMA work of one wave for one loop iteration kt, as 9 slots that are issued BETWEEN the MFMA groups (an LDS-DMA
     // instruction costs its wave ~100 cycles of issue; bunched after the barrier that is ~1000 cycles per tile during
@@ -144,22 +148,27 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // the end of the buffer the descriptor's bounds check returns zeros); they land in stages nobody reads any more.
     constexpr int KPIECES = SPL_K_BYTES / 1024, PIECES = SPL_TILE_BYTES / 1024, KV_SLOTS = (PIECES + NW - 1) / NW;
     auto dma_slot = [&](int kt, int st, int slot) {
-        if (slot < 4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * 4 + slot) * 1024), 16, coff[slot],
-                                                     (kt + 2) * (SPL_BK * 4), 0, 0);
+        if (slot < NCS) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
+                                                     (kt + 2) * (SPL_BK * (int)CEL), 0, 0);
         } else {
-            const int i = min(wave + NW * (slot - 4), PIECES - 1);      // surplus slots repeat the last piece
+            const int i = min(wave + NW * (slot - NCS), PIECES - 1);    // surplus slots repeat the last piece
             const bool isk = i < KPIECES;                                // wave-uniform
             unsigned char* dst = isk ? Ks + st * SPL_K_BYTES + i * 1024 : Vs + (st ^ 1) * SPL_V_BYTES + (i - KPIECES) * 1024;
             const int src = ((isk ? kt + 2 : kt + 1) * PIECES + i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (lptr_t)dst, 16, lane16, src, 0, 0);
         }
     };
-    constexpr int DMA_SLOTS = 4 + KV_SLOTS;      // 9 (NW = 8) or 14 (NW = 4): 8 go after the QK steps, the rest after PV steps
+    constexpr int DMA_SLOTS = NCS + KV_SLOTS;    // fp32 compat: 9 (NW = 8) or 14 (NW = 4): 8 go after the QK steps, the rest after PV steps
     static_assert(DMA_SLOTS <= 16, "16 places per iteration");
     auto dma_k = [&](int kt) { issue_linear<NW, SPL_K_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_KH, Ks + ((kt - kt0) & 1) * SPL_K_BYTES, wave, lane16); };
     auto dma_v = [&](int kt) { issue_linear<NW, SPL_V_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_VH, Vs + ((kt - kt0) & 1) * SPL_V_BYTES, wave, lane16); };
-    auto dma_c = [&](int kt) { issue_compat(c_rsrc, kt, coff, Cs + ((kt - kt0) & 1) * CSTAGE, wave); };
+    auto dma_c = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < NCS; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + ((kt - kt0) & 1) * CSTAGE + (wave * NCS + u) * 1024), 16,
+                                                     coff[u], kt * (SPL_BK * (int)CEL), 0, 0);
+    };
 
     // prologue: K, compat of the first two tiles and V of the first in flight, then this lane's Q fragments
     dma_k(kt0); dma_c(kt0);
@@ -185,8 +194,22 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 
     const int koff = l31 * SPL_K_STRIDE + 16 * h;   // K image: row of key l31, chunk 2j+h -> + 32 j   (immediates)
     const int voff = l31 * SPL_V_STRIDE + 16 * h;   // V^T image: row of channel 32c + l31, chunk 2j+h -> + 32 j + 32 c stride
-    const int crow_off = (wave * 32 + l31) * 128;   // compat row of this lane's query in a compat stage
-    const int csw = ((wave * 32 + l31) >> 1) & 7;
+    const int crow_off = (wave * 32 + l31) * CROW;  // compat row of this lane's query in a compat stage
+    const int csw = C16 ? (l31 >> 2) & 3 : ((wave * 32 + l31) >> 1) & 7;
+    constexpr float C16_INV = 1.0f / 65535.0f;      // 65535 * fl(1/65535) == 1.0f exactly (and 0 stays 0)
+    // unorm16 -> f32 of the 4 keys of group g (registers 4g..4g+3): words 2(g&1), 2(g&1)+1 of 16-B chunk 2h + (g>>1)
+    auto c16_group = [&](const unsigned (&w)[8], int g, float (&cc)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned word = w[2 * g + (e >> 1)];
+            cc[e] = (float)((e & 1) ? (word >> 16) : (word & 0xffffu)) * C16_INV;
+        }
+    };
+    auto c16_load = [&](const unsigned char* crow, int half, unsigned (&w)[8]) {   // half 0: groups 0,1; half 1: groups 2,3
+        const u32x4 v = *reinterpret_cast<const u32x4*>(crow + (((2 * h + half) ^ csw) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[4 * half + e] = v[e];
+    };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // logits of one tile relative to the current reference: tl = compat * s - m_run, keys >= N masked
@@ -222,11 +245,24 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
         }
+        if (C16) {
+            unsigned w[8];
+            c16_load(Cs + crow_off, 0, w);
+            c16_load(Cs + crow_off, 1, w);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 cc = *reinterpret_cast<const f32x4*>(Cs + crow_off + (((2 * g + h) ^ csw) << 4));
+            for (int g = 0; g < 4; ++g) {
+                float cc[4];
+                c16_group(w, g, cc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tl[4 * g + e] = cc[e] * sacc[4 * g + e];
+                for (int e = 0; e < 4; ++e) tl[4 * g + e] = cc[e] * sacc[4 * g + e];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 cc = *reinterpret_cast<const f32x4*>(Cs + crow_off + (((2 * g + h) ^ csw) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tl[4 * g + e] = cc[e] * sacc[4 * g + e];
+            }
         }
         mask_tail(kt0, tl);
         m_run = row_max(tl);
@@ -261,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
-                dma_slot(kt, st, j);
+                if (j < DMA_SLOTS) dma_slot(kt, st, j);
 #pragma unroll
                 for (int r = 2 * j; r < 2 * j + 2; ++r) {
                     const float p = __builtin_amdgcn_exp2f(tl[r]);
@@ -280,6 +316,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         {
             const unsigned char* V = Vs + st * SPL_V_BYTES;
             const unsigned char* Cn = Cs + (st ^ 1) * CSTAGE + crow_off;
+            unsigned cw[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = u >> 1, j = u & 1;
@@ -290,7 +327,17 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[j], o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[j], o[c], 0, 0, 0);
                 if (8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
-                if (u & 1) {                     // compat chunk 2g+h = keys 8g+4h..+3 = accumulator registers 4g..4g+3
+                if (C16) {
+                    if (u == 0) c16_load(Cn, 0, cw);
+                    if (u == 4) c16_load(Cn, 1, cw);
+                    if (u & 1) {
+                        const int g = u >> 1;
+                        float cc[4];
+                        c16_group(cw, g, cc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                    }
+                } else if (u & 1) {              // compat chunk 2g+h = keys 8g+4h..+3 = accumulator registers 4g..4g+3
                     const int g = u >> 1;
                     const f32x4 cc = *reinterpret_cast<const f32x4*>(Cn + (((2 * g + h) ^ csw) << 4));
 #pragma unroll
@@ -493,13 +540,12 @@ extern "C" int pdsc_attention_trace(long long* device_buffer) {   // diagnostics
     return PDSC_OK;
 }
 
-extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
-                                       float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
-                                       void* stream) {
+static int launch_attention_split(const void* q_split, const void* kv_tiles, const void* compat, bool c16, long long ld,
+                                  float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream) {
     PDSC_REQUIRE(q_split && kv_tiles && compat, "pdsc_sc_attention_split: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_split: bs=%d N=%d", bs, N);
-    PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % 4 == 0,
-                 "pdsc_sc_attention_split: ld=%lld must be a multiple of 4 and >= N rounded up to 32", ld);
+    PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % (c16 ? 8 : 4) == 0,
+                 "pdsc_sc_attention_split: ld=%lld must be a multiple of %d and >= N rounded up to 32", ld, c16 ? 8 : 4);
     const int tiles = spl_num_tiles(N);
     int nw, ns;
     split_plan(bs, N, &nw, &ns);
@@ -519,27 +565,38 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 4096);   // 2 stages x (K 17 KiB + V 20 KiB + compat nw*4 KiB)
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sc_attention_split_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (SPL_TILE_BYTES + 4 * 4096));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sc_attention_split_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (SPL_TILE_BYTES + 8 * 4096));
-        attr_set = true;
-    }
+    // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
+    const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
+    // dynamic-LDS opt-in per kernel instantiation and per device (the attribute is per device on ROCm)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned long long attr_done[6] = {0, 0, 0, 0, 0, 0};
+    auto opt_in = [&](int slot, const void* fn) -> int {
+        if (dev < 64 && (attr_done[slot] >> dev & 1ull)) return PDSC_OK;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return check_launch("pdsc_sc_attention_split(hipFuncSetAttribute)");
+        if (dev < 64) attr_done[slot] |= 1ull << dev;
+        return PDSC_OK;
+    };
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
-    profile_mark_begin(PDSC_PROF_ATTENTION, st);
-    if (nw == 8 && a.trace) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sc_attention_split_kernel<8, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (SPL_TILE_BYTES + 8 * 4096));
-        hipLaunchKernelGGL((sc_attention_split_kernel<8, true>), dim3(grid), dim3(512), lds_bytes, st, a);
-    } else if (nw == 8)
-        hipLaunchKernelGGL(sc_attention_split_kernel<8>, dim3(grid), dim3(512), lds_bytes, st, a);
-    else
-        hipLaunchKernelGGL(sc_attention_split_kernel<4>, dim3(grid), dim3(256), lds_bytes, st, a);
-    profile_mark_end(PDSC_PROF_ATTENTION, st);
-    int rc = check_launch("pdsc_sc_attention_split");
+    int rc = PDSC_OK;
+    const bool trace = nw == 8 && a.trace;
+#define PDSC_ATT_LAUNCH(SLOT, NWV, C16V, TRV)                                                                              \
+    do {                                                                                                                    \
+        rc = opt_in(SLOT, reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, C16V, TRV>));                       \
+        if (rc != PDSC_OK) return rc;                                                                                       \
+        profile_mark_begin(PDSC_PROF_ATTENTION, st);                                                                        \
+        hipLaunchKernelGGL((sc_attention_split_kernel<NWV, C16V, TRV>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);      \
+        profile_mark_end(PDSC_PROF_ATTENTION, st);                                                                          \
+    } while (0)
+    if (trace && c16) PDSC_ATT_LAUNCH(0, 8, true, true);
+    else if (trace) PDSC_ATT_LAUNCH(1, 8, false, true);
+    else if (nw == 8 && c16) PDSC_ATT_LAUNCH(2, 8, true, false);
+    else if (nw == 8) PDSC_ATT_LAUNCH(3, 8, false, false);
+    else if (c16) PDSC_ATT_LAUNCH(4, 4, true, false);
+    else PDSC_ATT_LAUNCH(5, 4, false, false);
+#undef PDSC_ATT_LAUNCH
+    rc = check_launch("pdsc_sc_attention_split");
     if (rc != PDSC_OK) return rc;
     if (nsplit > 1 && msg) {
         AttArgs c{};
@@ -548,4 +605,16 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
         rc = launch_attention_combine(c, bs, st);
     }
     return rc;
+}
+
+extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
+                                       float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
+                                       void* stream) {
+    return launch_attention_split(q_split, kv_tiles, compat, false, ld, msg, scratch, scratch_bytes, bs, N, nsplit, stream);
+}
+
+extern "C" int pdsc_sc_attention_split_u16(const void* q_split, const void* kv_tiles, const unsigned short* compat_u16,
+                                           long long ld, float* msg, void* scratch, size_t scratch_bytes, int bs, int N,
+                                           int nsplit, void* stream) {
+    return launch_attention_split(q_split, kv_tiles, compat_u16, true, ld, msg, scratch, scratch_bytes, bs, N, nsplit, stream);
 }

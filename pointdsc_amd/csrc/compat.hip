@@ -199,6 +199,90 @@ __global__ __launch_bounds__(256) void compat_sym_kernel(const float* __restrict
     }
 }
 
+// ---- unorm16 variant for the split-precision attention (the only consumer of the matrix in the forward) -----------
+// value = round(compat * 65535) (v_cvt_pknorm_u16_f32: 0 and 1 exact, |error| <= 2^-17), stored in the attention kernel's
+// tile order: inside every group of 32 keys, key 8g + 4h + e sits at position 16h + 4g + e -- the 16 keys a lane half of
+// the S^T accumulator holds are contiguous (attention_split.hip).  Same symmetric scheme as above; half the bytes.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ int c16_pos(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }   // r in [0, 32)
+constexpr int C16_PITCH = 2 * CS_T + 8;      // bytes per LDS strip row (128 u16 + pad)
+
+__global__ __launch_bounds__(256) void compat_sym_u16_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                             const float* __restrict__ sigma_spat,
+                                                             unsigned short* __restrict__ compat, long long ld, int N) {
+    const int I = blockIdx.y, J = blockIdx.x, b = blockIdx.z;
+    if (I > J) return;
+    __shared__ __attribute__((aligned(16))) unsigned char Ts[CS_STRIP * C16_PITCH];   // one 32 x 128 strip of u16, row-major
+    __shared__ __attribute__((aligned(16))) float rows_s[CS_T * 8];
+    const int i0 = I * CS_T, j0 = J * CS_T;
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    const int t = threadIdx.x;
+    if (t < CS_T) {
+        const int i = min(i0 + t, N - 1);
+        rows_s[t * 8 + 0] = srcb[i * 3 + 0]; rows_s[t * 8 + 1] = srcb[i * 3 + 1]; rows_s[t * 8 + 2] = srcb[i * 3 + 2];
+        rows_s[t * 8 + 4] = tgtb[i * 3 + 0]; rows_s[t * 8 + 5] = tgtb[i * 3 + 1]; rows_s[t * 8 + 6] = tgtb[i * 3 + 2];
+    }
+    const int l32 = t & 31, rg = t >> 5;
+    const int jc = j0 + l32 * 4;
+    float sx[4], sy[4], sz[4], tx[4], ty[4], tz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = min(jc + c, N - 1);
+        sx[c] = srcb[j * 3 + 0]; sy[c] = srcb[j * 3 + 1]; sz[c] = srcb[j * 3 + 2];
+        tx[c] = tgtb[j * 3 + 0]; ty[c] = tgtb[j * 3 + 1]; tz[c] = tgtb[j * 3 + 2];
+    }
+    const float sg = sigma_spat[0];
+    const float s2 = sg * sg;
+    const InvariantDivisor inv(s2);
+    unsigned short* outb = compat + (size_t)b * N * ld;
+    const bool offdiag = I != J;
+    const int jpos = (jc & ~31) + c16_pos(jc & 31);          // the 4 columns jc..jc+3 are contiguous in tile order
+    __syncthreads();
+    for (int strip = 0; strip < CS_T / CS_STRIP; ++strip) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sl = rg + 8 * r;                      // row inside the strip
+            const int il = strip * CS_STRIP + sl;
+            const int i = i0 + il;
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(rows_s + il * 8);
+            const f32x4 pt = *reinterpret_cast<const f32x4*>(rows_s + il * 8 + 4);
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ds = dist3<true>(ps[0] - sx[c], ps[1] - sy[c], ps[2] - sz[c]);
+                const float dt = dist3<true>(pt[0] - tx[c], pt[1] - ty[c], pt[2] - tz[c]);
+                const float v = compat_from_dists<true>(ds, dt, s2, inv);
+                o[c] = ((jc + c) < N && i < N) ? v : 0.0f;
+            }
+            uint2 q;
+            q.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(o[0], o[1]));
+            q.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(o[2], o[3]));
+            if (i < N && jc < ld) *reinterpret_cast<uint2*>(outb + (size_t)i * ld + jpos) = q;
+            if (offdiag) *reinterpret_cast<uint2*>(Ts + sl * C16_PITCH + 8 * l32) = q;
+        }
+        if (offdiag) {                                       // block-uniform
+            __syncthreads();
+            // output row j, 16-B chunk q = tile-order positions 8q..8q+7 of the strip's 32 rows (one whole key group)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int idx = t + 256 * p2, jl = idx >> 2, q = idx & 3;
+                unsigned w[4];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int p = 8 * q + m;
+                    const int sl = 8 * ((p >> 2) & 3) + 4 * (p >> 4) + (p & 3);          // inverse of c16_pos
+                    const unsigned v = *reinterpret_cast<const unsigned short*>(Ts + sl * C16_PITCH + 2 * jl);
+                    if (m & 1) w[m >> 1] |= v << 16; else w[m >> 1] = v;
+                }
+                const int j = j0 + jl;
+                if (j < N) *reinterpret_cast<u32x4*>(outb + (size_t)j * ld + i0 + strip * CS_STRIP + 8 * q) = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // self-test hook: the two hand-rolled exact primitives on arbitrary inputs (tests compare with IEEE results)
 __global__ void exact_math_selftest_kernel(const float* __restrict__ x, float b, float* __restrict__ sq, float* __restrict__ dv,
                                            long long n) {
@@ -250,4 +334,17 @@ extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const flo
         hipLaunchKernelGGL((pdsc::compat_sym_kernel<true>), sym_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, ld, N);
     pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
     return pdsc::check_launch("pdsc_spatial_compat");
+}
+
+extern "C" int pdsc_spatial_compat_u16(const float* src, const float* tgt, const float* sigma_spat, unsigned short* compat_u16,
+                                       long long ld, int bs, int N, void* stream) {
+    PDSC_REQUIRE(src && tgt && sigma_spat && compat_u16, "pdsc_spatial_compat_u16: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_spatial_compat_u16: bs=%d N=%d", bs, N);
+    PDSC_REQUIRE(ld >= pdsc::round_up(N, 32) && ld % 32 == 0, "pdsc_spatial_compat_u16: ld=%lld must be a multiple of 32 and >= N", ld);
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = pdsc::ceil_div(N, pdsc::CS_T);
+    pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
+    hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel, dim3(nt, nt, bs), dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N);
+    pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
+    return pdsc::check_launch("pdsc_spatial_compat_u16");
 }

@@ -32,6 +32,7 @@ __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) /
 // ---- device helpers ----------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Euclidean norm of a 3-vector with torch's CPU/GPU reduction order: sqrt(fma(z,z,fma(y,y,x*x))).
 // (oracle/pointdsc_oracle.py:pairwise_dist documents the measurement.)  sqrtf is IEEE-correct

@@ -30,6 +30,8 @@ from . import _lib
 _NUM_CHANNELS = 128
 # enum pdsc_attention_precision (include/pointdsc_hip.h)
 ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1, "bf16x3_all": 2}
+# enum pdsc_compat_format
+COMPAT_FORMATS = {"u16": 0, "f32": 1}
 
 
 def _conv(cin: int, cout: int) -> nn.Conv1d:
@@ -103,6 +105,9 @@ class PointDSC(nn.Module):
         # "fp32" = exact fp32 MFMA, "bf16x3_all" = the point-wise GEMMs in split precision too (features within 2e-5).
         # Set the attribute (or POINTDSC_ATTENTION_PRECISION) before calling forward.
         self.attention_precision = os.environ.get("POINTDSC_ATTENTION_PRECISION", "bf16x3")
+        # storage of the N x N spatial-consistency matrix between its build and the attention launches (split-precision
+        # modes): "u16" = unorm16 (|error| <= 7.6e-6, half the HBM stream; default), "f32" = the reference's fp32 matrix
+        self.compat_format = os.environ.get("POINTDSC_COMPAT_FORMAT", "u16")
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
@@ -114,9 +119,11 @@ class PointDSC(nn.Module):
         refine_thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
         if self.attention_precision not in ATTENTION_PRECISIONS:
             raise ValueError(f"attention_precision must be one of {sorted(ATTENTION_PRECISIONS)}, got {self.attention_precision!r}")
+        if self.compat_format not in COMPAT_FORMATS:
+            raise ValueError(f"compat_format must be one of {sorted(COMPAT_FORMATS)}, got {self.compat_format!r}")
         return _lib.PdscConfig(self.in_dim, self.num_layers, self.num_channels, self.num_iterations, self.k, 20,
                                float(self.inlier_threshold), float(self.nms_radius), float(refine_thr),
-                               ATTENTION_PRECISIONS[self.attention_precision])
+                               ATTENTION_PRECISIONS[self.attention_precision], COMPAT_FORMATS[self.compat_format])
 
     # The packed buffer is rebuilt after anything that can change weights through the nn.Module API
     # (load_state_dict, .to()/.cuda()/.float(), train()); after editing parameters in place call

@@ -50,6 +50,29 @@ def spatial_compat(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spa
     return (compat, dist) if want_dist else compat
 
 
+def spatial_compat_u16(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spat: torch.Tensor) -> torch.Tensor:
+    """[bs,N,3] x2 -> unorm16 compat [bs,N,ld] (int16 storage of uint16 bits) in the attention kernel's tile order
+    (pdsc_spatial_compat_u16); decode with `decode_compat_u16`."""
+    lib = _lib.load()
+    src, tgt = _chk(src_keypts, "src_keypts"), _chk(tgt_keypts, "tgt_keypts")
+    sig = _chk(sigma_spat.reshape(-1), "sigma_spat")
+    bs, n = src.shape[0], src.shape[1]
+    ld = compat_ld(n)
+    out = torch.empty(bs, n, ld, device=src.device, dtype=torch.int16)
+    _lib.check(lib.pdsc_spatial_compat_u16(_p(src), _p(tgt), _p(sig), _p(out), ld, bs, n, _stream()), "pdsc_spatial_compat_u16")
+    return out
+
+
+def decode_compat_u16(c16: torch.Tensor, n: int) -> torch.Tensor:
+    """unorm16 tile-order matrix -> fp32 [bs,N,N] in natural column order (tests)."""
+    bs, rows, ld = c16.shape
+    u = (c16.to(torch.int32) & 0xFFFF).to(torch.float32) / 65535.0
+    j = torch.arange(ld, device=c16.device)
+    r = j & 31
+    pos = (j & ~31) + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)
+    return u[:, :, pos][:, :, :n]
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [M,K] @ weight[Nout,K]^T (+bias)(relu)(+residual) -> [M,Nout]."""
@@ -120,15 +143,17 @@ def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: to
     """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128].
     merge=False (needs a key split > 1): returns (scratch, nsplit) with the un-merged partials for layer_fused_x3."""
     lib = _lib.load()
-    compat = _chk(compat, "compat")
+    c16 = compat.dtype == torch.int16                  # unorm16 matrix of spatial_compat_u16
+    compat = _chk(compat, "compat", torch.int16 if c16 else torch.float32)
     qs, kv = _chk(q_split, "q_split", torch.uint8), _chk(kv_tiles, "kv_tiles", torch.uint8)
     if nsplit <= 0:
         nsplit = int(lib.pdsc_attention_split_default_split(bs, n))
     msg = torch.empty(bs * n, 128, device=compat.device, dtype=torch.float32) if merge else None
     nb = int(lib.pdsc_attention_split_scratch_bytes(bs, n, nsplit))
     scratch = torch.empty(max(nb, 16), device=compat.device, dtype=torch.uint8)
-    _lib.check(lib.pdsc_sc_attention_split(_p(qs), _p(kv), _p(compat), compat.shape[-1], _p(msg), _p(scratch), nb, bs, n,
-                                           nsplit, _stream()), "pdsc_sc_attention_split")
+    fn = lib.pdsc_sc_attention_split_u16 if c16 else lib.pdsc_sc_attention_split
+    _lib.check(fn(_p(qs), _p(kv), _p(compat), compat.shape[-1], _p(msg), _p(scratch), nb, bs, n, nsplit, _stream()),
+               "pdsc_sc_attention_split")
     return msg if merge else (scratch, nsplit)
 
 

@@ -26,8 +26,11 @@ KITTI_MODEL = dict(BASE_MODEL, inlier_threshold=0.6, sigma_d=1.2, nms_radius=0.6
 
 WORKLOADS: Dict[str, dict] = {
     # BASELINE.json configs[1]: 3DMatch test, N=1000, batch 1 on one GPU
+    # (seed0 = 1001: on the pair seeded 1000 the REFERENCE's own fp32 and fp64 runs differ by 2.5e-4 in the pose -- six seed
+    #  hypotheses tie at the maximal inlier count and kNN sets decided at the 1e-7 level pick the winner; the five pairs
+    #  after it agree to < 1e-5 -- measured by oracle/make_bench_goldens.py, column reference_fp32_vs_fp64_dT)
     "n1000_b1": dict(baseline_config=1, num_corr=1000, global_batch=1, model=BASE_MODEL, wseed=6, logit_shift=0.05,
-                     pair=dict(inlier_ratio=0.2, noise=0.01, scale=3.0), seed0=1000,
+                     pair=dict(inlier_ratio=0.2, noise=0.01, scale=3.0), seed0=1001,
                      label="3DMatch-like synthetic correspondences (BASELINE.json configs[1])"),
     # BASELINE.json configs[2] (the headline metric): N=5000, 32 pairs sharded over the GPUs
     "n5000_b32": dict(baseline_config=2, num_corr=5000, global_batch=32, model=BASE_MODEL, wseed=6, logit_shift=0.05,

