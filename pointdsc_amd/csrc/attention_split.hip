@@ -34,6 +34,7 @@ struct AttSplitArgs {
     float* part_o;               // [bs][nsplit][Npad][128]
     float* part_ml;              // [bs][nsplit][Npad][2]
     int N, Npad, nsplit, num_tiles, nq, bs;
+    int compat_nt;               // A/B knob PDSC_ATT_COMPAT_NT: stream the compat slices with the non-temporal policy
     long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
 };
 
@@ -149,8 +150,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     constexpr int KPIECES = SPL_K_BYTES / 1024, PIECES = SPL_TILE_BYTES / 1024, KV_SLOTS = (PIECES + NW - 1) / NW;
     auto dma_slot = [&](int kt, int st, int slot) {
         if (slot < NCS) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
-                                                     (kt + 2) * (SPL_BK * (int)CEL), 0, 0);
+            if (a.compat_nt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
+                                                         (kt + 2) * (SPL_BK * (int)CEL), 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
+                                                         (kt + 2) * (SPL_BK * (int)CEL), 0, 0);
         } else {
             const int i = min(wave + NW * (slot - NCS), PIECES - 1);    // surplus slots repeat the last piece
             const bool isk = i < KPIECES;                                // wave-uniform
@@ -564,9 +569,13 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
+    { const char* e = getenv("PDSC_ATT_COMPAT_NT"); a.compat_nt = e ? atoi(e) : 0; }      // tuning/A-B knob, read per call
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
-    const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
+    // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)
+    const size_t stage_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
+    const size_t patch_bytes = (size_t)nw * 32 * (PDSC_CHANNELS * 4 + 16);
+    const size_t lds_bytes = stage_bytes > patch_bytes ? stage_bytes : patch_bytes;
     // dynamic-LDS opt-in per kernel instantiation and per device (the attribute is per device on ROCm)
     int dev = 0;
     (void)hipGetDevice(&dev);

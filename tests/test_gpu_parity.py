@@ -447,7 +447,7 @@ def _attention_split_model(q, k, v, compat):
     return w @ (d(vh) + d(vl))
 
 
-@pytest.mark.parametrize("n,bs", [(257, 1), (1000, 2), (2053, 1), (96, 3), (33, 1), (5000, 1)])
+@pytest.mark.parametrize("n,bs", [(257, 1), (1000, 2), (2053, 1), (96, 3), (33, 1), (5000, 1), (1500, 9)])   # (1500, 9): the 8-wave kernel
 @pytest.mark.parametrize("nsplit", [1, 0, 3])
 @pytest.mark.parametrize("fmt", ["f32", "u16"])
 def test_sc_attention_split_matches_fp64_softmax(n, bs, nsplit, fmt):

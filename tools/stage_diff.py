@@ -20,6 +20,8 @@ ap.add_argument("--config", default="n1000_b1")
 ap.add_argument("--pair", type=int, default=0)
 ap.add_argument("--bs", type=int, default=1)
 ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--compat-format", default="u16")
+ap.add_argument("--index", type=int, default=0, help="position inside the batch (the batch starts at --pair)")
 a = ap.parse_args()
 w = workloads.WORKLOADS[a.config]
 kw = dict(w["model"])
@@ -28,6 +30,7 @@ sd = workloads.state_dict(a.config, model.state_dict())
 model.load_state_dict(sd)
 model = model.eval().cuda()
 model.attention_precision = a.precision
+model.compat_format = a.compat_format
 batch = workloads.batch(a.config, a.pair, a.bs)
 n = w["num_corr"]
 S = int(n * kw["ratio"])
@@ -37,18 +40,19 @@ data["testing"] = True
 with torch.no_grad():
     res = model(data)
 torch.cuda.synchronize()
-ref = O.forward_testing(sd, batch["corr_pos"][:1], batch["src_keypts"][:1], batch["tgt_keypts"][:1], return_stages=True,
+ix = a.index
+ref = O.forward_testing(sd, batch["corr_pos"][ix:ix + 1], batch["src_keypts"][ix:ix + 1], batch["tgt_keypts"][ix:ix + 1], return_stages=True,
                         **{kk: kw[kk] for kk in ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")})
 st = ref["stages"][0]
 v = lambda name, dt=torch.float32: model.workspace_view(name, a.bs, n, dt).cpu()  # noqa: E731
-normed = v("normed")[: n * 128].reshape(n, 128)
-conf = v("conf")[:n]
-seeds = v("seeds", torch.int32)[:S].long()
-knn = v("knn_idx", torch.int32)[: S * k].reshape(S, k).long()
-strans = v("seed_trans")[: S * 16].reshape(S, 4, 4)
-counts = v("counts", torch.int32)[:S].long()
-best = int(v("best", torch.int32)[0])
-init = v("initial_trans")[:16].reshape(4, 4)
+normed = v("normed")[ix * n * 128: (ix + 1) * n * 128].reshape(n, 128)
+conf = v("conf")[ix * n: (ix + 1) * n]
+seeds = v("seeds", torch.int32)[ix * S: (ix + 1) * S].long()
+knn = v("knn_idx", torch.int32)[ix * S * k: (ix + 1) * S * k].reshape(S, k).long()
+strans = v("seed_trans")[ix * S * 16: (ix + 1) * S * 16].reshape(S, 4, 4)
+counts = v("counts", torch.int32)[ix * S: (ix + 1) * S].long()
+best = int(v("best", torch.int32)[ix])
+init = v("initial_trans")[ix * 16: (ix + 1) * 16].reshape(4, 4)
 print("normed  max|d|", float((normed - st["normed"]).abs().max()))
 print("conf    max|d|", float((conf - st["confidence"]).abs().max()), " min gap between sorted oracle keys near the cut:",
       float((torch.sort(st["nms_keys"], descending=True).values[:S + 1].diff().abs()).min()))
@@ -63,5 +67,5 @@ if torch.equal(seeds, st["seeds"]):
     print("oracle top counts", top.values[:6].tolist(), "at seeds", top.indices[:6].tolist(), " gpu counts there", counts[top.indices[:6]].tolist())
 print("best    gpu", best, "oracle", st["best"])
 print("initial max|d|", float((init - st["initial_trans"]).abs().max()))
-print("final   max|d|", float((res["final_trans"][0].cpu() - st["final_trans"]).abs().max()),
-      " labels flips", int((res["final_labels"][0].cpu() != st["final_labels"]).sum()), " refine solves oracle", st["refine_solves"])
+print("final   max|d|", float((res["final_trans"][ix].cpu() - st["final_trans"]).abs().max()),
+      " labels flips", int((res["final_labels"][ix].cpu() != st["final_labels"]).sum()), " refine solves oracle", st["refine_solves"])
