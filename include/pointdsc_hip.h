@@ -58,9 +58,9 @@ typedef struct pdsc_config {
  * (the split-precision modes only; PDSC_ATT_FP32 always uses fp32 storage):
  *   U16: unorm16, value = round(compat * 65535) / 65535 -- 0 and 1 exact, |error| <= 2^-17 = 7.6e-6, the size of the
  *        2^-16 product error of the bf16x3 arithmetic it feeds; half the HBM stream (2 N^2 instead of 4 N^2 bytes per
- *        layer per pair), half the workspace.                                                         [default]
- *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's. */
-enum pdsc_compat_format { PDSC_COMPAT_U16 = 0, PDSC_COMPAT_F32 = 1 };
+ *        layer per pair), half the workspace; +5 % pairs/s at N=5000 (tools/ab_forward.py).            [opt-in]
+ *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's.                     [default] */
+enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
 
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
  *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
@@ -373,6 +373,17 @@ size_t pdsc_sm_workspace_bytes(int bs, int N);
 int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
                      int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
                      void* workspace, size_t workspace_bytes, int bs, int N, void* stream);
+
+/* cal_confidence (models/PointDSC.py:366-401): confidence of a spectral-matching solution from its compatibility matrix
+ * M [bs][N][ld] (ld >= N, multiple of 4) and leading eigenvector [bs][N]:
+ *   method 0 'eig_value'      : Rayleigh quotient lambda1 = v^T M v / v^T v
+ *   method 1 'eig_value_ratio': lambda1 / lambda2, lambda2 from num_iterations power steps on B = M - lambda1 v v^T
+ *                               started at 1 (each step normalised by |.| + 1e-6), B never materialised
+ *   method 2 'xMx'            : v^T M v / N
+ * confidence [bs]; workspace from pdsc_cal_confidence_workspace_bytes.  One HBM-bound N x N mat-vec per step. */
+size_t pdsc_cal_confidence_workspace_bytes(int bs, int N);
+int pdsc_cal_confidence(const float* M, long long ld, const float* leading_eig, int method, int num_iterations,
+                        float* confidence, void* workspace, size_t workspace_bytes, int bs, int N, void* stream);
 
 /* ---- evaluation row on the device -----------------------------------------------------------
  * replaces libs/loss.py:44-51 (RE / TE / recall of TransformationLoss), :96-100 (precision / recall / F1, sklearn on the

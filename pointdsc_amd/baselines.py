@@ -39,3 +39,33 @@ def SM(corr: torch.Tensor, src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, i
                                   bs, n, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pdsc_sm_baseline")
     return (trans, labels, eig) if return_eig else (trans, labels)
+
+
+CONFIDENCE_METHODS = {"eig_value": 0, "eig_value_ratio": 1, "xMx": 2}
+
+
+def cal_confidence(M: torch.Tensor, leading_eig: torch.Tensor, method: str = "eig_value", num_iterations: int = 10) -> torch.Tensor:
+    """``PointDSC.cal_confidence`` (reference models/PointDSC.py:366-401): M [bs,N,N] (or [bs,N,ld], ld >= N a multiple of 4,
+    e.g. the matrix of ``ops.spatial_compat``), leading_eig [bs,N] -> confidence [bs,1] with the reference's three
+    methods; ``num_iterations`` = the module's power-iteration count (used by 'eig_value_ratio')."""
+    lib = _lib.load()
+    if method not in CONFIDENCE_METHODS:
+        raise ValueError(f"method must be one of {sorted(CONFIDENCE_METHODS)}")
+    if not M.is_cuda:
+        raise RuntimeError("pointdsc_amd has no CPU path: move the tensors to the GPU")
+    v = leading_eig.detach().to(torch.float32).contiguous()
+    bs, n = v.shape
+    m = M.detach().to(torch.float32)
+    if m.shape[-1] % 4 != 0:                                 # float4 row loads
+        m = torch.nn.functional.pad(m, (0, 4 - m.shape[-1] % 4))
+    m = m.contiguous()
+    ld = m.shape[-1]
+    conf = torch.empty(bs, device=m.device, dtype=torch.float32)
+    nb = int(lib.pdsc_cal_confidence_workspace_bytes(bs, n))
+    ws = torch.empty(nb, device=m.device, dtype=torch.uint8)
+    with torch.cuda.device(m.device):
+        rc = lib.pdsc_cal_confidence(C.c_void_p(m.data_ptr()), ld, C.c_void_p(v.data_ptr()), CONFIDENCE_METHODS[method],
+                                     int(num_iterations), C.c_void_p(conf.data_ptr()), C.c_void_p(ws.data_ptr()), nb, bs, n,
+                                     torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pdsc_cal_confidence")
+    return conf[:, None]

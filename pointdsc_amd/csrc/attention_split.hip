@@ -569,7 +569,10 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
-    { const char* e = getenv("PDSC_ATT_COMPAT_NT"); a.compat_nt = e ? atoi(e) : 0; }      // tuning/A-B knob, read per call
+    // the fp32 compat slices are read once per launch: streamed non-temporal they leave the L2 to the K/V tiles the other
+    // workgroups of the XCD re-read (+1.6 % pairs/s, tools/ab_forward.py; the unorm16 stream is faster without).
+    // PDSC_ATT_COMPAT_NT = 0 | 1 overrides (tuning/A-B knob, read per call).
+    { const char* e = getenv("PDSC_ATT_COMPAT_NT"); a.compat_nt = e ? atoi(e) : (c16 ? 0 : 1); }
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
     // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)

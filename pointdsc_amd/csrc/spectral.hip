@@ -145,6 +145,95 @@ __global__ __launch_bounds__(256) void sm_finish_kernel(const float* __restrict_
     }
 }
 
+
+// ---- cal_confidence (reference models/PointDSC.py:366-401): confidence of a spectral-matching solution -------------
+// One 1024-thread workgroup per pair for the O(N) vector steps (fixed-order reductions: deterministic), sm_matvec_kernel
+// for every M x.  B = M - lambda1 v v^T is never formed: B x = M x - lambda1 v (v . x).
+constexpr int CC_THREADS = 1024;
+template <int NV>
+__device__ __forceinline__ void cc_block_sum(double (&v)[NV], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double t = 0.0;
+        for (int w = 0; w < CC_THREADS / 64; ++w) t += red[w * NV + i];
+        v[i] = t;
+    }
+}
+// step 0: lambda1 = (v . Mv) / (v . v); x <- 1.   method 0 / 2 finish here (conf = lambda1, or v . Mv / N)
+__global__ __launch_bounds__(CC_THREADS) void cc_rayleigh_kernel(const float* __restrict__ v, const float* __restrict__ Mv, int method,
+                                                                 float* __restrict__ lambda1, float* __restrict__ x,
+                                                                 float* __restrict__ conf, int N) {
+    __shared__ double red[CC_THREADS / 64 * 2];
+    const int b = blockIdx.x;
+    const float* vb = v + (size_t)b * N;
+    const float* yb = Mv + (size_t)b * N;
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < N; i += CC_THREADS) {
+        acc[0] += (double)vb[i] * (double)yb[i];
+        acc[1] += (double)vb[i] * (double)vb[i];
+        if (x) x[(size_t)b * N + i] = 1.0f;
+    }
+    cc_block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        const float l1 = (float)acc[0] / (float)acc[1];
+        lambda1[b] = l1;
+        if (method == 0) conf[b] = l1;
+        if (method == 2) conf[b] = (float)acc[0] / (float)N;
+    }
+}
+// one deflated power step: z = Mx - lambda1 v (v . x);  x <- z / (|z| + 1e-6)
+__global__ __launch_bounds__(CC_THREADS) void cc_deflate_kernel(const float* __restrict__ v, const float* __restrict__ Mx,
+                                                                const float* __restrict__ lambda1, float* __restrict__ x, int N) {
+    __shared__ double red[CC_THREADS / 64];
+    const int b = blockIdx.x;
+    const float* vb = v + (size_t)b * N;
+    const float* yb = Mx + (size_t)b * N;
+    float* xb = x + (size_t)b * N;
+    double s[1] = {0.0};
+    for (int i = threadIdx.x; i < N; i += CC_THREADS) s[0] += (double)vb[i] * (double)xb[i];
+    cc_block_sum<1>(s, red);
+    const float coef = lambda1[b] * (float)s[0];
+    double n2[1] = {0.0};
+    for (int i = threadIdx.x; i < N; i += CC_THREADS) {
+        const float z = yb[i] - coef * vb[i];
+        n2[0] += (double)z * (double)z;
+    }
+    cc_block_sum<1>(n2, red);
+    const float inv = 1.0f / ((float)sqrt(n2[0]) + 1e-6f);
+    for (int i = threadIdx.x; i < N; i += CC_THREADS) xb[i] = (yb[i] - coef * vb[i]) * inv;
+}
+// lambda2 = (x . Bx) / (x . x);  conf = lambda1 / lambda2
+__global__ __launch_bounds__(CC_THREADS) void cc_ratio_kernel(const float* __restrict__ v, const float* __restrict__ Mx,
+                                                              const float* __restrict__ lambda1, const float* __restrict__ x,
+                                                              float* __restrict__ conf, int N) {
+    __shared__ double red[CC_THREADS / 64 * 3];
+    const int b = blockIdx.x;
+    const float* vb = v + (size_t)b * N;
+    const float* yb = Mx + (size_t)b * N;
+    const float* xb = x + (size_t)b * N;
+    double acc[3] = {0.0, 0.0, 0.0};                 // v.x, x.Mx, x.x
+    for (int i = threadIdx.x; i < N; i += CC_THREADS) {
+        acc[0] += (double)vb[i] * (double)xb[i];
+        acc[1] += (double)xb[i] * (double)yb[i];
+        acc[2] += (double)xb[i] * (double)xb[i];
+    }
+    cc_block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        const double l1 = (double)lambda1[b];
+        const float l2 = (float)((acc[1] - l1 * acc[0] * acc[0]) / acc[2]);     // x.Bx = x.Mx - lambda1 (v.x)^2
+        conf[b] = lambda1[b] / l2;
+    }
+}
+
 }  // namespace pdsc
 
 using namespace pdsc;
@@ -203,4 +292,53 @@ extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, 
     rc = check_launch("pdsc_sm_baseline(finish)");
     if (rc != PDSC_OK) return rc;
     return pdsc_rigid_transform_3d(src_keypts, tgt_keypts, wts, 0.0f, pred_trans, bs, N, stream);
+}
+
+extern "C" size_t pdsc_cal_confidence_workspace_bytes(int bs, int N) {
+    if (bs <= 0 || N <= 0) return 0;
+    return (size_t)bs * N * 4 * 2 + (size_t)bs * SMV_MAX_BLOCKS * 4 + (size_t)bs * 16 + 1024;
+}
+
+extern "C" int pdsc_cal_confidence(const float* M, long long ld, const float* leading_eig, int method, int num_iterations,
+                                   float* confidence, void* workspace, size_t workspace_bytes, int bs, int N, void* stream) {
+    PDSC_REQUIRE(M && leading_eig && confidence && workspace, "pdsc_cal_confidence: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && ld >= N && ld % 4 == 0, "pdsc_cal_confidence: bs=%d N=%d ld=%lld (ld >= N, multiple of 4)", bs, N, ld);
+    PDSC_REQUIRE(method >= 0 && method <= 2 && num_iterations >= 0, "pdsc_cal_confidence: method=%d iterations=%d", method, num_iterations);
+    PDSC_REQUIRE(ceil_div(N, SMV_ROWS) <= SMV_MAX_BLOCKS && (size_t)ld * sizeof(float) <= 160 * 1024 - 64,
+                 "pdsc_cal_confidence: N=%d too large", N);
+    if (workspace_bytes < pdsc_cal_confidence_workspace_bytes(bs, N)) {
+        set_error("pdsc_cal_confidence: workspace %zu < %zu bytes", workspace_bytes, pdsc_cal_confidence_workspace_bytes(bs, N));
+        return PDSC_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* y = (float*)workspace;
+    float* x = y + (size_t)bs * N;
+    float* part = x + (size_t)bs * N;
+    float* lam = part + (size_t)bs * SMV_MAX_BLOCKS;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sm_matvec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 64) != hipSuccess)
+        return check_launch("pdsc_cal_confidence(hipFuncSetAttribute)");
+    const int nblocks = ceil_div(N, SMV_ROWS);
+    auto matvec = [&](const float* in) {
+        hipLaunchKernelGGL(sm_matvec_kernel, dim3(nblocks, bs), dim3(256), (size_t)ld * sizeof(float), st, M, ld, in, (const float*)nullptr,
+                           0, y, part, N);
+        return check_launch("pdsc_cal_confidence(matvec)");
+    };
+    int rc = matvec(leading_eig);
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(cc_rayleigh_kernel, dim3(bs), dim3(CC_THREADS), 0, st, leading_eig, y, method, lam, method == 1 ? x : nullptr,
+                       confidence, N);
+    rc = check_launch("pdsc_cal_confidence(rayleigh)");
+    if (rc != PDSC_OK || method != 1) return rc;
+    for (int it = 0; it < num_iterations; ++it) {
+        rc = matvec(x);
+        if (rc != PDSC_OK) return rc;
+        hipLaunchKernelGGL(cc_deflate_kernel, dim3(bs), dim3(CC_THREADS), 0, st, leading_eig, y, lam, x, N);
+        rc = check_launch("pdsc_cal_confidence(deflate)");
+        if (rc != PDSC_OK) return rc;
+    }
+    rc = matvec(x);
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(cc_ratio_kernel, dim3(bs), dim3(CC_THREADS), 0, st, leading_eig, y, lam, x, confidence, N);
+    return check_launch("pdsc_cal_confidence(ratio)");
 }

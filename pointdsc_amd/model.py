@@ -31,7 +31,7 @@ _NUM_CHANNELS = 128
 # enum pdsc_attention_precision (include/pointdsc_hip.h)
 ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1, "bf16x3_all": 2}
 # enum pdsc_compat_format
-COMPAT_FORMATS = {"u16": 0, "f32": 1}
+COMPAT_FORMATS = {"f32": 0, "u16": 1}
 
 
 def _conv(cin: int, cout: int) -> nn.Conv1d:
@@ -106,8 +106,11 @@ class PointDSC(nn.Module):
         # Set the attribute (or POINTDSC_ATTENTION_PRECISION) before calling forward.
         self.attention_precision = os.environ.get("POINTDSC_ATTENTION_PRECISION", "bf16x3")
         # storage of the N x N spatial-consistency matrix between its build and the attention launches (split-precision
-        # modes): "u16" = unorm16 (|error| <= 7.6e-6, half the HBM stream; default), "f32" = the reference's fp32 matrix
-        self.compat_format = os.environ.get("POINTDSC_COMPAT_FORMAT", "u16")
+        # modes): "f32" = the reference's fp32 matrix, bit-exact (default); "u16" = unorm16 (|error| <= 7.6e-6): half the
+        # workspace and HBM stream, 5 % more pairs/s at N=5000 (tools/ab_forward.py), features as close to the exact-fp32
+        # path as with "f32" (2e-6) -- opt-in because any change of round-off can move a near-tie among the seed
+        # hypotheses (DESIGN.md "hard thresholds") and the committed reference goldens are met with more margin by "f32"
+        self.compat_format = os.environ.get("POINTDSC_COMPAT_FORMAT", "f32")
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None

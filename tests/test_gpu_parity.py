@@ -504,7 +504,7 @@ def test_split_and_fp32_attention_agree_through_the_encoder(n):
         out[prec if fmt == "u16" or prec == "fp32" else prec + "_f32compat"] = (
             model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
             model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
-    model.attention_precision, model.compat_format = "bf16x3", "u16"
+    model.attention_precision, model.compat_format = "bf16x3", "f32"
     scale = max(1.0, float(out["fp32"][0].abs().max()))
     print("feature error vs fp32:", {k: float((out["fp32"][0] - v[0]).abs().max()) / scale for k, v in out.items()})
     for prec, tol in (("bf16x3", 8e-6), ("bf16x3_f32compat", 8e-6), ("bf16x3_all", 3e-5)):
@@ -1075,6 +1075,31 @@ def test_sm_baseline_matches_reference_golden(name):
     assert flips <= 2 * int((~decided).sum())
     tol = 1e-4 if flips == 0 else 3e-3                                                      # another inlier subset moves the pose
     assert (trans[0].cpu() - torch.from_numpy(fx["ref_pred_trans"][0])).abs().max() < tol * max(1.0, float(fx["scale"]) / 3.0)
+
+
+def test_cal_confidence_matches_reference_golden():
+    """pdsc_cal_confidence vs the reference's own PointDSC.cal_confidence (models/PointDSC.py:366-401) on seeded pairs:
+    M rebuilt bit-exactly by pdsc_spatial_compat, leading eigenvector = the reference's; three methods; batch of 2."""
+    from pointdsc_amd import baselines
+    fx = np.load(GOLDEN / "confidence.npz", allow_pickle=False)
+    for ci in range(int(fx["num_cases"])):
+        n, seed, scale, sigma = int(fx[f"c{ci}_n"]), int(fx[f"c{ci}_seed"]), float(fx[f"c{ci}_scale"]), float(fx[f"c{ci}_sigma"])
+        pair = synthetic.make_pair(n, seed=seed, inlier_ratio=0.3, scale=scale, noise=scale / 300.0)
+        assert abs(float(pair["src_keypts"].double().sum()) - float(fx[f"c{ci}_src_checksum"])) < 1e-6
+        M = ops.spatial_compat(g(pair["src_keypts"]), g(pair["tgt_keypts"]), g(torch.tensor([sigma], dtype=torch.float32)))
+        v = g(torch.from_numpy(fx[f"c{ci}_leading_eig"]))
+        want = fx[f"c{ci}_conf"]
+        for k, method in enumerate(("eig_value", "eig_value_ratio", "xMx")):
+            got = baselines.cal_confidence(M, v, method=method, num_iterations=10)
+            assert got.shape == (1, 1)
+            rel = abs(float(got) - float(want[k])) / abs(float(want[k]))
+            assert rel < (1e-4 if method == "eig_value_ratio" else 2e-6), (n, method, float(got), float(want[k]))
+        # natural [bs, N, N] layout (N not a multiple of 4 is padded by the wrapper) and a batch of two
+        Mn = M[:, :, :n].contiguous()
+        two = baselines.cal_confidence(torch.cat([Mn, Mn * 0.5]), torch.cat([v, v]), method="eig_value")
+        assert abs(float(two[0]) - float(want[0])) / float(want[0]) < 2e-6 and abs(float(two[1]) - 0.5 * float(want[0])) / float(want[0]) < 2e-6
+    with pytest.raises(ValueError):
+        baselines.cal_confidence(M, v, method="nope")
 
 
 def test_sm_baseline_batched_equals_per_pair():

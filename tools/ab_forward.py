@@ -39,7 +39,7 @@ data["testing"] = True
 def apply(variant):
     parts = variant.split("+")
     model.compat_format = parts[0]
-    env = {"PDSC_ATT_COMPAT_NT": "0"}
+    env = {"PDSC_ATT_COMPAT_NT": "0"}          # explicit in every variant (the library's default depends on the format)
     for p in parts[1:]:
         if p == "nt":
             env["PDSC_ATT_COMPAT_NT"] = "1"
