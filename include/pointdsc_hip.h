@@ -10,7 +10,12 @@
  * Conventions
  *   - all pointers are DEVICE pointers (HIP, fp32 unless stated), caller-owned, never retained;
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it: no host
- *     synchronisation, no allocation, no hidden global state (graph-capturable);
+ *     synchronisation, no allocation (graph-capturable).  Results depend on the arguments only.  Process-global
+ *     state is limited to: the per-(kernel, device) dynamic-LDS opt-in table (mutex-protected), the error string
+ *     (thread-local), and the opt-in DIAGNOSTIC hooks -- pdsc_profile_* event timing, pdsc_attention_trace,
+ *     pdsc_layer_trace -- which are process-wide switches and not thread-safe: use them from one thread.
+ *     Tuning / A-B knobs are PDSC_* environment variables read on every call (nothing is cached; DESIGN.md lists
+ *     them); the shipped behaviour is the default;
  *   - tensors are dense row-major; `bs` = number of correspondence sets (pairs), `N` = correspondences
  *     per pair, `C` = 128 channels, `S` = number of seeds, `k` = neighbours per seed;
  *   - bs > 1 means bs independent pairs, i.e. the reference called once per pair (the reference's
@@ -162,7 +167,7 @@ int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, f
 /* Same chain, with the head additionally (or instead of qkv_out, which may then be NULL) emitting the bf16 hi/lo
  * operand streams of the split-precision attention (layout: pointdsc_amd/csrc/split_layout.h):
  *   q_split  [bs*N][256] bf16 (hi | lo), pdsc_split_q_bytes(bs, N) bytes;
- *   kv_tiles [bs][ceil(N/32)][32 KiB],   pdsc_split_kv_bytes(bs, N) bytes.
+ *   kv_tiles [bs][ceil(N/32)][37 KiB],   pdsc_split_kv_bytes(bs, N) bytes.
  * Rows are bs pairs of N points (a 32-point tile never straddles two pairs).
  * The tail input is either `msg` (merged rows) or the un-merged key-split partials (`part_o`, `part_ml`, nsplit, Npad)
  * exactly as pdsc_sc_attention_split leaves them in its scratch when called with msg == NULL: the merge then happens

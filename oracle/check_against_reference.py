@@ -193,7 +193,12 @@ def main():
         # hard requirements of the pin
         must = [rep["src_dist_bitexact"], rep["compat_bitexact"], rep["seeds_set_equal"], rep["labels_equal"],
                 rep["final_trans_maxabs"] < (1e-3 if case.get("tie_case") else 2e-5), rep["conf_maxabs"] < 1e-4 * max(rep["feat_scale"], 1.0),
-                rep["ref_RE_deg"] < 1.0 and rep["num_inliers_pred"] >= 0.9 * rep["num_inliers_gt"]]  # fixture is well-conditioned
+                rep["ref_RE_deg"] < 1.0 and rep["num_inliers_pred"] >= 0.9 * rep["num_inliers_gt"],  # fixture is well-conditioned
+                # neighbour SETS of the seeds: equal for >= 90 % of the seeds.  The rest differ by near-tie distances at the
+                # 1e-7 level (2 - 2 x x^T in another summation order); a seed with another neighbour set gets another
+                # hypothesis (seed_trans_maxabs can be O(1)) and another inlier count -- labels, best index and pose, the
+                # quantities the path returns, still have to agree (the entries above)
+                rep["knn_sets_equal_frac"] is None or rep["knn_sets_equal_frac"] >= 0.9]
         if not all(must):
             ok = False
             print("  !! pin violated:", must)

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "pdsc_common.h"
 
 namespace pdsc {
@@ -23,6 +24,28 @@ int check_launch(const char* what) {
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));
         return PDSC_ERR_LAUNCH;
+    }
+    return PDSC_OK;
+}
+
+// ---- dynamic-LDS opt-in, once per (kernel, device) ----------------------------------------------
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
+    struct Entry { const void* fn; unsigned long long devices; size_t bytes; };
+    static Entry table[64];
+    static int used = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return check_launch(what);
+    std::lock_guard<std::mutex> lock(mu);
+    Entry* e = nullptr;
+    for (int i = 0; i < used; ++i)
+        if (table[i].fn == fn) { e = &table[i]; break; }
+    if (e && dev < 64 && (e->devices >> dev & 1ull) && e->bytes >= bytes) return PDSC_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return check_launch(what);
+    if (!e && used < 64) { e = &table[used++]; e->fn = fn; e->devices = 0; e->bytes = 0; }
+    if (e && dev < 64) {
+        if (bytes > e->bytes) { e->bytes = bytes; e->devices = 0; }      // a larger request must be repeated on every device
+        e->devices |= 1ull << dev;
     }
     return PDSC_OK;
 }
@@ -291,30 +314,19 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                         : pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg_out, att_scratch, att_bytes, bs, N, nsplit, stream);
     };
     PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
-    static int fused = -1;
-    if (fused < 0) {
-        const char* env = getenv("PDSC_FUSED_LAYERS");          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
-        fused = env ? atoi(env) : 1;
-    }
+    const int fused = env_int("PDSC_FUSED_LAYERS", 1);          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
     if (fused && cfg->num_layers > 0 && split) {
         // split precision: head of layer 0, then per layer attention (partials left un-merged when the keys are split)
         // + ONE launch for the merge, the tail of layer i and the head of layer i+1
         const int ns = pdsc_attention_split_default_split(bs, N);
         const int Npad = (int)round_up(N, 256);
-        static int fuse_env = -1;
-        if (fuse_env < 0) {
-            const char* env = getenv("PDSC_FUSE_MERGE");         // tuning/A-B knob
-            fuse_env = env ? atoi(env) : 1;
-        }
+        const int fuse_env = env_int("PDSC_FUSE_MERGE", 1);      // tuning/A-B knob
         const bool fuse_merge = fuse_env && ns > 1 && ns <= 4;   // the layer kernels merge up to 4 splits while loading (merge_partials.h)
         const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;
         const float* part_ml = fuse_merge ? part_o + (size_t)bs * ns * Npad * C : nullptr;
-        static int frag_env = -1;
-        if (frag_env < 0) {
-            const char* env = getenv("PDSC_LAYER_FRAG");          // tuning/A-B knob: 0 = natural-layout weights (pdsc_layer_fused_split)
-            const char* var = getenv("PDSC_LAYER_VARIANT");
-            frag_env = (env ? atoi(env) : 1) && !(var && var[0] == 'b');
-        }
+        // tuning/A-B knob: PDSC_LAYER_FRAG = 0 = natural-layout weights (pdsc_layer_fused_split)
+        const char* var = getenv("PDSC_LAYER_VARIANT");
+        const bool frag_env = env_int("PDSC_LAYER_FRAG", 1) && !(var && var[0] == 'b');
         // default: wavefront-resident layer kernel on fragment streams; small problems: the workgroup-per-tile kernel (layer.hip)
         const bool frag = frag_env && !x3_gemm && !pdsc_layer_prefers_block(bs, N);
         if (x3_gemm)

@@ -307,15 +307,14 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * pdsc::ATT_C : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = 4 * pdsc::ATT_TILE_FLOATS * sizeof(float);   // 64 KiB
-    static int variant = -1;
-    if (variant < 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        const char* env = getenv("PDSC_ATT_VARIANT");       // tuning/A-B knob; default = shipped variant
-        variant = env ? atoi(env) : PDSC_ATT_DEFAULT_VARIANT;
+    {
+        int rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<0>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
+        if (rc_lds == PDSC_OK)
+            rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<1>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
+        if (rc_lds != PDSC_OK) return rc_lds;
     }
+    const char* env_variant = getenv("PDSC_ATT_VARIANT");       // tuning/A-B knob, read per call; default = shipped variant
+    const int variant = env_variant ? atoi(env_variant) : PDSC_ATT_DEFAULT_VARIANT;
     dim3 grid(pdsc::ceil_div(N, pdsc::ATT_BQ), nsplit, bs);
     pdsc::profile_mark_begin(PDSC_PROF_ATTENTION, st);
     if (variant == 0)

@@ -493,9 +493,7 @@ static void split_plan(int bs, int N, int* nw_out, int* nsplit_out) {
         if (((ns * bs) & 7) != 0) cost *= 1.03;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
     }
-    static int force_nw = -1, force_ns = -1;             // tuning/A-B knobs
-    if (force_nw < 0) { const char* e = getenv("PDSC_ATT_SPLIT_NW"); force_nw = e ? atoi(e) : 0; }
-    if (force_ns < 0) { const char* e = getenv("PDSC_ATT_SPLIT_NS"); force_ns = e ? atoi(e) : 0; }
+    const int force_nw = env_int("PDSC_ATT_SPLIT_NW", 0), force_ns = env_int("PDSC_ATT_SPLIT_NS", 0);   // tuning/A-B knobs
     *nw_out = (force_nw == 4 || force_nw == 8) ? force_nw : nw;
     *nsplit_out = force_ns > 0 ? (force_ns < tiles ? force_ns : tiles) : best;
 }
@@ -572,30 +570,20 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     // the fp32 compat slices are read once per launch: streamed non-temporal they leave the L2 to the K/V tiles the other
     // workgroups of the XCD re-read (+1.6 % pairs/s, tools/ab_forward.py; the unorm16 stream is faster without).
     // PDSC_ATT_COMPAT_NT = 0 | 1 overrides (tuning/A-B knob, read per call).
-    { const char* e = getenv("PDSC_ATT_COMPAT_NT"); a.compat_nt = e ? atoi(e) : (c16 ? 0 : 1); }
+    a.compat_nt = env_int("PDSC_ATT_COMPAT_NT", c16 ? 0 : 1);
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
     // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)
     const size_t stage_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
     const size_t patch_bytes = (size_t)nw * 32 * (PDSC_CHANNELS * 4 + 16);
     const size_t lds_bytes = stage_bytes > patch_bytes ? stage_bytes : patch_bytes;
-    // dynamic-LDS opt-in per kernel instantiation and per device (the attribute is per device on ROCm)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static unsigned long long attr_done[6] = {0, 0, 0, 0, 0, 0};
-    auto opt_in = [&](int slot, const void* fn) -> int {
-        if (dev < 64 && (attr_done[slot] >> dev & 1ull)) return PDSC_OK;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return check_launch("pdsc_sc_attention_split(hipFuncSetAttribute)");
-        if (dev < 64) attr_done[slot] |= 1ull << dev;
-        return PDSC_OK;
-    };
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
     int rc = PDSC_OK;
     const bool trace = nw == 8 && a.trace;
 #define PDSC_ATT_LAUNCH(SLOT, NWV, C16V, TRV)                                                                              \
     do {                                                                                                                    \
-        rc = opt_in(SLOT, reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, C16V, TRV>));                       \
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, C16V, TRV>), lds_bytes,       \
+                                "pdsc_sc_attention_split(dynamic LDS)");                                                    \
         if (rc != PDSC_OK) return rc;                                                                                       \
         profile_mark_begin(PDSC_PROF_ATTENTION, st);                                                                        \
         hipLaunchKernelGGL((sc_attention_split_kernel<NWV, C16V, TRV>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);      \

@@ -311,13 +311,9 @@ extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const flo
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_spatial_compat: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= N && ld % 4 == 0, "pdsc_spatial_compat: ld=%lld must be >= N and a multiple of 4", ld);
     hipStream_t st = (hipStream_t)stream;
-    static int variant = -1;
-    if (variant < 0) {
-        // tuning/A-B knob (all variants produce identical bits): 0 = full tiles + hipcc IEEE math, 1 = full tiles +
-        // hand-rolled exact math, 2 = symmetric + IEEE math, 3 = symmetric + hand-rolled exact math
-        const char* env = getenv("PDSC_COMPAT_VARIANT");
-        variant = env ? atoi(env) : PDSC_COMPAT_DEFAULT_VARIANT;
-    }
+    // tuning/A-B knob (all variants produce identical bits): 0 = full tiles + hipcc IEEE math, 1 = full tiles +
+    // hand-rolled exact math, 2 = symmetric + IEEE math, 3 = symmetric + hand-rolled exact math
+    const int variant = pdsc::env_int("PDSC_COMPAT_VARIANT", PDSC_COMPAT_DEFAULT_VARIANT);
     const dim3 full_grid(pdsc::ceil_div((int)ld, pdsc::CT_COLS), pdsc::ceil_div(N, pdsc::CT_ROWS), bs);
     const int nt = pdsc::ceil_div(N, pdsc::CS_T);
     const dim3 sym_grid(nt, nt, bs);

@@ -139,12 +139,8 @@ static size_t linear_lds_bytes(int NT, int K) { return (size_t)(LIN_BM + 64 * NT
 
 template <int NT, int MODE>
 static int launch_linear(const LinearArgs& a, int batches, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<NT, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)linear_lds_bytes(NT, 128));
-        attr_done = true;
-    }
+    const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_kernel<NT, MODE>), linear_lds_bytes(NT, 128), "pdsc_linear(dynamic LDS)");
+    if (rc_lds != PDSC_OK) return rc_lds;
     dim3 grid(ceil_div(a.Nout, 64 * NT), ceil_div(a.M, LIN_BM), batches);
     hipLaunchKernelGGL((linear_kernel<NT, MODE>), grid, dim3(256), linear_lds_bytes(NT, a.K), st, a);
     return check_launch("pdsc_linear");
@@ -255,12 +251,8 @@ __global__ __launch_bounds__(256, 2) void gram_rows_kernel(GramArgs a) {
 template <int MODE>
 static int launch_gram(GramArgs a, int bs, hipStream_t st) {
     const size_t lds_bytes = 2 * (size_t)GR_COLS * GR_LD * sizeof(float);     // 67 584 B
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_rows_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes);
-        attr_done = true;
-    }
+    const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_rows_kernel<MODE>), lds_bytes, "gram_rows(dynamic LDS)");
+    if (rc_lds != PDSC_OK) return rc_lds;
     const int row_blocks = ceil_div(a.R, GR_ROWS), tiles = ceil_div(a.N, GR_COLS);
     int splits = ceil_div(768, row_blocks * bs);                   // ~3 workgroups per CU in flight
     if (splits > tiles) splits = tiles;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/pointdsc_hip.h"
 
 #define PDSC_WAVE 64
@@ -21,9 +22,20 @@ int check_launch(const char* what);
         }                                             \
     } while (0)
 
+// Dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) of kernel `fn`, done once per (kernel, device) --
+// the attribute is per device -- and checked: returns PDSC_OK or PDSC_ERR_LAUNCH with the error text set.  Thread-safe.
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
+
 // opt-in event timing of the roofline kernels (api.hip); no-ops unless pdsc_profile_enable() was called
 void profile_mark_begin(int kind, hipStream_t st);
 void profile_mark_end(int kind, hipStream_t st);
+
+// Tuning / A-B knobs are environment variables read on EVERY call (no value is cached in the library; the shipped
+// behaviour is the default): PDSC_* names are listed in DESIGN.md.
+static inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -303,11 +303,9 @@ extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist
     int idx_bits = 1;
     while ((1 << idx_bits) < N) ++idx_bits;
     const size_t lds_bytes = (size_t)N * sizeof(unsigned int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pdsc::knn_select_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   // + ~12 KiB static <= 160 KiB
-        attr_done = true;
+    {   // + ~12 KiB static <= 160 KiB
+        const int rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::knn_select_kernel), 144 * 1024, "pdsc_knn_seeds(dynamic LDS)");
+        if (rc_lds != PDSC_OK) return rc_lds;
     }
     hipLaunchKernelGGL(pdsc::knn_select_kernel, dim3(S, bs), dim3(pdsc::KNN_THREADS), lds_bytes, st, dist_scratch, ldd,
                        knn_idx, N, S, k, idx_bits);

@@ -271,11 +271,8 @@ extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, 
     if (rc != PDSC_OK) return rc;
     // v0 = 1 (bit pattern of 1.0f)
     if (hipMemsetD32Async((hipDeviceptr_t)va, 0x3f800000, (size_t)bs * N, st) != hipSuccess) return check_launch("pdsc_sm_baseline(ones)");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm_matvec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        attr_done = true;
-    }
+    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sm_matvec_kernel), 160 * 1024 - 64, "pdsc_sm_baseline(dynamic LDS)");
+    if (rc != PDSC_OK) return rc;
     const int nblocks = ceil_div(N, SMV_ROWS);
     float *vin = va, *vout = vb, *pin = nullptr, *pout = pa;
     for (int it = 0; it < num_iterations; ++it) {
@@ -315,9 +312,10 @@ extern "C" int pdsc_cal_confidence(const float* M, long long ld, const float* le
     float* x = y + (size_t)bs * N;
     float* part = x + (size_t)bs * N;
     float* lam = part + (size_t)bs * SMV_MAX_BLOCKS;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sm_matvec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024 - 64) != hipSuccess)
-        return check_launch("pdsc_cal_confidence(hipFuncSetAttribute)");
+    {
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&sm_matvec_kernel), 160 * 1024 - 64, "pdsc_cal_confidence(dynamic LDS)");
+        if (rc_lds != PDSC_OK) return rc_lds;
+    }
     const int nblocks = ceil_div(N, SMV_ROWS);
     auto matvec = [&](const float* in) {
         hipLaunchKernelGGL(sm_matvec_kernel, dim3(nblocks, bs), dim3(256), (size_t)ld * sizeof(float), st, M, ld, in, (const float*)nullptr,

@@ -81,6 +81,15 @@ class PointDSC(nn.Module):
         super().__init__()
         if num_channels != _NUM_CHANNELS:
             raise ValueError(f"pointdsc_amd supports num_channels={_NUM_CHANNELS} (the released models); got {num_channels}")
+        # limits of the HIP path (include/pointdsc_hip.h), checked here so that they do not surface at the first forward:
+        # the first conv is packed with 8 input columns (the released models use in_dim = 6; the reference's in_dim 9 / 12
+        # variants, datasets/ThreeDMatch.py:299-312, are not supported), one wavefront lane per neighbour, at most 32 power iterates kept
+        if not 1 <= in_dim <= 8:
+            raise ValueError(f"pointdsc_amd supports 1 <= in_dim <= 8 (released models: 6); got {in_dim}")
+        if not 1 <= k <= 64:
+            raise ValueError(f"pointdsc_amd supports 1 <= k <= 64 neighbours per seed (released models: 40); got {k}")
+        if not 0 <= num_iterations <= 32:
+            raise ValueError(f"pointdsc_amd supports 0 <= num_iterations <= 32 (released models: 10); got {num_iterations}")
         self.in_dim = in_dim
         self.num_layers = num_layers
         self.num_iterations = num_iterations
@@ -135,6 +144,14 @@ class PointDSC(nn.Module):
         self._wpack = None
         self._wsplit = None
         self._wpack_key = None
+        self._tensors = None
+
+    def _weights_fingerprint(self) -> int:
+        """Changes whenever a parameter or buffer is modified in place (optimizer step, ``p.data.copy_``, a sub-module's
+        ``load_state_dict``): the sum of the tensors' version counters.  ~30 us per call."""
+        if getattr(self, "_tensors", None) is None:
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        return sum([t._version for t in self._tensors]) + 31 * sum([t.data_ptr() & 0xFFFF for t in self._tensors[:4]])
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed_weights()
@@ -154,7 +171,7 @@ class PointDSC(nn.Module):
         the constructor's sigma_d exactly like in the reference)."""
         lib = _lib.load()
         device = device or self.sigma.device
-        key = (str(device), self.sigma.data_ptr())
+        key = (str(device), self.sigma.data_ptr(), self._weights_fingerprint())
         if self._wpack is not None and self._wpack_key == key:
             return self._wpack
         cfg = self._config()

@@ -19,6 +19,24 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_device(fn):
+    """Run the wrapper with the first CUDA tensor argument's device current (the library launches on the calling
+    thread's current device and on that device's current stream), like PointDSC.forward does."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if torch.is_tensor(a) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+            if isinstance(a, (tuple, list)) and a and torch.is_tensor(a[0]) and a[0].is_cuda:
+                with torch.cuda.device(a[0].device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapped
+
+
 def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (pointdsc_amd has no CPU path)")
@@ -35,6 +53,7 @@ def compat_ld(n: int) -> int:
     return int(_lib.load().pdsc_compat_ld(n))
 
 
+@_on_device
 def spatial_compat(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spat: torch.Tensor,
                    want_dist: bool = False):
     """[bs,N,3] x2 -> compat [bs,N,ld] (view [..., :N] is the reference matrix), optional src_dist."""
@@ -50,6 +69,7 @@ def spatial_compat(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spa
     return (compat, dist) if want_dist else compat
 
 
+@_on_device
 def spatial_compat_u16(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spat: torch.Tensor) -> torch.Tensor:
     """[bs,N,3] x2 -> unorm16 compat [bs,N,ld] (int16 storage of uint16 bits) in the attention kernel's tile order
     (pdsc_spatial_compat_u16); decode with `decode_compat_u16`."""
@@ -73,6 +93,7 @@ def decode_compat_u16(c16: torch.Tensor, n: int) -> torch.Tensor:
     return u[:, :, pos][:, :, :n]
 
 
+@_on_device
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [M,K] @ weight[Nout,K]^T (+bias)(relu)(+residual) -> [M,Nout]."""
@@ -88,6 +109,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+@_on_device
 def layer0(corr_pos: torch.Tensor, w0_padded: torch.Tensor, b0: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _chk(corr_pos, "corr_pos").reshape(-1, corr_pos.shape[-1])
@@ -97,6 +119,7 @@ def layer0(corr_pos: torch.Tensor, w0_padded: torch.Tensor, b0: torch.Tensor) ->
     return y
 
 
+@_on_device
 def layer_fused(msg, res, feat_in, tail_w=None, head_w=None, want_feat=False):
     """Fused point-wise chain (pdsc_layer_fused).  tail_w = (w1,b1,w2,b2,w3,b3) folded fc_message of layer i,
     head_w = (wp,bp,wq,bq) folded PointCN / stacked qkv of layer i+1.  Returns (feat or None, featB or None, qkv or None)."""
@@ -115,6 +138,7 @@ def layer_fused(msg, res, feat_in, tail_w=None, head_w=None, want_feat=False):
     return feat, featB, qkv
 
 
+@_on_device
 def sc_attention(qkv: torch.Tensor, compat: torch.Tensor, bs: int, n: int, nsplit: int = 0) -> torch.Tensor:
     """qkv [bs*N,384] (q pre-scaled by log2(e)/sqrt(128)), compat [bs,N,ld] -> msg [bs*N,128]."""
     lib = _lib.load()
@@ -128,6 +152,7 @@ def sc_attention(qkv: torch.Tensor, compat: torch.Tensor, bs: int, n: int, nspli
     return msg
 
 
+@_on_device
 def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
     """fp32 (q|k|v) rows [bs*N,384] -> (q_split, kv_tiles) byte tensors in the layout of csrc/split_layout.h."""
     lib = _lib.load()
@@ -138,6 +163,7 @@ def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
     return qs, kv
 
 
+@_on_device
 def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: torch.Tensor, bs: int, n: int,
                        nsplit: int = 0, merge: bool = True):
     """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128].
@@ -157,6 +183,7 @@ def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: to
     return msg if merge else (scratch, nsplit)
 
 
+@_on_device
 def frag_weights_tail(tail_w) -> torch.Tensor:
     """(fc1 w, b, fc2 w, b, fc3 w, b) fp32 [out][in] -> the fragment-ordered tail stream of pdsc_layer_fused_frag."""
     lib = _lib.load()
@@ -165,6 +192,7 @@ def frag_weights_tail(tail_w) -> torch.Tensor:
     return out
 
 
+@_on_device
 def frag_weights_head(head_w) -> torch.Tensor:
     """(pcn w, b, qkv w, b): pcn kept fp32, q|k|v -> bf16 hi / lo, biases as one more k-step -> the head stream."""
     lib = _lib.load()
@@ -173,6 +201,7 @@ def frag_weights_head(head_w) -> torch.Tensor:
     return out
 
 
+@_on_device
 def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False, partials=None,
                       qkv_split: bool = False, frag: bool = False):
     """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
@@ -222,6 +251,7 @@ def split_weight(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([hi.reshape(-1), lo.reshape(-1)]).view(torch.uint8)
 
 
+@_on_device
 def layer_fused_x3(msg, res, feat_in, tail_w, head_w, bs: int, n: int, partials=None, want_qkv: bool = False,
                    want_feat: bool = False):
     """pdsc_layer_fused_x3 (split-precision chain).  tail_w/head_w as in layer_fused (fp32 matrices; split here).
@@ -269,6 +299,7 @@ def layer_fused_x3(msg, res, feat_in, tail_w, head_w, bs: int, n: int, partials=
 STATS_COLUMNS = ("success", "RE_deg", "TE_cm", "num_gt_inliers", "gt_inlier_ratio", "num_true_positives", "precision", "recall", "f1")
 
 
+@_on_device
 def eval_stats(trans, gt_trans, pred_labels, gt_labels, re_thre: float = 15.0, te_thre: float = 30.0) -> torch.Tensor:
     """[bs,9] evaluation rows on the device (columns: STATS_COLUMNS) -- libs/loss.py:44-51,96-100 and the stats row of
     evaluation/test_3DMatch.py:90-98 without the per-pair device->host copies."""
@@ -282,6 +313,7 @@ def eval_stats(trans, gt_trans, pred_labels, gt_labels, re_thre: float = 15.0, t
     return stats
 
 
+@_on_device
 def feature_compat(normed: torch.Tensor, sigma: torch.Tensor, bs: int, n: int) -> torch.Tensor:
     """normed [bs*N,128] -> M [bs,N,N] = clamp(1 - (1 - F F^T)/sigma^2, 0, 1), zero diagonal (models/PointDSC.py:158-163)."""
     lib = _lib.load()
@@ -291,6 +323,7 @@ def feature_compat(normed: torch.Tensor, sigma: torch.Tensor, bs: int, n: int) -
     return m
 
 
+@_on_device
 def normalize_confidence(feat, h2, w3, b3) -> Tuple[torch.Tensor, torch.Tensor]:
     lib = _lib.load()
     feat, h2, w3, b3 = _chk(feat, "feat"), _chk(h2, "h2"), _chk(w3.reshape(-1), "w3"), _chk(b3.reshape(-1), "b3")
@@ -302,6 +335,7 @@ def normalize_confidence(feat, h2, w3, b3) -> Tuple[torch.Tensor, torch.Tensor]:
     return normed, conf
 
 
+@_on_device
 def nms_keys(src_keypts, conf, radius: float) -> torch.Tensor:
     lib = _lib.load()
     src, conf = _chk(src_keypts, "src_keypts"), _chk(conf, "conf")
@@ -311,6 +345,7 @@ def nms_keys(src_keypts, conf, radius: float) -> torch.Tensor:
     return keys
 
 
+@_on_device
 def rank_select(keys, num_seeds: int) -> torch.Tensor:
     lib = _lib.load()
     keys = _chk(keys, "keys")
@@ -320,11 +355,13 @@ def rank_select(keys, num_seeds: int) -> torch.Tensor:
     return seeds
 
 
+@_on_device
 def pick_seeds(src_keypts, scores, R: float, max_num: int) -> torch.Tensor:
     """reference PointDSC.pick_seeds (dists replaced by the keypoints they were computed from)."""
     return rank_select(nms_keys(src_keypts, scores, R), max_num).long()
 
 
+@_on_device
 def knn_seeds(normed, seeds, k: int, return_dist: bool = False):
     """normed [bs,N,128], seeds [bs,S] int32 -> knn_idx [bs,S,k] int32."""
     lib = _lib.load()
@@ -338,6 +375,7 @@ def knn_seeds(normed, seeds, k: int, return_dist: bool = False):
     return (idx, dist[..., :n]) if return_dist else idx
 
 
+@_on_device
 def seed_power_iteration(normed, src, tgt, knn_idx, sigma, sigma_spat, num_iterations: int, want_M: bool = False):
     lib = _lib.load()
     normed, src, tgt = _chk(normed, "normed"), _chk(src, "src"), _chk(tgt, "tgt")
@@ -354,6 +392,7 @@ def seed_power_iteration(normed, src, tgt, knn_idx, sigma, sigma_spat, num_itera
     return iters, mask, M
 
 
+@_on_device
 def seed_transforms(src, tgt, knn_idx, iters, mask, num_iterations: int):
     lib = _lib.load()
     src, tgt = _chk(src, "src"), _chk(tgt, "tgt")
@@ -367,6 +406,7 @@ def seed_transforms(src, tgt, knn_idx, iters, mask, num_iterations: int):
     return trans, w
 
 
+@_on_device
 def rigid_transform_3d(A: torch.Tensor, B: torch.Tensor, weights: Optional[torch.Tensor] = None,
                        weight_threshold: float = 0) -> torch.Tensor:
     """Drop-in for reference models/common.py:rigid_transform_3d: A,B [bs,n,3] -> [bs,4,4]."""
@@ -380,6 +420,7 @@ def rigid_transform_3d(A: torch.Tensor, B: torch.Tensor, weights: Optional[torch
     return T
 
 
+@_on_device
 def score_hypotheses(seed_trans, src, tgt, inlier_threshold: float):
     lib = _lib.load()
     seed_trans, src, tgt = _chk(seed_trans, "seed_trans"), _chk(src, "src"), _chk(tgt, "tgt")
@@ -396,6 +437,7 @@ def score_hypotheses(seed_trans, src, tgt, inlier_threshold: float):
     return counts, best, initial, labels
 
 
+@_on_device
 def post_refinement(initial_trans, src, tgt, threshold: float, max_iters: int = 20):
     lib = _lib.load()
     initial_trans, src, tgt = _chk(initial_trans, "initial_trans"), _chk(src, "src"), _chk(tgt, "tgt")
