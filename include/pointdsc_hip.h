@@ -299,6 +299,14 @@ int pdsc_seed_transforms(const float* src_keypts, const float* tgt_keypts, const
                          float* seed_weights /* optional [bs][S][k] */,
                          int bs, int N, int S, int k, int num_iterations, void* stream);
 
+/* ---- a-7 + a-8 + a-9 in one launch (what the forward calls) -------------------------------------
+ * pdsc_seed_power_iteration and, for the LAST iterate, pdsc_seed_transforms by the same wavefront that owns the seed;
+ * a second, normally empty launch re-solves the seeds of a pair whose global early exit (conv_mask) selected an earlier
+ * iterate.  seed_trans / seed_weights / seed_M may be NULL (then this is pdsc_seed_power_iteration). */
+int pdsc_seed_solve(const float* normed, const float* src_keypts, const float* tgt_keypts, const int* knn_idx,
+                    const float* sigma, const float* sigma_spat, float* eig_iters, unsigned int* conv_mask, float* seed_M,
+                    float* seed_trans, float* seed_weights, int bs, int N, int S, int k, int num_iterations, void* stream);
+
 /* rigid_transform_3d(A, B, weights, weight_threshold) (models/common.py:7-45 + utils/SE3.py:73-96):
  * A,B [bs][n][3], weights [bs][n] or NULL (=1), T [bs][16] row-major 4x4 with p_B = R p_A + t.
  * weights are NOT modified (the reference zeroes weights < threshold in place). */

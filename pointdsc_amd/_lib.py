@@ -81,6 +81,7 @@ SIGNATURES = {
     "pdsc_rank_select": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pdsc_knn_seeds": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pdsc_seed_power_iteration": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pdsc_seed_solve": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _vp]),
     "pdsc_seed_transforms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pdsc_rigid_transform_3d": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "pdsc_score_hypotheses": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),

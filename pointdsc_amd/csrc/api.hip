@@ -412,11 +412,17 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     }
     // Step 3 & 4 (:182 -> :234-336): per-seed hypotheses, scoring, best
     PDSC_TRY(pdsc_knn_seeds(normed, seeds, knn_dist, knn_idx, bs, N, S, k, stream));
-    PDSC_TRY(pdsc_seed_power_iteration(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig,
-                                       conv_mask, nullptr, bs, N, S, k, cfg->num_iterations, stream));
-    if (mode == 1 && bs > 1) PDSC_TRY(pdsc_conv_mask_all_pairs(conv_mask, bs, stream));
-    PDSC_TRY(pdsc_seed_transforms(src, tgt, knn_idx, eig, conv_mask, seed_trans, seed_w, bs, N, S, k,
-                                  cfg->num_iterations, stream));
+    if (mode == 1 && bs > 1) {
+        // validation forward: the early exit is taken over the seeds of ALL pairs of the batch (one torch.allclose over
+        // [bs*S, k]) -- the per-pair masks are AND-ed before the iterate is chosen, so the two steps stay apart
+        PDSC_TRY(pdsc_seed_power_iteration(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig,
+                                           conv_mask, nullptr, bs, N, S, k, cfg->num_iterations, stream));
+        PDSC_TRY(pdsc_conv_mask_all_pairs(conv_mask, bs, stream));
+        PDSC_TRY(pdsc_seed_transforms(src, tgt, knn_idx, eig, conv_mask, seed_trans, seed_w, bs, N, S, k,
+                                      cfg->num_iterations, stream));
+    } else
+        PDSC_TRY(pdsc_seed_solve(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig, conv_mask, nullptr,
+                                 seed_trans, seed_w, bs, N, S, k, cfg->num_iterations, stream));
     PDSC_TRY(pdsc_score_hypotheses(seed_trans, src, tgt, cfg->inlier_threshold, counts, bs, N, S, stream));
     if (mode == 0) {
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S,

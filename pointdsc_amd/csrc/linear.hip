@@ -111,28 +111,40 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
     }
 }
 
-// encoder.layer0: in_dim (<=8) inputs -> C channels, pure VALU (K=6 is too thin for MFMA).
+// encoder.layer0: in_dim (<=8) inputs -> C channels, pure VALU (K=6 is too thin for MFMA); bound by the 512 B per point it
+// writes.  A thread keeps its 4 channels' weights (4 x 8 + bias) in registers and walks L0_ROWS_PER_THREAD rows: per row
+// in_dim broadcast loads, 32 FMAs, one 16-byte store (a wave instruction stores 2 whole rows).
+constexpr int L0_ROWS_PER_BLOCK = 128, L0_ROWS_PER_THREAD = L0_ROWS_PER_BLOCK / 8;
 __global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ corr, int in_dim,
                                                      const float* __restrict__ W0, const float* __restrict__ b0,
                                                      float* __restrict__ feat, int M) {
-    // thread -> (row, 4 consecutive channels); 32 threads per row
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long row = gid >> 5;
-    const int c4 = (int)(gid & 31) * 4;
-    if (row >= M) return;
-    float x[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) x[d] = d < in_dim ? corr[row * in_dim + d] : 0.f;
-    f32x4 o;
+    const int c4 = (threadIdx.x & 31) * 4, rl = threadIdx.x >> 5;        // 32 channel groups x 8 row lanes
+    float w[4][8], bias[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float* w = W0 + (c4 + c) * 8;
-        float s = 0.f;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(W0 + (c4 + c) * 8), hi = *reinterpret_cast<const f32x4*>(W0 + (c4 + c) * 8 + 4);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) s = fmaf(x[d], w[d], s);
-        o[c] = s + b0[c4 + c];
+        for (int d = 0; d < 4; ++d) { w[c][d] = lo[d]; w[c][4 + d] = hi[d]; }
+        bias[c] = b0[c4 + c];
     }
-    *reinterpret_cast<f32x4*>(feat + row * PDSC_CHANNELS + c4) = o;
+    const long long row0 = (long long)blockIdx.x * L0_ROWS_PER_BLOCK + rl;
+#pragma unroll 4
+    for (int i = 0; i < L0_ROWS_PER_THREAD; ++i) {
+        const long long row = row0 + 8 * i;
+        if (row >= M) break;
+        float x[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) x[d] = d < in_dim ? corr[row * in_dim + d] : 0.f;
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s = fmaf(x[d], w[c][d], s);      // same chain as before: bit-identical results
+            o[c] = s + bias[c];
+        }
+        *reinterpret_cast<f32x4*>(feat + row * PDSC_CHANNELS + c4) = o;
+    }
 }
 
 static size_t linear_lds_bytes(int NT, int K) { return (size_t)(LIN_BM + 64 * NT) * (K + 4) * sizeof(float); }
@@ -301,8 +313,7 @@ extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, c
                            void* stream) {
     PDSC_REQUIRE(corr_pos && W0 && b0 && feat, "pdsc_layer0: null pointer");
     PDSC_REQUIRE(in_dim >= 1 && in_dim <= 8 && M > 0, "pdsc_layer0: in_dim=%d M=%d", in_dim, M);
-    const long long threads = (long long)M * 32;
-    hipLaunchKernelGGL(pdsc::layer0_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pdsc::layer0_kernel, dim3((unsigned)pdsc::ceil_div(M, pdsc::L0_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
                        corr_pos, in_dim, W0, b0, feat, M);
     return pdsc::check_launch("pdsc_layer0");
 }

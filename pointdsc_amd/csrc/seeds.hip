@@ -78,31 +78,85 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
     if (!ok1 && i1 < N) keys[(size_t)b * N + i1] = c1 * 0.0f;
 }
 
-// ---- stable descending rank by counting; seeds[rank] = index for rank < num_seeds -------------------
-__global__ __launch_bounds__(256) void rank_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds,
-                                                          int N, int num_seeds) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    if (i >= N) return;
+// ---- top-S by descending key, equal keys by ascending index: one workgroup per pair ---------------------
+//   1. radix select (4 x 8 bits, most significant first) of the S-th value in descending order on monotone key bits
+//      (-0.0 and +0.0 compare equal, as in torch.sort);
+//   2. the S survivors -- every key above the threshold value plus the lowest-index keys equal to it -- are collected as
+//      composites (descending-key bits << 32 | index);
+//   3. each survivor's rank among the S composites (S^2 comparisons instead of N^2) places its index into seeds[].
+// Replaces an N^2 rank count (158 us at 32 pairs of N = 5000).
+constexpr int SEL_THREADS = 1024;
+__device__ __forceinline__ unsigned int desc_key_bits(float f) {
+    unsigned int u = __float_as_uint(f == 0.0f ? 0.0f : f);                    // -0.0 -> +0.0
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                           // ascending float order == ascending unsigned
+    return ~u;                                                                // ... descending
+}
+__global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds, int N,
+                                                                  int num_seeds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long surv[];     // [num_seeds]
+    __shared__ int hist[256];
+    __shared__ unsigned int sh_prefix;
+    __shared__ int sh_remaining, sh_count, sh_eq_base;
+    __shared__ int wave_cnt[SEL_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
     const float* k = keys + (size_t)b * N;
-    const float ki = k[i];
-    // the rank is only needed when it is < num_seeds: the count is kept wave-uniform (ballot + popcount) and the scan stops
-    // as soon as num_seeds predecessors are known -- on average ~1/3 of the N^2 comparisons (S = N/10)
-    int cnt = 0;
-    for (int j0 = 0; j0 < N && cnt < num_seeds; j0 += 256) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 64 * u + lane;
-            bool before = false;
-            if (j < N) {
-                const float kj = k[j];
-                before = (kj > ki) || (kj == ki && j < i);
-            }
-            cnt += __popcll(__ballot(before));
+    unsigned int prefix = 0, mask = 0;
+    int remaining = num_seeds;                        // 1-based rank of the wanted value inside the current candidate set
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        for (int i = t; i < N; i += SEL_THREADS) {
+            const unsigned int u = desc_key_bits(k[i]);
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
         }
+        __syncthreads();
+        if (t == 0) {
+            int before = 0, d = 0;
+            for (; d < 255; ++d) {
+                if (before + hist[d] >= remaining) break;
+                before += hist[d];
+            }
+            sh_prefix = prefix | ((unsigned int)d << shift);
+            sh_remaining = remaining - before;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        remaining = sh_remaining;
+        mask |= 255u << shift;
     }
-    if (lane == 0 && cnt < num_seeds) seeds[(size_t)b * num_seeds + cnt] = i;
+    // prefix = the S-th value (descending); `remaining` of the keys equal to it are wanted: those with the lowest indices
+    if (t == 0) { sh_count = 0; sh_eq_base = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += SEL_THREADS) {
+        const int i = i0 + t;
+        const unsigned int u = i < N ? desc_key_bits(k[i]) : 0xFFFFFFFFu;
+        const bool eq = i < N && u == prefix;
+        const unsigned long long bal = __ballot(eq);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int eq_before = sh_eq_base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) eq_before += wave_cnt[w];
+        const bool take = i < N && (u < prefix || (eq && eq_before < remaining));
+        if (take) {
+            const int slot = atomicAdd(&sh_count, 1);
+            surv[slot] = ((unsigned long long)u << 32) | (unsigned int)i;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int w = 0; w < SEL_THREADS / 64; ++w) tot += wave_cnt[w];
+            sh_eq_base += tot;
+        }
+        __syncthreads();
+    }
+    // exactly num_seeds survivors; rank each among them (composites are unique)
+    for (int e = t; e < num_seeds; e += SEL_THREADS) {
+        const unsigned long long mine = surv[e];
+        int rank = 0;
+        for (int f = 0; f < num_seeds; ++f) rank += surv[f] < mine;          // LDS broadcast reads
+        seeds[(size_t)b * num_seeds + rank] = (int)(mine & 0xFFFFFFFFull);
+    }
 }
 
 // ---- kNN selection: one workgroup per seed row, radix select (8-bit digits, most significant first) of the
@@ -285,8 +339,13 @@ extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, in
     PDSC_REQUIRE(keys && seeds, "pdsc_rank_select: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && num_seeds >= 0 && num_seeds <= N, "pdsc_rank_select: bs=%d N=%d S=%d", bs, N, num_seeds);
     if (num_seeds == 0) return PDSC_OK;
-    hipLaunchKernelGGL(pdsc::rank_select_kernel, dim3(pdsc::ceil_div(N, 4), bs), dim3(256), 0, (hipStream_t)stream, keys,
-                       seeds, N, num_seeds);
+    const size_t lds_bytes = (size_t)num_seeds * sizeof(unsigned long long);
+    PDSC_REQUIRE(lds_bytes <= 128 * 1024, "pdsc_rank_select: num_seeds=%d exceeds the single-workgroup LDS list (16384)", num_seeds);
+    const int rc = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::seed_select_kernel), lds_bytes > 65536 ? 128 * 1024 : 65536,
+                                            "pdsc_rank_select(dynamic LDS)");
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(pdsc::seed_select_kernel, dim3(bs), dim3(pdsc::SEL_THREADS), lds_bytes, (hipStream_t)stream, keys, seeds, N,
+                       num_seeds);
     return pdsc::check_launch("pdsc_rank_select");
 }
 

@@ -3,119 +3,11 @@
 //   reference: models/PointDSC.py:257-282 (matrices + weight normalisation), :347-358 (power iteration),
 //              models/common.py:7-45 (rigid_transform_3d; torch.svd is done on the HOST there),
 //              utils/SE3.py:73-96 (integrate_trans).
-// One workgroup per seed, lane i of every wave owns neighbour i (k <= 64); the k x k matrix build (k^2 x 128 MACs, the
-// only sizeable part) is split column-wise over the 4 waves.  Nothing here is bandwidth- or MFMA-bound
-// (S * ~0.5 MFLOP); the point is zero host round trips (the reference pays one D2H+H2D per SVD batch and
-// one sync per power iteration) and k x k never leaving LDS.
+// One WAVEFRONT per seed (seed_solve_kernel below), lane i owns neighbour i (k <= 64).  Zero host round trips (the reference
+// pays one D2H+H2D per SVD batch and one sync per power iteration); k x k never leaves the CU.
 #include "pdsc_common.h"
 
 namespace pdsc {
-
-constexpr int FS_LD = PDSC_CHANNELS + 4;     // padded feature row (16 distinct bank slots for b128 reads)
-constexpr int MS_LD = PDSC_MAX_K + 1;
-
-constexpr int SP_WAVES = 4;
-
-__global__ __launch_bounds__(64 * SP_WAVES) void seed_power_kernel(const float* __restrict__ normed, const float* __restrict__ src,
-                                                        const float* __restrict__ tgt, const int* __restrict__ knn_idx,
-                                                        const float* __restrict__ sigma, const float* __restrict__ sigma_spat,
-                                                        float* __restrict__ eig_iters, unsigned int* __restrict__ conv_mask,
-                                                        float* __restrict__ seed_M, int N, int S, int k, int num_iter) {
-    extern __shared__ __attribute__((aligned(16))) float Fs[];        // [k][FS_LD]
-    __shared__ __attribute__((aligned(16))) float Ms[PDSC_MAX_K * MS_LD];
-    __shared__ __attribute__((aligned(16))) float pts[PDSC_MAX_K][8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = blockIdx.x, b = blockIdx.y;
-    const bool valid = lane < k;
-    const int* idxp = knn_idx + ((size_t)b * S + s) * k;
-    const int idx = idxp[valid ? lane : 0];
-    const float* srcb = src + (size_t)b * N * 3;
-    const float* tgtb = tgt + (size_t)b * N * 3;
-    const float* nb = normed + (size_t)b * N * PDSC_CHANNELS;
-    if (wave == 0) {
-        pts[lane][0] = srcb[idx * 3]; pts[lane][1] = srcb[idx * 3 + 1]; pts[lane][2] = srcb[idx * 3 + 2];
-        pts[lane][4] = tgtb[idx * 3]; pts[lane][5] = tgtb[idx * 3 + 1]; pts[lane][6] = tgtb[idx * 3 + 2];
-    }
-    // gather the k feature rows (32 float4 chunks each), two rows per wave instruction
-    for (int e = threadIdx.x; e < k * 32; e += 64 * SP_WAVES) {
-        const int j = e >> 5, c = e & 31;
-        const int rj = __shfl(idx, j, 64);           // every wave holds the same idx vector
-        *reinterpret_cast<f32x4*>(Fs + j * FS_LD + c * 4) = *reinterpret_cast<const f32x4*>(nb + (size_t)rj * PDSC_CHANNELS + c * 4);
-    }
-    __syncthreads();
-
-    const float sg = sigma[0], sig2 = sg * sg;
-    const float sd = sigma_spat[0], sd2 = sd * sd;
-    // k x k feature Gram on the exact fp32 MFMA: wave w owns the 32 x 32 tile (rows 32(w>>1).., columns 32(w&1)..) of the
-    // k <= 64 neighbours; rows >= k of Fs are never written, their products land in rows / columns >= k that are skipped.
-    // Accumulator lane = column j, register r = row i: the spatial term is evaluated in the same layout (the points of
-    // row i are LDS broadcasts) and the finished M goes to LDS row-major for the power iteration.
-    {
-        const int rb = wave >> 1, cb = wave & 1;
-        const int jcol = 32 * cb + (lane & 31), hh = lane >> 5;
-        if (32 * rb < k && 32 * cb < k) {              // wave-uniform: tiles entirely beyond k have nothing to do
-            const float* arow = Fs + min(32 * rb + (lane & 31), k - 1) * FS_LD + 4 * hh;
-            const float* brow = Fs + min(jcol, k - 1) * FS_LD + 4 * hh;
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * q);
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + 8 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
-            }
-            const int jc = min(jcol, k - 1);
-            const float jx = pts[jc][0], jy = pts[jc][1], jz = pts[jc][2];
-            const float kx = pts[jc][4], ky = pts[jc][5], kz = pts[jc][6];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (i < k && jcol < k) {
-                    const float fm = fmaxf(1.0f - (1.0f - acc[r]) / sig2, 0.0f);
-                    const float dx = pts[i][0] - jx, dy = pts[i][1] - jy, dz = pts[i][2] - jz;
-                    const float ex = pts[i][4] - kx, ey = pts[i][5] - ky, ez = pts[i][6] - kz;
-                    const float ds = sqrtf((dx * dx + dy * dy) + dz * dz);          // ((a-b)**2).sum(-1) ** 0.5
-                    const float dt = sqrtf((ex * ex + ey * ey) + ez * ez);
-                    const float df = ds - dt;
-                    const float sm = fmaxf(1.0f - (df * df) / sd2, 0.0f);
-                    const float m = (i == jcol) ? 0.0f : fm * sm;
-                    Ms[i * MS_LD + jcol] = m;
-                    if (seed_M) seed_M[(((size_t)b * S + s) * k + i) * k + jcol] = m;
-                }
-            }
-        }
-    }
-    __syncthreads();                                 // Ms complete
-    if (wave != 0) return;                           // the power iteration is one wave's work
-    // power iteration: v <- M v / (||M v|| + 1e-6), every iterate kept, allclose flag per iteration
-    float v = valid ? 1.0f : 0.0f;
-    float last = v;
-    unsigned int bits = 0;
-    float* out = eig_iters + ((size_t)b * S + s) * num_iter * PDSC_MAX_K;
-    float mrow[PDSC_MAX_K];                          // this lane's row of M, in registers for all iterations
-    {
-        const float* mr = Ms + lane * MS_LD;
-#pragma unroll
-        for (int j = 0; j < PDSC_MAX_K; ++j) mrow[j] = j < k ? mr[j] : 0.f;
-    }
-    for (int it = 0; it < num_iter; ++it) {
-        float nv = 0.f;
-#pragma unroll
-        for (int j = 0; j < PDSC_MAX_K; ++j)
-            // j >= k: mrow[j] = 0 and v[j] = 0 add an exact zero, so this is the j = 0..k-1 chain without 64 branches
-            nv = fmaf(mrow[j], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j)), nv);
-        nv = valid ? nv : 0.f;
-        const float nrm = sqrtf(wave_sum(nv * nv));
-        v = nv / (nrm + 1e-6f);
-        out[it * PDSC_MAX_K + lane] = v;
-        const bool close = fabsf(v - last) <= (1e-8f + 1e-5f * fabsf(last));   // torch.allclose(v, last)
-        if (__all(close || !valid)) bits |= (1u << it);
-        last = v;
-    }
-    if (lane == 0) atomicAnd(conv_mask + b, bits);
-}
 
 // chosen iterate = first iteration at which EVERY seed of the pair passed allclose (the reference breaks
 // there), else the last one.
@@ -124,30 +16,14 @@ __device__ __forceinline__ int chosen_iterate(unsigned int mask, int num_iter) {
     return m ? (__ffs((int)m) - 1) : (num_iter - 1);
 }
 
-__global__ __launch_bounds__(64) void seed_transform_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                            const int* __restrict__ knn_idx,
-                                                            const float* __restrict__ eig_iters,
-                                                            const unsigned int* __restrict__ conv_mask,
-                                                            float* __restrict__ seed_trans, float* __restrict__ seed_w,
-                                                            int N, int S, int k, int num_iter) {
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x, b = blockIdx.y;
-    const bool valid = lane < k;
-    const int idx = knn_idx[((size_t)b * S + s) * k + (valid ? lane : 0)];
-    const float* srcb = src + (size_t)b * N * 3;
-    const float* tgtb = tgt + (size_t)b * N * 3;
-    float v = valid ? 1.0f : 0.0f;
-    if (num_iter > 0) {
-        const int it = chosen_iterate(conv_mask[b], num_iter);
-        v = eig_iters[(((size_t)b * S + s) * num_iter + it) * PDSC_MAX_K + lane];
-        v = valid ? v : 0.f;
-    }
+// weighted Procrustes of one seed: lane = neighbour, v = its eigenvector entry (0 for lanes >= k).
+// models/PointDSC.py:282 (weight normalisation), models/common.py:17-45.  Writes the 4x4 (lane 0) and the weights.
+__device__ __forceinline__ void seed_procrustes(int lane, bool valid, float v, float ax, float ay, float az, float bx, float by,
+                                                float bz, float* __restrict__ trans_out, float* __restrict__ w_out) {
     float w = v / (wave_sum(v) + 1e-6f);                       // models/PointDSC.py:282
     if (w < 0.f) w = 0.f;                                      // models/common.py:20 (weight_threshold = 0)
     w = valid ? w : 0.f;
-    if (seed_w && valid) seed_w[((size_t)b * S + s) * k + lane] = w;
-    const float ax = srcb[idx * 3], ay = srcb[idx * 3 + 1], az = srcb[idx * 3 + 2];
-    const float bx = tgtb[idx * 3], by = tgtb[idx * 3 + 1], bz = tgtb[idx * 3 + 2];
+    if (w_out && valid) w_out[lane] = w;
     const float den = wave_sum(w) + 1e-6f;
     float cA[3] = {wave_sum(ax * w) / den, wave_sum(ay * w) / den, wave_sum(az * w) / den};
     float cB[3] = {wave_sum(bx * w) / den, wave_sum(by * w) / den, wave_sum(bz * w) / den};
@@ -158,7 +34,177 @@ __global__ __launch_bounds__(64) void seed_transform_kernel(const float* __restr
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) H[r * 3 + c] = wave_sum(am[r] * w * bm[c]);
-    if (lane == 0) kabsch_from_covariance(H, cA, cB, seed_trans + ((size_t)b * S + s) * 16);
+    if (lane == 0) kabsch_from_covariance(H, cA, cB, trans_out);
+}
+
+// only_if_early_exit: the fused solver below already wrote the hypotheses of the LAST iterate; this launch then re-solves
+// a pair's seeds only when the reference's global early exit picked an earlier iterate (rare), and returns at once otherwise.
+__global__ __launch_bounds__(64) void seed_transform_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                            const int* __restrict__ knn_idx,
+                                                            const float* __restrict__ eig_iters,
+                                                            const unsigned int* __restrict__ conv_mask,
+                                                            float* __restrict__ seed_trans, float* __restrict__ seed_w,
+                                                            int N, int S, int k, int num_iter, int only_if_early_exit) {
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const bool valid = lane < k;
+    int it = num_iter - 1;
+    if (num_iter > 0) it = chosen_iterate(conv_mask[b], num_iter);
+    if (only_if_early_exit && it == num_iter - 1) return;
+    const int idx = knn_idx[((size_t)b * S + s) * k + (valid ? lane : 0)];
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    float v = valid ? 1.0f : 0.0f;
+    if (num_iter > 0) {
+        v = eig_iters[(((size_t)b * S + s) * num_iter + it) * PDSC_MAX_K + lane];
+        v = valid ? v : 0.f;
+    }
+    seed_procrustes(lane, valid, v, srcb[idx * 3], srcb[idx * 3 + 1], srcb[idx * 3 + 2], tgtb[idx * 3], tgtb[idx * 3 + 1],
+                    tgtb[idx * 3 + 2], seed_trans + ((size_t)b * S + s) * 16, seed_w ? seed_w + ((size_t)b * S + s) * k : nullptr);
+}
+
+// ---- fused per-seed solver (a-7 + a-8 + a-9 in one launch): ONE WAVEFRONT PER SEED -----------------------------------------
+// NB = ceil(k / 16) blocks of 16 neighbours.  The feature rows go straight from global memory (L2-resident: 2.5 MB per pair)
+// into MFMA operand registers -- lane (row r = lane & 15 of a block, k-slot kq = lane >> 4) holds channels 16 q + 4 kq + e,
+// q = 0..7, of neighbour 16 R + r: 8 float4 per block -- and the k x k Gram is accumulated on v_mfma_f32_16x16x4_f32 for
+// the NB (NB + 1) / 2 tiles on / above the diagonal only (M is symmetric bit for bit: same products, same order).  The
+// spatial term is evaluated in the accumulator layout, M goes to a wave-private LDS patch (mirrored), every lane < k then
+// owns one row in registers for the power iterations (v broadcast through LDS), and the same lanes (= neighbours) feed the
+// weighted Procrustes of the last iterate.  No workgroup barrier anywhere: the 4 waves of a workgroup are independent.
+constexpr int SV_WAVES = 4;
+template <int NB>
+struct SolveLds {
+    static constexpr int KP = 16 * NB, MLD = KP + 1;
+    float M[KP * MLD];
+    float pts[KP][8];
+    float v[KP];
+};
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NB>
+__global__ __launch_bounds__(64 * SV_WAVES) void seed_solve_kernel(const float* __restrict__ normed, const float* __restrict__ src,
+                                                                   const float* __restrict__ tgt, const int* __restrict__ knn_idx,
+                                                                   const float* __restrict__ sigma, const float* __restrict__ sigma_spat,
+                                                                   float* __restrict__ eig_iters, unsigned int* __restrict__ conv_mask,
+                                                                   float* __restrict__ seed_M, float* __restrict__ seed_trans,
+                                                                   float* __restrict__ seed_w, int N, int S, int k, int num_iter) {
+    using L = SolveLds<NB>;
+    constexpr int KP = L::KP, MLD = L::MLD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.x * SV_WAVES + wave, b = blockIdx.y;
+    if (s >= S) return;                                   // wave-uniform; no workgroup barrier below
+    L& sh = *reinterpret_cast<L*>(lds_raw + (size_t)wave * sizeof(L));
+    const bool valid = lane < k;
+    const int* idxp = knn_idx + ((size_t)b * S + s) * k;
+    const int idx = idxp[valid ? lane : 0];
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    const float* nb = normed + (size_t)b * N * PDSC_CHANNELS;
+    const float ax = srcb[idx * 3], ay = srcb[idx * 3 + 1], az = srcb[idx * 3 + 2];
+    const float bx = tgtb[idx * 3], by = tgtb[idx * 3 + 1], bz = tgtb[idx * 3 + 2];
+    if (lane < KP) {
+        *reinterpret_cast<f32x4*>(&sh.pts[lane][0]) = f32x4{ax, ay, az, 0.f};
+        *reinterpret_cast<f32x4*>(&sh.pts[lane][4]) = f32x4{bx, by, bz, 0.f};
+    }
+    // operand fragments: block R, chunk q -> float4 of neighbour min(16 R + (lane & 15), k - 1)
+    const int r16 = lane & 15, kq = lane >> 4;
+    f32x4 frag[NB][8];
+#pragma unroll
+    for (int R = 0; R < NB; ++R) {
+        const int nbr = __shfl(idx, min(16 * R + r16, k - 1), 64);
+        const float* row = nb + (size_t)nbr * PDSC_CHANNELS + 4 * kq;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) frag[R][q] = *reinterpret_cast<const f32x4*>(row + 16 * q);
+    }
+    const float sg = sigma[0], sig2 = sg * sg;
+    const float sd = sigma_spat[0], sd2 = sd * sd;
+    wave_lds_sync();                                      // pts visible to the wave
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+            if (16 * J >= k) continue;                    // wave-uniform: tile entirely beyond k
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[I][q][e], frag[J][q][e], acc, 0, 0, 0);
+            // accumulator: column j = 16 J + (lane & 15), rows i = 16 I + 4 (lane >> 4) + r
+            const int j = 16 * J + r16;
+            const f32x4 pj = *reinterpret_cast<const f32x4*>(&sh.pts[j][0]);
+            const f32x4 qj = *reinterpret_cast<const f32x4*>(&sh.pts[j][4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + 4 * kq + r;
+                const f32x4 pi = *reinterpret_cast<const f32x4*>(&sh.pts[i][0]);
+                const f32x4 qi = *reinterpret_cast<const f32x4*>(&sh.pts[i][4]);
+                const float fm = fmaxf(1.0f - (1.0f - acc[r]) / sig2, 0.0f);
+                const float dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
+                const float ex = qi[0] - qj[0], ey = qi[1] - qj[1], ez = qi[2] - qj[2];
+                const float ds = sqrtf((dx * dx + dy * dy) + dz * dz);          // ((a-b)**2).sum(-1) ** 0.5
+                const float dt = sqrtf((ex * ex + ey * ey) + ez * ez);
+                const float df = ds - dt;
+                const float sm = fmaxf(1.0f - (df * df) / sd2, 0.0f);
+                const float m = (i == j || i >= k || j >= k) ? 0.0f : fm * sm;
+                sh.M[i * MLD + j] = m;
+                if (I != J) sh.M[j * MLD + i] = m;        // mirror (block-uniform condition)
+            }
+        }
+    }
+    wave_lds_sync();
+    if (seed_M) {
+        for (int e = lane; e < k * k; e += 64) seed_M[((size_t)b * S + s) * k * k + e] = sh.M[(e / k) * MLD + (e % k)];
+    }
+    // power iteration: v <- M v / (||M v|| + 1e-6), every iterate kept, allclose flag per iteration
+    float mrow[KP];
+    {
+        const float* mr = sh.M + min(lane, KP - 1) * MLD;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) mrow[j] = mr[j];
+    }
+    float v = valid ? 1.0f : 0.0f, last = v;
+    unsigned int bits = 0;
+    float* out = eig_iters + ((size_t)b * S + s) * num_iter * PDSC_MAX_K;
+    for (int it = 0; it < num_iter; ++it) {
+        if (lane < KP) sh.v[lane] = v;
+        wave_lds_sync();
+        float nv = 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < KP / 4; ++j4) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&sh.v[4 * j4]);     // broadcast
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nv = fmaf(mrow[4 * j4 + e], vv[e], nv);  // the j = 0..k-1 chain (rows / columns >= k are 0)
+        }
+        nv = valid ? nv : 0.f;
+        const float nrm = sqrtf(wave_sum(nv * nv));
+        v = nv / (nrm + 1e-6f);
+        out[it * PDSC_MAX_K + lane] = v;
+        const bool close = fabsf(v - last) <= (1e-8f + 1e-5f * fabsf(last));   // torch.allclose(v, last)
+        if (__all(close || !valid)) bits |= (1u << it);
+        last = v;
+        wave_lds_sync();                                  // everyone has read sh.v before it is overwritten
+    }
+    if (lane == 0) atomicAnd(conv_mask + b, bits);
+    if (seed_trans)                                       // hypothesis of the LAST iterate (the common case, see seed_transform_kernel)
+        seed_procrustes(lane, valid, valid ? v : 0.f, ax, ay, az, bx, by, bz, seed_trans + ((size_t)b * S + s) * 16,
+                        seed_w ? seed_w + ((size_t)b * S + s) * k : nullptr);
+}
+
+template <int NB>
+static int launch_seed_solve(const float* normed, const float* src, const float* tgt, const int* knn_idx, const float* sigma,
+                             const float* sigma_spat, float* eig_iters, unsigned int* conv_mask, float* seed_M, float* seed_trans,
+                             float* seed_w, int bs, int N, int S, int k, int num_iter, hipStream_t st) {
+    const size_t lds_bytes = SV_WAVES * sizeof(SolveLds<NB>);
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&seed_solve_kernel<NB>), lds_bytes, "pdsc_seed_solve(dynamic LDS)");
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(seed_solve_kernel<NB>, dim3(ceil_div(S, SV_WAVES), bs), dim3(64 * SV_WAVES), lds_bytes, st, normed, src, tgt,
+                       knn_idx, sigma, sigma_spat, eig_iters, conv_mask, seed_M, seed_trans, seed_w, N, S, k, num_iter);
+    return check_launch("pdsc_seed_solve");
 }
 
 // general rigid_transform_3d(A, B, weights, weight_threshold): one 256-thread workgroup per problem
@@ -225,12 +271,30 @@ extern "C" int pdsc_seed_power_iteration(const float* normed, const float* src, 
     PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K, "pdsc_seed_power_iteration: k=%d (max %d)", k, PDSC_MAX_K);
     PDSC_REQUIRE(num_iterations >= 0 && num_iterations <= PDSC_MAX_POWER_ITERS,
                  "pdsc_seed_power_iteration: num_iterations=%d (max %d)", num_iterations, PDSC_MAX_POWER_ITERS);
+    return pdsc_seed_solve(normed, src, tgt, knn_idx, sigma, sigma_spat, eig_iters, conv_mask, seed_M, nullptr, nullptr, bs, N, S, k,
+                           num_iterations, stream);
+}
+
+extern "C" int pdsc_seed_solve(const float* normed, const float* src, const float* tgt, const int* knn_idx, const float* sigma,
+                               const float* sigma_spat, float* eig_iters, unsigned int* conv_mask, float* seed_M, float* seed_trans,
+                               float* seed_weights, int bs, int N, int S, int k, int num_iterations, void* stream) {
+    PDSC_REQUIRE(normed && src && tgt && knn_idx && sigma && sigma_spat && eig_iters && conv_mask, "pdsc_seed_solve: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_seed_solve: bs=%d N=%d S=%d", bs, N, S);
+    PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K, "pdsc_seed_solve: k=%d (max %d)", k, PDSC_MAX_K);
+    PDSC_REQUIRE(num_iterations >= 0 && num_iterations <= PDSC_MAX_POWER_ITERS, "pdsc_seed_solve: num_iterations=%d (max %d)",
+                 num_iterations, PDSC_MAX_POWER_ITERS);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(conv_mask, 0xFF, sizeof(unsigned int) * bs, st) != hipSuccess) return pdsc::check_launch("memset");
-    const size_t lds_bytes = (size_t)k * pdsc::FS_LD * sizeof(float);
-    hipLaunchKernelGGL(pdsc::seed_power_kernel, dim3(S, bs), dim3(64 * pdsc::SP_WAVES), lds_bytes, st, normed, src, tgt, knn_idx, sigma,
-                       sigma_spat, eig_iters, conv_mask, seed_M, N, S, k, num_iterations);
-    return pdsc::check_launch("pdsc_seed_power_iteration");
+    const int nb = pdsc::ceil_div(k, 16);
+#define PDSC_SOLVE(NBV) pdsc::launch_seed_solve<NBV>(normed, src, tgt, knn_idx, sigma, sigma_spat, eig_iters, conv_mask, seed_M, seed_trans, \
+                                                     seed_weights, bs, N, S, k, num_iterations, st)
+    int rc = nb == 1 ? PDSC_SOLVE(1) : nb == 2 ? PDSC_SOLVE(2) : nb == 3 ? PDSC_SOLVE(3) : PDSC_SOLVE(4);
+#undef PDSC_SOLVE
+    if (rc != PDSC_OK || !seed_trans || num_iterations <= 0) return rc;
+    // the reference's global early exit (models/PointDSC.py:354-356) picked an earlier iterate for some pair: re-solve its seeds
+    hipLaunchKernelGGL(pdsc::seed_transform_kernel, dim3(S, bs), dim3(64), 0, st, src, tgt, knn_idx, eig_iters, conv_mask, seed_trans,
+                       seed_weights, N, S, k, num_iterations, 1);
+    return pdsc::check_launch("pdsc_seed_solve(early-exit fix-up)");
 }
 
 extern "C" int pdsc_seed_transforms(const float* src, const float* tgt, const int* knn_idx, const float* eig_iters,
@@ -240,7 +304,7 @@ extern "C" int pdsc_seed_transforms(const float* src, const float* tgt, const in
     PDSC_REQUIRE(bs > 0 && N > 0 && S > 0 && k >= 1 && k <= PDSC_MAX_K, "pdsc_seed_transforms: bs=%d N=%d S=%d k=%d", bs, N, S, k);
     PDSC_REQUIRE(num_iterations >= 0 && num_iterations <= PDSC_MAX_POWER_ITERS, "pdsc_seed_transforms: num_iterations=%d", num_iterations);
     hipLaunchKernelGGL(pdsc::seed_transform_kernel, dim3(S, bs), dim3(64), 0, (hipStream_t)stream, src, tgt, knn_idx, eig_iters,
-                       conv_mask, seed_trans, seed_weights, N, S, k, num_iterations);
+                       conv_mask, seed_trans, seed_weights, N, S, k, num_iterations, 0);
     return pdsc::check_launch("pdsc_seed_transforms");
 }
 
