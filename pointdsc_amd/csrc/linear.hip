@@ -112,13 +112,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
 }
 
 // encoder.layer0: in_dim (<=8) inputs -> C channels, pure VALU (K=6 is too thin for MFMA); bound by the 512 B per point it
-// writes.  A thread keeps its 4 channels' weights (4 x 8 + bias) in registers and walks L0_ROWS_PER_THREAD rows: per row
+// writes.  A thread keeps its 4 channels' weights (4 x 8 + bias) in registers and walks its share of the rows: per row
 // in_dim broadcast loads, 32 FMAs, one 16-byte store (a wave instruction stores 2 whole rows).
-constexpr int L0_ROWS_PER_BLOCK = 128, L0_ROWS_PER_THREAD = L0_ROWS_PER_BLOCK / 8;
+constexpr int L0_MAX_BLOCKS = 2048;
 __global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ corr, int in_dim,
                                                      const float* __restrict__ W0, const float* __restrict__ b0,
                                                      float* __restrict__ feat, int M) {
-    const int c4 = (threadIdx.x & 31) * 4, rl = threadIdx.x >> 5;        // 32 channel groups x 8 row lanes
+    const int c4 = (threadIdx.x & 31) * 4, rl = threadIdx.x >> 5;        // 32 channel groups x 8 row lanes, grid-stride over rows
     float w[4][8], bias[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -127,11 +127,7 @@ __global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ c
         for (int d = 0; d < 4; ++d) { w[c][d] = lo[d]; w[c][4 + d] = hi[d]; }
         bias[c] = b0[c4 + c];
     }
-    const long long row0 = (long long)blockIdx.x * L0_ROWS_PER_BLOCK + rl;
-#pragma unroll 4
-    for (int i = 0; i < L0_ROWS_PER_THREAD; ++i) {
-        const long long row = row0 + 8 * i;
-        if (row >= M) break;
+    for (long long row = (long long)blockIdx.x * 8 + rl; row < M; row += (long long)gridDim.x * 8) {
         float x[8];
 #pragma unroll
         for (int d = 0; d < 8; ++d) x[d] = d < in_dim ? corr[row * in_dim + d] : 0.f;
@@ -313,7 +309,8 @@ extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, c
                            void* stream) {
     PDSC_REQUIRE(corr_pos && W0 && b0 && feat, "pdsc_layer0: null pointer");
     PDSC_REQUIRE(in_dim >= 1 && in_dim <= 8 && M > 0, "pdsc_layer0: in_dim=%d M=%d", in_dim, M);
-    hipLaunchKernelGGL(pdsc::layer0_kernel, dim3((unsigned)pdsc::ceil_div(M, pdsc::L0_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
+    const int blocks = pdsc::ceil_div(M, 8) < pdsc::L0_MAX_BLOCKS ? pdsc::ceil_div(M, 8) : pdsc::L0_MAX_BLOCKS;
+    hipLaunchKernelGGL(pdsc::layer0_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        corr_pos, in_dim, W0, b0, feat, M);
     return pdsc::check_launch("pdsc_layer0");
 }

@@ -111,14 +111,24 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float* _
             if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (t == 0) {
-            int before = 0, d = 0;
-            for (; d < 255; ++d) {
-                if (before + hist[d] >= remaining) break;
-                before += hist[d];
+        if (wave == 0) {                              // digit d with  sum(hist[< d]) < remaining <= sum(hist[<= d])
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            int incl = (h0 + h1) + (h2 + h3);
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
             }
-            sh_prefix = prefix | ((unsigned int)d << shift);
-            sh_remaining = remaining - before;
+            const unsigned long long reach = __ballot(incl >= remaining);      // never empty: the total is >= remaining
+            const int first = __ffsll((long long)reach) - 1;
+            if (lane == first) {
+                int before = incl - ((h0 + h1) + (h2 + h3)), d = 4 * lane;
+                if (before + h0 < remaining) { before += h0; ++d;
+                    if (before + h1 < remaining) { before += h1; ++d;
+                        if (before + h2 < remaining) { before += h2; ++d; } } }
+                sh_prefix = prefix | ((unsigned int)d << shift);
+                sh_remaining = remaining - before;
+            }
         }
         __syncthreads();
         prefix = sh_prefix;

@@ -16,8 +16,11 @@ __device__ __forceinline__ int chosen_iterate(unsigned int mask, int num_iter) {
     return m ? (__ffs((int)m) - 1) : (num_iter - 1);
 }
 
-// weighted Procrustes of one seed: lane = neighbour, v = its eigenvector entry (0 for lanes >= k).
-// models/PointDSC.py:282 (weight normalisation), models/common.py:17-45.  Writes the 4x4 (lane 0) and the weights.
+// weighted Procrustes of one seed, part 1: lane = neighbour, v = its eigenvector entry (0 for lanes >= k).
+// models/PointDSC.py:282 (weight normalisation), models/common.py:17-33.  Lane 0 leaves the 3x3 covariance H and the two
+// centroids in the seed's 16-float slot (H[9] | cA[3] | cB[3] | -); part 2, kabsch_batch_kernel, turns every slot into the
+// 4x4 in place with ONE THREAD PER SEED: the fp64 Jacobi is ~20 k serial cycles, which as "lane 0 of a wavefront per seed"
+// left 63 of 64 lanes idle and dominated the fused solver (150 of 255 us at 16 000 seeds).
 __device__ __forceinline__ void seed_procrustes(int lane, bool valid, float v, float ax, float ay, float az, float bx, float by,
                                                 float bz, float* __restrict__ trans_out, float* __restrict__ w_out) {
     float w = v / (wave_sum(v) + 1e-6f);                       // models/PointDSC.py:282
@@ -34,7 +37,27 @@ __device__ __forceinline__ void seed_procrustes(int lane, bool valid, float v, f
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) H[r * 3 + c] = wave_sum(am[r] * w * bm[c]);
-    if (lane == 0) kabsch_from_covariance(H, cA, cB, trans_out);
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) trans_out[e] = H[e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { trans_out[9 + e] = cA[e]; trans_out[12 + e] = cB[e]; }
+    }
+}
+
+// part 2 (models/common.py:35-45 + utils/SE3.py:73-96): slot (H | cA | cB) -> row-major 4x4, one thread per seed
+__global__ __launch_bounds__(64) void kabsch_batch_kernel(float* __restrict__ seed_trans, int count) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    float* slot = seed_trans + (size_t)i * 16;
+    float H[9], cA[3], cB[3], T[16];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H[e] = slot[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { cA[e] = slot[9 + e]; cB[e] = slot[12 + e]; }
+    kabsch_from_covariance(H, cA, cB, T);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) slot[e] = T[e];
 }
 
 // only_if_early_exit: the fused solver below already wrote the hypotheses of the LAST iterate; this launch then re-solves
@@ -290,11 +313,18 @@ extern "C" int pdsc_seed_solve(const float* normed, const float* src, const floa
                                                      seed_weights, bs, N, S, k, num_iterations, st)
     int rc = nb == 1 ? PDSC_SOLVE(1) : nb == 2 ? PDSC_SOLVE(2) : nb == 3 ? PDSC_SOLVE(3) : PDSC_SOLVE(4);
 #undef PDSC_SOLVE
-    if (rc != PDSC_OK || !seed_trans || num_iterations <= 0) return rc;
+    if (rc != PDSC_OK || !seed_trans) return rc;
+    if (num_iterations <= 0) {
+        hipLaunchKernelGGL(pdsc::kabsch_batch_kernel, dim3(pdsc::ceil_div(bs * S, 64)), dim3(64), 0, st, seed_trans, bs * S);
+        return pdsc::check_launch("pdsc_seed_solve(kabsch)");
+    }
     // the reference's global early exit (models/PointDSC.py:354-356) picked an earlier iterate for some pair: re-solve its seeds
     hipLaunchKernelGGL(pdsc::seed_transform_kernel, dim3(S, bs), dim3(64), 0, st, src, tgt, knn_idx, eig_iters, conv_mask, seed_trans,
                        seed_weights, N, S, k, num_iterations, 1);
-    return pdsc::check_launch("pdsc_seed_solve(early-exit fix-up)");
+    rc = pdsc::check_launch("pdsc_seed_solve(early-exit fix-up)");
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(pdsc::kabsch_batch_kernel, dim3(pdsc::ceil_div(bs * S, 64)), dim3(64), 0, st, seed_trans, bs * S);
+    return pdsc::check_launch("pdsc_seed_solve(kabsch)");
 }
 
 extern "C" int pdsc_seed_transforms(const float* src, const float* tgt, const int* knn_idx, const float* eig_iters,
@@ -305,7 +335,10 @@ extern "C" int pdsc_seed_transforms(const float* src, const float* tgt, const in
     PDSC_REQUIRE(num_iterations >= 0 && num_iterations <= PDSC_MAX_POWER_ITERS, "pdsc_seed_transforms: num_iterations=%d", num_iterations);
     hipLaunchKernelGGL(pdsc::seed_transform_kernel, dim3(S, bs), dim3(64), 0, (hipStream_t)stream, src, tgt, knn_idx, eig_iters,
                        conv_mask, seed_trans, seed_weights, N, S, k, num_iterations, 0);
-    return pdsc::check_launch("pdsc_seed_transforms");
+    const int rc = pdsc::check_launch("pdsc_seed_transforms");
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(pdsc::kabsch_batch_kernel, dim3(pdsc::ceil_div(bs * S, 64)), dim3(64), 0, (hipStream_t)stream, seed_trans, bs * S);
+    return pdsc::check_launch("pdsc_seed_transforms(kabsch)");
 }
 
 extern "C" int pdsc_rigid_transform_3d(const float* A, const float* B, const float* weights, float weight_threshold,
