@@ -68,6 +68,24 @@ __device__ __forceinline__ int wave_sum(int v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// Wave-wide float sum on the VALU's data-parallel primitives (DPP) instead of six ds_bpermute round trips through the LDS
+// crossbar (~100 cycles each): pair swap, quad swap, half-row mirror, row mirror leave every lane of a 16-lane row with
+// the row total (both partners of every step add the same two numbers, so the copies are bit-identical); row_bcast:15 /
+// row_bcast:31 fold the four rows into lane 63; one v_readlane broadcasts.  Deterministic, but ANOTHER summation order than
+// wave_sum above -- used where a wavefront owns a whole small problem (per-seed solver), not where bit patterns are pinned.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define PDSC_DPP_ADD(ctrl, row_mask)                                                                                    \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+    PDSC_DPP_ADD(0xB1, 0xf);      // quad_perm [1,0,3,2]
+    PDSC_DPP_ADD(0x4E, 0xf);      // quad_perm [2,3,0,1]
+    PDSC_DPP_ADD(0x141, 0xf);     // row_half_mirror
+    PDSC_DPP_ADD(0x140, 0xf);     // row_mirror
+    PDSC_DPP_ADD(0x142, 0xa);     // row_bcast:15 -> rows 1, 3
+    PDSC_DPP_ADD(0x143, 0xc);     // row_bcast:31 -> rows 2, 3
+#undef PDSC_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

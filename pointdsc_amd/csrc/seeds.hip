@@ -204,16 +204,34 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __
     __shared__ unsigned long long bound;
     __shared__ int fcand_n;
     unsigned long long mymin = ~0ULL;
-    for (int j = t; j < N; j += KNN_THREADS) {
-        const unsigned int kb = float_order_bits(row[j]);
-        keys[j] = kb;
-        const unsigned long long v = ((unsigned long long)kb << idx_bits) | (unsigned)j;
-        mymin = v < mymin ? v : mymin;
+    // the row is read as float4 with four loads in flight per thread (a scalar strided loop waits for every load in turn:
+    // 20 dependent HBM round trips per thread at N = 5000 were most of this kernel's 237 us); rows are 256-byte aligned
+    // (ldd is a multiple of 64) and only columns < N are looked at
+    for (int j0 = 0; j0 < N; j0 += KNN_THREADS * 16) {
+        f32x4 part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + (u * KNN_THREADS + t) * 4;
+            part[u] = j < N ? *reinterpret_cast<const f32x4*>(row + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + (u * KNN_THREADS + t) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (j + e < N) {
+                    const unsigned int kb = float_order_bits(part[u][e]);
+                    keys[j + e] = kb;
+                    const unsigned long long v = ((unsigned long long)kb << idx_bits) | (unsigned)(j + e);
+                    mymin = v < mymin ? v : mymin;
+                }
+            }
+        }
     }
     tmin[t] = mymin;
     if (t == 0) { cand_n = 0; fcand_n = 0; }
     __syncthreads();
-    if (N >= KNN_THREADS && want <= KNN_THREADS) {           // every thread owns at least one element
+    if ((N + 3) / 4 >= want && want <= KNN_THREADS) {        // at least k+1 threads own elements (a thread owns float4 groups)
         int r = 0;
         for (int u = 0; u < KNN_THREADS; ++u) r += tmin[u] < mymin;
         if (r == want - 1) bound = mymin;                     // exactly one thread: minima are distinct

@@ -23,20 +23,20 @@ __device__ __forceinline__ int chosen_iterate(unsigned int mask, int num_iter) {
 // left 63 of 64 lanes idle and dominated the fused solver (150 of 255 us at 16 000 seeds).
 __device__ __forceinline__ void seed_procrustes(int lane, bool valid, float v, float ax, float ay, float az, float bx, float by,
                                                 float bz, float* __restrict__ trans_out, float* __restrict__ w_out) {
-    float w = v / (wave_sum(v) + 1e-6f);                       // models/PointDSC.py:282
+    float w = v / (wave_sum_dpp(v) + 1e-6f);                       // models/PointDSC.py:282
     if (w < 0.f) w = 0.f;                                      // models/common.py:20 (weight_threshold = 0)
     w = valid ? w : 0.f;
     if (w_out && valid) w_out[lane] = w;
-    const float den = wave_sum(w) + 1e-6f;
-    float cA[3] = {wave_sum(ax * w) / den, wave_sum(ay * w) / den, wave_sum(az * w) / den};
-    float cB[3] = {wave_sum(bx * w) / den, wave_sum(by * w) / den, wave_sum(bz * w) / den};
+    const float den = wave_sum_dpp(w) + 1e-6f;
+    float cA[3] = {wave_sum_dpp(ax * w) / den, wave_sum_dpp(ay * w) / den, wave_sum_dpp(az * w) / den};
+    float cB[3] = {wave_sum_dpp(bx * w) / den, wave_sum_dpp(by * w) / den, wave_sum_dpp(bz * w) / den};
     const float am[3] = {ax - cA[0], ay - cA[1], az - cA[2]};
     const float bm[3] = {bx - cB[0], by - cB[1], bz - cB[2]};
     float H[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) H[r * 3 + c] = wave_sum(am[r] * w * bm[c]);
+        for (int c = 0; c < 3; ++c) H[r * 3 + c] = wave_sum_dpp(am[r] * w * bm[c]);
     if (lane == 0) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) trans_out[e] = H[e];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * SV_WAVES) void seed_solve_kernel(const float* 
             for (int e = 0; e < 4; ++e) nv = fmaf(mrow[4 * j4 + e], vv[e], nv);  // the j = 0..k-1 chain (rows / columns >= k are 0)
         }
         nv = valid ? nv : 0.f;
-        const float nrm = sqrtf(wave_sum(nv * nv));
+        const float nrm = sqrtf(wave_sum_dpp(nv * nv));
         v = nv / (nrm + 1e-6f);
         out[it * PDSC_MAX_K + lane] = v;
         const bool close = fabsf(v - last) <= (1e-8f + 1e-5f * fabsf(last));   // torch.allclose(v, last)
