@@ -14,6 +14,22 @@ struct AttArgs {
     int N, Npad, nsplit, num_tiles;
 };
 
+// arguments of the split-precision kernels (attention_split.hip, attention_wide.hip)
+struct AttSplitArgs {
+    const __bf16* qs;             // [bs*N][256]  (hi | lo), q pre-scaled by log2(e)/sqrt(C)
+    const unsigned char* kv;     // [bs][num_tiles][32 KiB]
+    const void* compat;          // [bs][N][ld] fp32, or (C16) unorm16 in the tile order of pdsc_spatial_compat_u16
+    long long ld;
+    float* msg;                  // [bs*N][128]
+    float* part_o;               // [bs][nsplit][Npad][128]
+    float* part_ml;              // [bs][nsplit][Npad][2]
+    int N, Npad, nsplit, num_tiles, nq, bs;
+    int compat_nt;               // A/B knob PDSC_ATT_COMPAT_NT: stream the compat slices with the non-temporal policy
+    long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
+};
+
+int launch_attention_wide(const AttSplitArgs& a, unsigned grid, hipStream_t st);
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

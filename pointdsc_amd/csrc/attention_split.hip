@@ -25,18 +25,6 @@
 
 namespace pdsc {
 
-struct AttSplitArgs {
-    const __bf16* qs;            // [bs*N][256]  (hi | lo), q pre-scaled by log2(e)/sqrt(C)
-    const unsigned char* kv;     // [bs][num_tiles][32 KiB]
-    const void* compat;          // [bs][N][ld] fp32, or (C16) unorm16 in the tile order of pdsc_spatial_compat_u16
-    long long ld;
-    float* msg;                  // [bs*N][128]
-    float* part_o;               // [bs][nsplit][Npad][128]
-    float* part_ml;              // [bs][nsplit][Npad][2]
-    int N, Npad, nsplit, num_tiles, nq, bs;
-    int compat_nt;               // A/B knob PDSC_ATT_COMPAT_NT: stream the compat slices with the non-temporal policy
-    long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
-};
 
 // LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, descriptor + scalar offset + one 32-bit lane
 // offset -- no 64-bit address registers) of one part of a tile.  The K part (17 KiB) and the V^T part (20 KiB) of a
@@ -580,6 +568,19 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
     int rc = PDSC_OK;
     const bool trace = nw == 8 && a.trace;
+    // A/B knob PDSC_ATT_WIDE = 1: the one-wave-per-SIMD, 64-queries-per-wave variant (attention_wide.hip) where the plan
+    // picks the 8-wave kernel
+    if (nw == 8 && !c16 && !trace && env_int("PDSC_ATT_WIDE", 0)) {
+        rc = launch_attention_wide(a, grid, st);
+        if (rc != PDSC_OK) return rc;
+        if (nsplit > 1 && msg) {
+            AttArgs c{};
+            c.msg = msg; c.part_o = a.part_o; c.part_ml = a.part_ml;
+            c.N = N; c.Npad = a.Npad; c.nsplit = nsplit; c.num_tiles = tiles;
+            rc = launch_attention_combine(c, bs, st);
+        }
+        return rc;
+    }
 #define PDSC_ATT_LAUNCH(SLOT, NWV, C16V, TRV)                                                                              \
     do {                                                                                                                    \
         rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, C16V, TRV>), lds_bytes,       \

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(64 * SV_WAVES) void seed_solve_kernel(const float* 
 #pragma unroll
         for (int q = 0; q < 8; ++q) frag[R][q] = *reinterpret_cast<const f32x4*>(row + 16 * q);
     }
-    const float sg = sigma[0], sig2 = sg * sg;
-    const float sd = sigma_spat[0], sd2 = sd * sd;
+    const float sg = sigma[0], sig2 = sg * sg, rsig2 = 1.0f / sig2;
+    const float sd = sigma_spat[0], sd2 = sd * sd, rsd2 = 1.0f / sd2;
     wave_lds_sync();                                      // pts visible to the wave
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
@@ -166,13 +166,16 @@ __global__ __launch_bounds__(64 * SV_WAVES) void seed_solve_kernel(const float* 
                 const int i = 16 * I + 4 * kq + r;
                 const f32x4 pi = *reinterpret_cast<const f32x4*>(&sh.pts[i][0]);
                 const f32x4 qi = *reinterpret_cast<const f32x4*>(&sh.pts[i][4]);
-                const float fm = fmaxf(1.0f - (1.0f - acc[r]) / sig2, 0.0f);
+                // 1-ulp hardware sqrt and multiplication by the (refined) reciprocals instead of the IEEE sequences: the
+                // entries of M feed a power iteration, nothing is thresholded on them (24 elements per lane x ~50 VALU ops
+                // saved; this kernel is VALU-bound)
+                const float fm = fmaxf(1.0f - (1.0f - acc[r]) * rsig2, 0.0f);
                 const float dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
                 const float ex = qi[0] - qj[0], ey = qi[1] - qj[1], ez = qi[2] - qj[2];
-                const float ds = sqrtf((dx * dx + dy * dy) + dz * dz);          // ((a-b)**2).sum(-1) ** 0.5
-                const float dt = sqrtf((ex * ex + ey * ey) + ez * ez);
+                const float ds = __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz);          // ((a-b)**2).sum(-1) ** 0.5
+                const float dt = __builtin_amdgcn_sqrtf((ex * ex + ey * ey) + ez * ez);
                 const float df = ds - dt;
-                const float sm = fmaxf(1.0f - (df * df) / sd2, 0.0f);
+                const float sm = fmaxf(1.0f - (df * df) * rsd2, 0.0f);
                 const float m = (i == j || i >= k || j >= k) ? 0.0f : fm * sm;
                 sh.M[i * MLD + j] = m;
                 if (I != J) sh.M[j * MLD + i] = m;        // mirror (block-uniform condition)
