@@ -138,12 +138,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     constexpr int KPIECES = SPL_K_BYTES / 1024, PIECES = SPL_TILE_BYTES / 1024, KV_SLOTS = (PIECES + NW - 1) / NW;
     auto dma_slot = [&](int kt, int st, int slot) {
         if (slot < NCS) {
-            if (a.compat_nt)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
-                                                         (kt + 2) * (SPL_BK * (int)CEL), 0, 2);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
-                                                         (kt + 2) * (SPL_BK * (int)CEL), 0, 0);
+            // the fp32 compat slices are read once per launch: streamed with the non-temporal policy (aux = 2) they leave
+            // the L2 to the K/V tiles the other workgroups of the XCD re-read: +1.6 % pairs/s; the unorm16 stream measured
+            // faster without (tools/ab_forward.py, profiles/r02_ab_forward_*.txt)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
+                                                     (kt + 2) * (SPL_BK * (int)CEL), 0, C16 ? 0 : 2);
         } else {
             const int i = min(wave + NW * (slot - NCS), PIECES - 1);    // surplus slots repeat the last piece
             const bool isk = i < KPIECES;                                // wave-uniform
@@ -215,14 +214,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             }
         }
     };
+    // maximum over the two lane halves of a query: one v_permlane32_swap (VALU) instead of a ds_bpermute round trip
+    auto half_max = [&](float m) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
     auto row_max = [&](const float (&tl)[16]) {
         float m = tl[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m = fmaxf(m, tl[r]);
-        return fmaxf(m, __shfl_xor(m, 32, 64));
+        return half_max(m);
     };
 
     float tl[16];                                // logits of the tile whose P is formed next
+    float mx_next = -INFINITY;
     f32x16 sacc;
     PDSC_TRACE_STAMP(0)                          // 0: prologue issue + Q loads
     // ---- tile kt0: S^T = K Q^T, logits, reference = row maximum ---------------------------------------------
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             const unsigned char* V = Vs + st * SPL_V_BYTES;
             const unsigned char* Cn = Cs + (st ^ 1) * CSTAGE + crow_off;
             unsigned cw[8];
+            mx_next = -INFINITY;                 // row maximum of tile kt+1's logits, gathered as they are formed
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = u >> 1, j = u & 1;
@@ -329,12 +335,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                         c16_group(cw, g, cc);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                        mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                     }
                 } else if (u & 1) {              // compat chunk 2g+h = keys 8g+4h..+3 = accumulator registers 4g..4g+3
                     const int g = u >> 1;
                     const f32x4 cc = *reinterpret_cast<const f32x4*>(Cn + (((2 * g + h) ^ csw) << 4));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                    mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                 }
             }
         }
@@ -342,8 +350,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         PDSC_TRACE_STAMP(6)                      // 6: phase B
         // ---- does tile kt+1 move the reference exponent of any query?  (rare after the first tiles) -------------
         if (has_next) {
-            mask_tail(kt + 1, tl);
-            const float mloc = row_max(tl);
+            float mloc;
+            if ((kt + 2) * SPL_BK > N) {         // tile kt+1 is the ragged last tile of the pair (wave-uniform, once per pair)
+                mask_tail(kt + 1, tl);
+                mloc = row_max(tl);
+            } else
+                mloc = half_max(mx_next);
             if (!__all(mloc <= ATT_RESCALE_THR)) {
                 const float delta = mloc > ATT_RESCALE_THR ? mloc : 0.f;      // per query; 0 = stays
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -555,10 +567,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
-    // the fp32 compat slices are read once per launch: streamed non-temporal they leave the L2 to the K/V tiles the other
-    // workgroups of the XCD re-read (+1.6 % pairs/s, tools/ab_forward.py; the unorm16 stream is faster without).
-    // PDSC_ATT_COMPAT_NT = 0 | 1 overrides (tuning/A-B knob, read per call).
-    a.compat_nt = env_int("PDSC_ATT_COMPAT_NT", c16 ? 0 : 1);
+    a.compat_nt = c16 ? 0 : 1;                 // (the wide variant still takes it as an argument)
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
     // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)

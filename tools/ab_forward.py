@@ -2,10 +2,9 @@
 """Interleaved A/B of whole-forward variants inside ONE process (the chip's power state drifts by a few per cent between
 processes and boxes, so variants are compared as A B C A B C ... rounds of the same length and the medians reported).
 
-    python tools/ab_forward.py --config n5000_b32 --variants f32 u16 f32+nt u16+nt [--rounds 7] [--steps 25]
+    python tools/ab_forward.py --config n5000_b32 --variants f32 u16 f32+PDSC_ATT_WIDE=1 [--rounds 7] [--steps 25]
 
-A variant is `<compat_format>[+nt][+<ENV>=<value>...]`: model.compat_format, PDSC_ATT_COMPAT_NT and any further per-call
-environment knob of the library.
+A variant is `<compat_format>[+<ENV>=<value>...]`: model.compat_format and any per-call environment knob of the library.
 """
 import argparse
 import os
@@ -39,13 +38,10 @@ data["testing"] = True
 def apply(variant):
     parts = variant.split("+")
     model.compat_format = parts[0]
-    env = {"PDSC_ATT_COMPAT_NT": "0"}          # explicit in every variant (the library's default depends on the format)
+    env = {}
     for p in parts[1:]:
-        if p == "nt":
-            env["PDSC_ATT_COMPAT_NT"] = "1"
-        else:
-            k, v = p.split("=")
-            env[k] = v
+        k, v = p.split("=")
+        env[k] = v
     os.environ.update(env)
     return env
 
@@ -68,8 +64,7 @@ with torch.no_grad():
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / a.steps)
             for k in env:
-                if k != "PDSC_ATT_COMPAT_NT":
-                    os.environ.pop(k, None)
+                os.environ.pop(k, None)
 base = statistics.median(times[a.variants[0]])
 for v in a.variants:
     med = statistics.median(times[v])
