@@ -321,11 +321,14 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const int ns = pdsc_attention_split_default_split(bs, N);
         const int Npad = (int)round_up(N, 256);
         const int fuse_env = env_int("PDSC_FUSE_MERGE", 1);      // tuning/A-B knob
-        const bool fuse_merge = fuse_env && ns > 1 && ns <= 4;   // the layer kernels merge up to 4 splits while loading (merge_partials.h)
+        // the layer kernels merge the key-split partials while loading (merge_partials.h): up to 4 splits, 8 in the
+        // workgroup-per-tile kernel that small problems take
+        const char* var = getenv("PDSC_LAYER_VARIANT");          // same rule as pdsc_layer_fused_split
+        const bool block_layer = !x3_gemm && ((var && var[0] == 'b') || (!(var && var[0] == 'w') && pdsc_layer_prefers_block(bs, N)));
+        const bool fuse_merge = fuse_env && ns > 1 && ns <= (block_layer ? 8 : 4);
         const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;
         const float* part_ml = fuse_merge ? part_o + (size_t)bs * ns * Npad * C : nullptr;
         // tuning/A-B knob: PDSC_LAYER_FRAG = 0 = natural-layout weights (pdsc_layer_fused_split)
-        const char* var = getenv("PDSC_LAYER_VARIANT");
         const bool frag_env = env_int("PDSC_LAYER_FRAG", 1) && !(var && var[0] == 'b');
         // default: wavefront-resident layer kernel on fragment streams; small problems: the workgroup-per-tile kernel (layer.hip)
         const bool frag = frag_env && !x3_gemm && !pdsc_layer_prefers_block(bs, N);

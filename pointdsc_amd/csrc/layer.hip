@@ -167,11 +167,30 @@ __device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs
             *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_finish<NS>(L[i]);
         }
     };
+    // 5..8 splits (small problems: the attention plan splits the keys further to fill the chip): one chunk at a time --
+    // registers for a single set of NS partials; costs four dependent round trips instead of one, still cheaper than the
+    // attention_combine launch + the msg round trip it replaces
+    auto run_seq = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
+            const int m = min(m0 + row, M - 1);
+            const size_t slot0 = (size_t)b * NS * a.Npad + (size_t)(m - b * a.N);
+            MergeLoads<NS> L;
+            merge_partials_load<NS>(L, a.part_o, a.part_ml, slot0, (size_t)a.Npad, c4);
+            *reinterpret_cast<f32x4*>(Xs + row * LF_LD + c4) = merge_partials_finish<NS>(L);
+        }
+    };
     switch (a.nsplit) {
         case 1: run(std::integral_constant<int, 1>{}); break;
         case 2: run(std::integral_constant<int, 2>{}); break;
         case 3: run(std::integral_constant<int, 3>{}); break;
-        default: run(std::integral_constant<int, 4>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 5: run_seq(std::integral_constant<int, 5>{}); break;
+        case 6: run_seq(std::integral_constant<int, 6>{}); break;
+        case 7: run_seq(std::integral_constant<int, 7>{}); break;
+        default: run_seq(std::integral_constant<int, 8>{}); break;
     }
 }
 
@@ -388,8 +407,8 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused: bs=%d N=%d", bs, N);
     if (tail) {
         PDSC_REQUIRE(res && w1 && b1 && w2 && b2 && w3 && b3, "pdsc_layer_fused: tail needs res, fc1..fc3");
-        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= pdsc::MERGE_MAX_SPLIT && Npad >= N,
-                               "pdsc_layer_fused: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", pdsc::MERGE_MAX_SPLIT);
+        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= pdsc::MERGE_MAX_SPLIT_BLOCK && Npad >= N,
+                               "pdsc_layer_fused: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", pdsc::MERGE_MAX_SPLIT_BLOCK);
     } else PDSC_REQUIRE(feat_in, "pdsc_layer_fused: head-only needs feat_in");
     if (head) PDSC_REQUIRE((qkv_out || q_split) && wp && bp && wq && bq, "pdsc_layer_fused: head needs qkv_out or the split streams, pcn, qkv weights");
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
@@ -404,7 +423,11 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     const char* ev = getenv("PDSC_LAYER_VARIANT");          // read per call
     const int variant = !ev ? 0 : ev[0] == 'b' ? 1 : ev[0] == 'w' ? 2 : 0;
     const bool block_variant = variant == 1 || (variant == 0 && pdsc_layer_prefers_block(bs, N));
-    if (!block_variant) return pdsc::launch_layer_wave(a, tail, head, st);
+    if (!block_variant) {
+        PDSC_REQUIRE(msg || !tail || nsplit <= pdsc::MERGE_MAX_SPLIT, "pdsc_layer_fused: the wavefront-per-tile kernel merges at most %d splits",
+                     pdsc::MERGE_MAX_SPLIT);
+        return pdsc::launch_layer_wave(a, tail, head, st);
+    }
     if (tail && head) {
         pdsc::profile_mark_begin(PDSC_PROF_LAYER, st);
         const int rc = pdsc::launch_layer<true, true>(a, st);

@@ -7,7 +7,8 @@
 
 namespace pdsc {
 
-constexpr int MERGE_MAX_SPLIT = 4;      // larger key splits go through attention_combine_kernel
+constexpr int MERGE_MAX_SPLIT = 4;        // larger key splits go through attention_combine_kernel ...
+constexpr int MERGE_MAX_SPLIT_BLOCK = 8;  // ... except in the workgroup-per-tile layer kernel (layer.hip: small problems)
 
 __device__ __forceinline__ f32x4 merge_partials_chunk(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                       size_t slot0, size_t sp_stride, int ns, int c4) {

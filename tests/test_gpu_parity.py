@@ -403,6 +403,28 @@ def test_layer_fused_x3_merges_attention_partials(n, bs, nsplit):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 5), (1000, 1, 8), (300, 2, 6), (1000, 1, 7)])
+def test_block_layer_kernel_merges_up_to_eight_partials(n, bs, nsplit):
+    """Small problems (N = 1000 x 1 pair: the attention plan splits the keys 8 ways) merge the partials inside the
+    workgroup-per-tile layer kernel as well: == the same kernel fed the combine kernel's merged msg."""
+    gen = torch.Generator().manual_seed(n + nsplit)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    batch = synthetic.make_batch(bs, n, seed=9 + n)
+    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    qkv = torch.cat([rnd(bs * n, 128) * 0.3 * QSCALE, rnd(bs * n, 128) * 0.3, rnd(bs * n, 128)], dim=-1)
+    qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+    msg = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit)
+    partials = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit, merge=False)
+    res = rnd(bs * n, 128)
+    tail_w = [g(x) for x in (rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128))]
+    head_w = [g(x) for x in (rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384))]
+    assert _lib.load().pdsc_layer_prefers_block(bs, n) == 1
+    a = ops.layer_fused_split(msg, g(res), None, tail_w, head_w, bs, n, want_qkv=True, qkv_split=True)
+    b = ops.layer_fused_split(None, g(res), None, tail_w, head_w, bs, n, want_qkv=True, qkv_split=True, partials=partials)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 2), (1000, 2, 3), (300, 3, 4), (5000, 2, 2)])
 def test_layer_fused_frag_merges_attention_partials(n, bs, nsplit):
     """pdsc_layer_fused_frag = layer_wave_kernel (the kernel the bench times) fed the UN-MERGED key-split partials
