@@ -269,6 +269,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     }
 
     PDSC_TRACE_STAMP(1)                          // 1: first tile (wait + QK + logits)
+    if (a.prio_mode == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);       // static priority, no per-segment flips
+    if (a.prio_mode == 2 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int st = (kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
         const bool has_next = kt + 1 < kt1;
@@ -567,6 +569,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
+    a.prio_mode = env_int("PDSC_ATT_PRIO", 0);
     a.compat_nt = c16 ? 0 : 1;                 // (the wide variant still takes it as an argument)
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
