@@ -270,6 +270,12 @@ int pdsc_normalize_confidence(const float* feat, const float* h2, const float* w
  *   seeds   = first num_seeds indices by descending key, equal keys by ascending index. */
 int pdsc_nms_keys(const float* src_keypts, const float* conf, float radius, float* keys,
                   int bs, int N, void* stream);
+/* the same keys, bit for bit, from ~1 % of the pair evaluations: points counting-sorted into a 2-D cell grid of width >=
+ * radius, the predicate evaluated against the 3 x 3 neighbouring cells only (what the forward calls; workspace from
+ * pdsc_nms_workspace_bytes; radius <= 0 / NaN / NULL workspace fall back to pdsc_nms_keys) */
+size_t pdsc_nms_workspace_bytes(int bs, int N);
+int pdsc_nms_keys_grid(const float* src_keypts, const float* conf, float radius, float* keys, void* workspace,
+                       size_t workspace_bytes, int bs, int N, void* stream);
 int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream);
 
 /* ---- a-6  feature-space kNN of the seeds -------------------------------------------------------

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pdsc_sc_attention": (_i, [_vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "pdsc_normalize_confidence": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pdsc_nms_keys": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
+    "pdsc_nms_workspace_bytes": (_sz, [_i, _i]),
+    "pdsc_nms_keys_grid": (_i, [_vp, _vp, _f, _vp, _vp, _sz, _i, _i, _vp]),
     "pdsc_rank_select": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pdsc_knn_seeds": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pdsc_seed_power_iteration": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

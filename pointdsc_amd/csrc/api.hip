@@ -179,6 +179,7 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("h2", M * 32 * f);
     L.add("conf", M * f);
     L.add("keys", M * f);
+    L.add("nms_ws", pdsc_nms_workspace_bytes(bs, N));
     L.add("seeds", (size_t)bs * S * sizeof(int));
     L.add("knn_dist", (size_t)bs * S * ld * f);
     L.add("knn_idx", (size_t)bs * S * (k > 0 ? k : 1) * sizeof(int));
@@ -406,7 +407,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
     PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
     if (mode == 0) {
-        PDSC_TRY(pdsc_nms_keys(src, conf, cfg->nms_radius, keys, bs, N, stream));
+        PDSC_TRY(pdsc_nms_keys_grid(src, conf, cfg->nms_radius, keys, ws + L.find("nms_ws"), pdsc_nms_workspace_bytes(bs, N), bs, N, stream));
         PDSC_TRY(pdsc_rank_select(keys, seeds, bs, N, S, stream));
     } else {
         // models/PointDSC.py:158-163 and :176

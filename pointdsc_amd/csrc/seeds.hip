@@ -78,6 +78,136 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
     if (!ok1 && i1 < N) keys[(size_t)b * N + i1] = c1 * 0.0f;
 }
 
+// ---- NMS keys through a 2-D cell grid: the same predicate on ~1 % of the pairs --------------------------------------
+// A point j can only suppress i when ||s_i - s_j|| < R, hence |dx| < R and |dy| < R.  nms_grid_kernel (one workgroup per
+// pair) counting-sorts the points into <= 64 x 64 cells of width >= R (1 + 1e-3) in x and y; nms_window_kernel evaluates the
+// UNCHANGED predicate -- same fp32 expression for the squared distance, same radius2 -- against the points of the 3 x 3
+// neighbouring cells only.  Every skipped j has |dx| or |dy| >= R (1 + 1e-3), so its computed squared distance is >= radius2
+// (margin 1e-3 against rounding of order 1e-7) and the predicate is true: the keys are bit-identical to nms_flags_kernel's.
+// The cell of a point is floor((x - xmin) / w) in fp32 with w >= R (1 + 1e-3): for |x_i - x_j| < R the two quotients differ
+// by < 0.999 + 64 * 2^-22 < 1, so their floors differ by at most 1 whatever the rounding.
+constexpr int GRID_MAX = 64;
+struct NmsGridHeader { float xmin, ymin, inv_unused0, inv_unused1, wx, wy; int nbx, nby; };
+static_assert(sizeof(NmsGridHeader) == 32, "header layout");
+__device__ __forceinline__ int grid_cell_1d(float v, float vmin, float w, int nb) {
+    const int c = (int)floorf((v - vmin) / w);
+    return c < 0 ? 0 : (c >= nb ? nb - 1 : c);
+}
+static size_t nms_ws_pair_bytes(int N) {
+    return (size_t)round_up((long long)N * 16 + (long long)N * 4 + (GRID_MAX * GRID_MAX + 1) * 4 + sizeof(NmsGridHeader), 256);
+}
+__global__ __launch_bounds__(1024) void nms_grid_kernel(const float* __restrict__ src, const float* __restrict__ conf, float radius,
+                                                        unsigned char* __restrict__ ws, size_t ws_pair, int N) {
+    __shared__ int cells[GRID_MAX * GRID_MAX + 1];
+    __shared__ float red[4][16];
+    __shared__ int wtot[16];
+    __shared__ NmsGridHeader hdr;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+    const float* s = src + (size_t)b * N * 3;
+    const float* c = conf + (size_t)b * N;
+    unsigned char* w = ws + (size_t)b * ws_pair;
+    float4* rec = reinterpret_cast<float4*>(w);
+    int* oidx = reinterpret_cast<int*>(w + (size_t)N * 16);
+    int* cell_start = reinterpret_cast<int*>(w + (size_t)N * 20);
+    NmsGridHeader* hout = reinterpret_cast<NmsGridHeader*>(w + (size_t)N * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
+    float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
+    for (int i = t; i < N; i += 1024) {
+        const float x = s[i * 3], y = s[i * 3 + 1];
+        xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        xmn = fminf(xmn, __shfl_xor(xmn, off, 64)); xmx = fmaxf(xmx, __shfl_xor(xmx, off, 64));
+        ymn = fminf(ymn, __shfl_xor(ymn, off, 64)); ymx = fmaxf(ymx, __shfl_xor(ymx, off, 64));
+    }
+    if (lane == 0) { red[0][wave] = xmn; red[1][wave] = xmx; red[2][wave] = ymn; red[3][wave] = ymx; }
+    for (int i = t; i <= GRID_MAX * GRID_MAX; i += 1024) cells[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 1; k < 16; ++k) {
+            red[0][0] = fminf(red[0][0], red[0][k]); red[1][0] = fmaxf(red[1][0], red[1][k]);
+            red[2][0] = fminf(red[2][0], red[2][k]); red[3][0] = fmaxf(red[3][0], red[3][k]);
+        }
+        const float rm = radius * 1.001f;
+        const float rx = red[1][0] - red[0][0], ry = red[3][0] - red[2][0];
+        int nbx = (int)fminf(floorf(rx / rm), (float)GRID_MAX), nby = (int)fminf(floorf(ry / rm), (float)GRID_MAX);
+        if (!(nbx >= 1)) nbx = 1;
+        if (!(nby >= 1)) nby = 1;
+        hdr.xmin = red[0][0]; hdr.ymin = red[2][0]; hdr.nbx = nbx; hdr.nby = nby;
+        hdr.wx = nbx > 1 ? rx / (float)nbx : 1.0f;            // >= rm by construction (nbx <= rx / rm); one cell: any width
+        hdr.wy = nby > 1 ? ry / (float)nby : 1.0f;
+        hdr.inv_unused0 = 0.f; hdr.inv_unused1 = 0.f;
+    }
+    __syncthreads();
+    const NmsGridHeader h = hdr;
+    const int ncell = h.nbx * h.nby;
+    // histogram
+    for (int i = t; i < N; i += 1024) {
+        const int cell = grid_cell_1d(s[i * 3 + 1], h.ymin, h.wy, h.nby) * h.nbx + grid_cell_1d(s[i * 3], h.xmin, h.wx, h.nbx);
+        atomicAdd(&cells[cell], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cells[0..ncell) in place (4 consecutive cells per thread), total into cells[ncell]
+    {
+        int v[4], sum = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (4 * t + e) < ncell ? cells[4 * t + e] : 0; sum += v[e]; }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int k = 0; k < wave; ++k) base += wtot[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (4 * t + e < ncell) cells[4 * t + e] = base;
+            base += v[e];
+        }
+        if (t == 1023) cells[ncell] = base;                   // == N
+    }
+    __syncthreads();
+    for (int i = t; i <= ncell; i += 1024) cell_start[i] = cells[i];
+    if (t == 0) *hout = h;
+    __syncthreads();
+    // scatter (cells[] now serves as the per-cell cursor)
+    for (int i = t; i < N; i += 1024) {
+        const float x = s[i * 3], y = s[i * 3 + 1], z = s[i * 3 + 2];
+        const int cell = grid_cell_1d(y, h.ymin, h.wy, h.nby) * h.nbx + grid_cell_1d(x, h.xmin, h.wx, h.nbx);
+        const int pos = atomicAdd(&cells[cell], 1);
+        rec[pos] = make_float4(x, y, z, c[i]);
+        oidx[pos] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_window_kernel(const unsigned char* __restrict__ ws, size_t ws_pair, float radius2,
+                                                         float* __restrict__ keys, int N) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const unsigned char* w = ws + (size_t)b * ws_pair;
+    const float4* rec = reinterpret_cast<const float4*>(w);
+    const int* oidx = reinterpret_cast<const int*>(w + (size_t)N * 16);
+    const int* cell_start = reinterpret_cast<const int*>(w + (size_t)N * 20);
+    const NmsGridHeader h = *reinterpret_cast<const NmsGridHeader*>(w + (size_t)N * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
+    if (p >= N) return;
+    const float4 me = rec[p];
+    const int cx = grid_cell_1d(me.x, h.xmin, h.wx, h.nbx), cy = grid_cell_1d(me.y, h.ymin, h.wy, h.nby);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.nbx - 1);
+    bool ok = true;
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, h.nby - 1); ++yy) {
+        const int j0 = cell_start[yy * h.nbx + x0], j1 = cell_start[yy * h.nbx + x1 + 1];
+        for (int j = j0; j < j1; ++j) {
+            const float4 o = rec[j];
+            const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));                  // norm3's radicand, as nms_flags_kernel
+            ok = ok && ((me.w >= o.w) || (d2 >= radius2));
+        }
+    }
+    keys[(size_t)b * N + oidx[p]] = ok ? me.w : me.w * 0.0f;                        // -0.0 for suppressed negatives, like torch
+}
+
 // ---- top-S by descending key, equal keys by ascending index: one workgroup per pair ---------------------
 //   1. radix select (4 x 8 bits, most significant first) of the S-th value in descending order on monotone key bits
 //      (-0.0 and +0.0 compare equal, as in torch.sort);
@@ -335,18 +465,13 @@ extern "C" int pdsc_normalize_confidence(const float* feat, const float* h2, con
     return pdsc::check_launch("pdsc_normalize_confidence");
 }
 
+static float nms_radius2(float radius);
+static float nms_radius2_fwd(float radius) { return nms_radius2(radius); }
+
 extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, float* keys, int bs, int N, void* stream) {
     PDSC_REQUIRE(src && conf && keys, "pdsc_nms_keys: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_nms_keys: bs=%d N=%d", bs, N);
-    // smallest x with sqrtf(x) >= radius (host sqrtf is correctly rounded, like the device's)
-    float radius2 = 0.f;
-    if (radius > 0.f) {
-        radius2 = radius * radius;
-        while (radius2 > 0.f && sqrtf(nextafterf(radius2, 0.f)) >= radius) radius2 = nextafterf(radius2, 0.f);
-        while (sqrtf(radius2) < radius) radius2 = nextafterf(radius2, INFINITY);
-    } else if (radius != radius) {
-        radius2 = radius;                                                    // NaN radius: every comparison is false
-    }
+    const float radius2 = nms_radius2_fwd(radius);
     {
         hipStream_t st = (hipStream_t)stream;
         if (hipMemcpyAsync(keys, conf, (size_t)bs * N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -361,6 +486,45 @@ extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, 
         hipLaunchKernelGGL(pdsc::nms_flags_kernel, dim3(row_blocks, splits, bs), dim3(256), 0, st, src, conf, radius2, keys, N, slice);
         return pdsc::check_launch("pdsc_nms_keys");
     }
+}
+
+// smallest x with sqrtf(x) >= radius (host sqrtf is correctly rounded, like the device's)
+static float nms_radius2(float radius) {
+    float radius2 = 0.f;
+    if (radius > 0.f) {
+        radius2 = radius * radius;
+        while (radius2 > 0.f && sqrtf(nextafterf(radius2, 0.f)) >= radius) radius2 = nextafterf(radius2, 0.f);
+        while (sqrtf(radius2) < radius) radius2 = nextafterf(radius2, INFINITY);
+    } else if (radius != radius) {
+        radius2 = radius;                                                    // NaN radius: every comparison is false
+    }
+    return radius2;
+}
+
+extern "C" size_t pdsc_nms_workspace_bytes(int bs, int N) {
+    if (bs <= 0 || N <= 0) return 0;
+    return (size_t)bs * pdsc::nms_ws_pair_bytes(N);
+}
+
+extern "C" int pdsc_nms_keys_grid(const float* src, const float* conf, float radius, float* keys, void* workspace,
+                                  size_t workspace_bytes, int bs, int N, void* stream) {
+    PDSC_REQUIRE(src && conf && keys, "pdsc_nms_keys_grid: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_nms_keys_grid: bs=%d N=%d", bs, N);
+    // a radius that is not a positive finite number has no cell width: the N^2 kernel handles it (every point its own maximum
+    // for radius <= 0, none for NaN)
+    if (!(radius > 0.f) || !(radius < INFINITY) || !workspace) return pdsc_nms_keys(src, conf, radius, keys, bs, N, stream);
+    if (workspace_bytes < pdsc_nms_workspace_bytes(bs, N)) {
+        pdsc::set_error("pdsc_nms_keys_grid: workspace %zu < %zu bytes", workspace_bytes, pdsc_nms_workspace_bytes(bs, N));
+        return PDSC_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ws_pair = pdsc::nms_ws_pair_bytes(N);
+    hipLaunchKernelGGL(pdsc::nms_grid_kernel, dim3(bs), dim3(1024), 0, st, src, conf, radius, (unsigned char*)workspace, ws_pair, N);
+    int rc = pdsc::check_launch("pdsc_nms_keys_grid(grid)");
+    if (rc != PDSC_OK) return rc;
+    hipLaunchKernelGGL(pdsc::nms_window_kernel, dim3(pdsc::ceil_div(N, 256), bs), dim3(256), 0, st, (const unsigned char*)workspace, ws_pair,
+                       nms_radius2(radius), keys, N);
+    return pdsc::check_launch("pdsc_nms_keys_grid(window)");
 }
 
 extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream) {

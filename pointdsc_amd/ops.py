@@ -346,6 +346,19 @@ def nms_keys(src_keypts, conf, radius: float) -> torch.Tensor:
 
 
 @_on_device
+def nms_keys_grid(src_keypts, conf, radius: float) -> torch.Tensor:
+    """pdsc_nms_keys_grid: the same keys from the 3 x 3 neighbouring cells of a 2-D grid (what the forward calls)."""
+    lib = _lib.load()
+    src, conf = _chk(src_keypts, "src_keypts"), _chk(conf, "conf")
+    bs, n = src.shape[0], src.shape[1]
+    keys = torch.empty(bs, n, device=src.device, dtype=torch.float32)
+    nb = int(lib.pdsc_nms_workspace_bytes(bs, n))
+    ws = torch.empty(nb, device=src.device, dtype=torch.uint8)
+    _lib.check(lib.pdsc_nms_keys_grid(_p(src), _p(conf), float(radius), _p(keys), _p(ws), nb, bs, n, _stream()), "pdsc_nms_keys_grid")
+    return keys
+
+
+@_on_device
 def rank_select(keys, num_seeds: int) -> torch.Tensor:
     lib = _lib.load()
     keys = _chk(keys, "keys")

@@ -585,6 +585,24 @@ def test_nms_keys_and_seeds_bit_exact(n):
     assert torch.equal(seeds[0].cpu().long(), c["st"]["seeds"])
 
 
+@pytest.mark.parametrize("n,bs,scale,radius", [(257, 1, 3.0, 0.1), (1000, 3, 3.0, 0.1), (5000, 2, 3.0, 0.1), (3000, 2, 60.0, 0.6),
+                                               (2000, 1, 3.0, 5.0), (1500, 2, 3.0, 1e-4), (700, 1, 3.0, 0.0), (10000, 1, 3.0, 0.1)])
+def test_nms_keys_grid_is_bit_identical_to_the_n2_kernel(n, bs, scale, radius):
+    """pdsc_nms_keys_grid (cell grid + 3 x 3 window, what the forward calls) == pdsc_nms_keys (all N^2 pairs), bit for bit:
+    dense and sparse radii (one cell / 64 x 64 cells), clustered points, duplicates, radius 0 (fallback), batches."""
+    gen = torch.Generator().manual_seed(n + bs)
+    batch = synthetic.make_batch(bs, n, seed=60 + n, scale=scale, noise=scale / 300.0)
+    src = batch["src_keypts"].clone()
+    src[:, : n // 10] = src[:, n // 10: 2 * (n // 10)]              # exact duplicates
+    src[:, -(n // 8):] = src[:, -(n // 8):] * 0.01 + 1.0             # a tight cluster (many points per cell)
+    conf = torch.randn(bs, n, generator=gen)
+    conf[:, ::7] = conf[:, 1::7][:, : conf[:, ::7].shape[1]]         # equal confidences
+    a = ops.nms_keys(g(src), g(conf), radius)
+    b = ops.nms_keys_grid(g(src), g(conf), radius)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))     # incl. the sign of suppressed zeros
+    assert 0 < int((a != g(conf)).sum()) < bs * n or radius <= 1e-4
+
+
 def test_seed_ties_resolve_by_ascending_index():
     n = 500
     pair = synthetic.make_pair(n, seed=3)
