@@ -913,6 +913,26 @@ def test_bench_timed_path_uses_the_wave_layer_kernel_and_fused_merge():
     assert 1 < ns <= 4, ns
 
 
+def test_forward_is_bitwise_repeatable():
+    """Same inputs, same process: poses, labels, features and every seed hypothesis come out bit for bit the same (no
+    order-dependent float atomics anywhere on the path), in both compat formats."""
+    model, _ = _bench_model("n5000_b32")
+    batch = workloads.batch("n5000_b32", 0, 8)
+    try:
+        for fmt in ("f32", "u16"):
+            model.compat_format = fmt
+            runs = []
+            for _ in range(3):
+                res = _forward(model, batch)
+                runs.append((res["final_trans"].clone(), res["final_labels"].clone(),
+                             model.workspace_view("featA", 8, 5000)[: 8 * 5000 * 128].clone(),
+                             model.workspace_view("seed_trans", 8, 5000)[: 8 * 500 * 16].clone()))
+            for r in runs[1:]:
+                assert all(torch.equal(x, y) for x, y in zip(runs[0], r)), fmt
+    finally:
+        model.compat_format = "f32"
+
+
 def test_batched_forward_equals_per_pair_calls():
     c = case(1000)
     batch = synthetic.make_batch(3, 1000, seed=300, inlier_ratio=0.3)
