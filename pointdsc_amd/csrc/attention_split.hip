@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         if (slot < NCS) {
             // the fp32 compat slices are read once per launch: streamed with the non-temporal policy (aux = 2) they leave
             // the L2 to the K/V tiles the other workgroups of the XCD re-read: +1.6 % pairs/s; the unorm16 stream measured
-            // faster without (tools/ab_forward.py, profiles/r02_ab_forward_*.txt)
+            // faster without (tools/ab_forward.py, profiles/r02_c_ab_forward_compat_format_b32.txt)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
                                                      (kt + 2) * (SPL_BK * (int)CEL), 0, C16 ? 0 : 2);
         } else {
