@@ -71,8 +71,12 @@ constexpr int SPL_V_BYTES = 2 * 128 * SPL_V_STRIDE;   // Vh | Vl   20 KiB
 // C16: the compat stream is unorm16 (pdsc_spatial_compat_u16: value = u / 65535, 0 and 1 exact, |error| <= 2^-17; inside
 // every 32-key group the 16 keys a lane half holds are contiguous: position 16 h + 4 g + e for key 8 g + 4 h + e), i.e.
 // 64 B per query row per tile instead of 128: half the HBM stream, half the compat LDS stage and DMA instructions.
-template <int NW, bool C16 = false, bool TRACE = false>
+// CM (compat mode): 0 = fp32 matrix, slices staged in LDS by LDS-DMA (default);  1 = unorm16 matrix, staged in LDS (C16);
+// 2 = fp32 matrix, every lane loads the 16 values of its query straight into registers (CREG: no compat LDS stage -- 74 KiB
+// per workgroup, so two 4-wave workgroups fit a CU and one's prologue / epilogue overlaps the other's main loop).
+template <int NW, int CM = 0, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
+    constexpr bool C16 = CM == 1, CREG = CM == 2;
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = TRACE ? (long long)__builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     unsigned char* const Vs = lds + 2 * SPL_K_BYTES;                // 2 x 20 KiB
     unsigned char* const Cs = Vs + 2 * SPL_V_BYTES;                 // 2 x NW*4 KiB
     constexpr int CROW = C16 ? 64 : 128;         // bytes of compat per query row per tile
-    constexpr int CSTAGE = NW * 32 * CROW;
-    constexpr int NCS = C16 ? 2 : 4;             // compat DMA pieces (1 KiB) per wave per tile
+    constexpr int CSTAGE = CREG ? 0 : NW * 32 * CROW;
+    constexpr int NCS = CREG ? 0 : (C16 ? 2 : 4);     // compat DMA pieces (1 KiB) per wave per tile
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -116,6 +120,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const unsigned lane16 = lane * 16;
     // (sized 4, not NCS: with a template-dependent bound hipcc 7.2's host pass silently drops the kernel's launch stub)
     unsigned coff[4] = {0u, 0u, 0u, 0u};         // byte offset of this lane's 16-B compat chunk per DMA piece, tile 0
+    // CREG: byte offset of this lane's first 16-B chunk (keys 4h..4h+3 of tile 0) inside the descriptor; chunk g at + 32 g
+    const unsigned creg_off = (unsigned)min(wave * 32 + (lane & 31), q_rows - 1) * (unsigned)a.ld * 4u + 16u * (unsigned)(lane >> 5);
+    auto creg_load = [&](int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            dst[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rsrc, creg_off + 32u * g, kt * (SPL_BK * 4), 0));
+    };
 #pragma unroll
     for (int u = 0; u < NCS; ++u) {
         if (C16) {
@@ -163,8 +174,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     };
 
     // prologue: K, compat of the first two tiles and V of the first in flight, then this lane's Q fragments
+    f32x4 ccur[4], cnext[4];                     // CREG: compat of the tile whose logits are formed next / the one after
     dma_k(kt0); dma_c(kt0);
+    if (CREG) creg_load(kt0, ccur);
     if (kt0 + 1 < kt1) { dma_k(kt0 + 1); dma_c(kt0 + 1); }
+    if (CREG) creg_load(kt0 + 1, cnext);
     dma_v(kt0);
     const int qrow = min(qb * (NW * 32) + wave * 32 + l31, N - 1);
     bf16x8 qh[8], ql[8];
@@ -254,6 +268,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tl[4 * g + e] = cc[e] * sacc[4 * g + e];
             }
+        } else if (CREG) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tl[4 * g + e] = ccur[g][e] * sacc[4 * g + e];
+                ccur[g] = cnext[g];              // compat of tile kt0 + 1 for the first phase B
+            }
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -279,6 +300,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         PDSC_TRACE_STAMP(2)                      // 2: wait for own DMA
         __syncthreads();
         PDSC_TRACE_STAMP(3)                      // 3: barrier
+        if (CREG) {
+            if (kt != kt0) {                     // (the loads issued one iteration ago have landed: vmcnt(0) above)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ccur[g] = cnext[g];
+            }
+            creg_load(kt + 2, cnext);            // a whole iteration to land
+        }
         PDSC_TRACE_STAMP(4)                      // 4: (unused)
 
         // ---- phase A: S^T(kt+1) = K Q^T on the matrix pipe | P(kt) = exp2(tl), hi/lo split on the VALU ---------
@@ -337,6 +365,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                         c16_group(cw, g, cc);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                        mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
+                    }
+                } else if (CREG) {
+                    if (u & 1) {
+                        const int g = u >> 1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(ccur[g][e], sacc[4 * g + e], -m_run);
                         mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                     }
                 } else if (u & 1) {              // compat chunk 2g+h = keys 8g+4h..+3 = accumulator registers 4g..4g+3
@@ -574,7 +609,9 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
     // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)
-    const size_t stage_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
+    // A/B knob PDSC_ATT_CREG = 1: fp32 compat values straight into registers (no LDS stage)
+    const bool creg = !c16 && env_int("PDSC_ATT_CREG", 0) != 0;
+    const size_t stage_bytes = 2 * (size_t)(SPL_TILE_BYTES + (creg ? 0 : nw * 32 * (c16 ? 64 : 128)));
     const size_t patch_bytes = (size_t)nw * 32 * (PDSC_CHANNELS * 4 + 16);
     const size_t lds_bytes = stage_bytes > patch_bytes ? stage_bytes : patch_bytes;
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
@@ -582,7 +619,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     const bool trace = nw == 8 && a.trace;
     // A/B knob PDSC_ATT_WIDE = 1: the one-wave-per-SIMD, 64-queries-per-wave variant (attention_wide.hip) where the plan
     // picks the 8-wave kernel
-    if (nw == 8 && !c16 && !trace && env_int("PDSC_ATT_WIDE", 0)) {
+    if (nw == 8 && !c16 && !creg && !trace && env_int("PDSC_ATT_WIDE", 0)) {
         rc = launch_attention_wide(a, grid, st);
         if (rc != PDSC_OK) return rc;
         if (nsplit > 1 && msg) {
@@ -593,21 +630,23 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
         }
         return rc;
     }
-#define PDSC_ATT_LAUNCH(SLOT, NWV, C16V, TRV)                                                                              \
+#define PDSC_ATT_LAUNCH(NWV, CMV, TRV)                                                                                    \
     do {                                                                                                                    \
-        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, C16V, TRV>), lds_bytes,       \
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, CMV, TRV>), lds_bytes,        \
                                 "pdsc_sc_attention_split(dynamic LDS)");                                                    \
         if (rc != PDSC_OK) return rc;                                                                                       \
         profile_mark_begin(PDSC_PROF_ATTENTION, st);                                                                        \
-        hipLaunchKernelGGL((sc_attention_split_kernel<NWV, C16V, TRV>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);      \
+        hipLaunchKernelGGL((sc_attention_split_kernel<NWV, CMV, TRV>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);       \
         profile_mark_end(PDSC_PROF_ATTENTION, st);                                                                          \
     } while (0)
-    if (trace && c16) PDSC_ATT_LAUNCH(0, 8, true, true);
-    else if (trace) PDSC_ATT_LAUNCH(1, 8, false, true);
-    else if (nw == 8 && c16) PDSC_ATT_LAUNCH(2, 8, true, false);
-    else if (nw == 8) PDSC_ATT_LAUNCH(3, 8, false, false);
-    else if (c16) PDSC_ATT_LAUNCH(4, 4, true, false);
-    else PDSC_ATT_LAUNCH(5, 4, false, false);
+    if (trace && c16) PDSC_ATT_LAUNCH(8, 1, true);
+    else if (trace) PDSC_ATT_LAUNCH(8, 0, true);
+    else if (nw == 8 && c16) PDSC_ATT_LAUNCH(8, 1, false);
+    else if (nw == 8 && creg) PDSC_ATT_LAUNCH(8, 2, false);
+    else if (nw == 8) PDSC_ATT_LAUNCH(8, 0, false);
+    else if (c16) PDSC_ATT_LAUNCH(4, 1, false);
+    else if (creg) PDSC_ATT_LAUNCH(4, 2, false);
+    else PDSC_ATT_LAUNCH(4, 0, false);
 #undef PDSC_ATT_LAUNCH
     rc = check_launch("pdsc_sc_attention_split");
     if (rc != PDSC_OK) return rc;
