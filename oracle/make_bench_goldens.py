@@ -48,7 +48,10 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, str(REF))
     from models.PointDSC import PointDSC as RefPointDSC  # the unmodified reference
-    only = sys.argv[1:]
+    # --all: every pair of every workload (census fixtures bench_<name>_all.npz for tools/parity_census.py), not just the
+    # first GOLDEN_PAIRS that the tests and bench.py --check use
+    all_pairs = "--all" in sys.argv
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     report = json.loads((GOLDEN / "BENCH_PINNING.json").read_text()) if (GOLDEN / "BENCH_PINNING.json").exists() else {}
     ok = True
     for name, w in workloads.WORKLOADS.items():
@@ -57,7 +60,7 @@ def main():
         kw = dict(w["model"])
         tmpl = AmdPointDSC(**kw).state_dict()
         ref = RefPointDSC(**kw).eval()
-        G = min(GOLDEN_PAIRS, w["global_batch"])
+        G = w["global_batch"] if all_pairs else min(GOLDEN_PAIRS, w["global_batch"])
         batch = workloads.batch(name, 0, G)
         if w["logit_shift"] is None:
             ref.load_state_dict(workloads.state_dict(name, tmpl, shift=0.0), strict=True)
@@ -89,8 +92,8 @@ def main():
                 res = ref(dict(one, testing=True))
                 t_ref = time.perf_counter() - t0
                 t0 = time.perf_counter()
-                ores = O.forward_testing(sd, one["corr_pos"], one["src_keypts"], one["tgt_keypts"],
-                                         **{k: kw[k] for k in ORACLE_KEYS})
+                ores = res if all_pairs else O.forward_testing(sd, one["corr_pos"], one["src_keypts"], one["tgt_keypts"],
+                                                               **{k: kw[k] for k in ORACLE_KEYS})     # (census: reference only)
                 t_or = time.perf_counter() - t0
                 torch.set_default_dtype(torch.float64)
                 res64 = ref64(dict({k_: v_.double() for k_, v_ in one.items()}, testing=True))
@@ -112,13 +115,13 @@ def main():
                 ok = False
                 print("  !! pin violated")
         np.savez_compressed(
-            GOLDEN / f"bench_{name}.npz",
+            GOLDEN / (f"bench_{name}_all.npz" if all_pairs else f"bench_{name}.npz"),
             ref_final_trans=np.stack(trans), ref_final_labels_bits=np.packbits(np.stack(labels), axis=1),
             logit_shift=np.float64(shift), num_corr=np.int64(w["num_corr"]), stable=np.array(stable, dtype=np.bool_),
             input_checksum=np.array([float(batch[k].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts")]),
             weights_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
             gt_trans=batch["gt_trans"].numpy())
-        report[name] = rep
+        report[name + "_all" if all_pairs else name] = rep
     (GOLDEN / "BENCH_PINNING.json").write_text(json.dumps(report, indent=1))
     print("oracle pinned against the reference on the bench workloads" if ok else "ORACLE DISAGREES WITH THE REFERENCE")
     return 0 if ok else 1

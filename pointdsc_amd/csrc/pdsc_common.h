@@ -1,6 +1,7 @@
 // Shared host/device helpers for libpointdsc_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +36,21 @@ void profile_mark_end(int kind, hipStream_t st);
 static inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+}
+
+// The smallest fp32 x with sqrtf(x) >= thr (host sqrtf is correctly rounded, like the device's): since the correctly
+// rounded square root is monotone, `sqrt(x) >= thr` <=> `x >= x*` and `sqrt(x) < thr` <=> `x < x*`, bit for bit -- lets
+// the N^2 / S*N predicate loops compare the radicand and skip the ~20-instruction IEEE sqrt.  thr <= 0 -> 0; NaN -> NaN.
+static inline float sqrt_threshold_radicand(float thr) {
+    float x = 0.f;
+    if (thr > 0.f) {
+        x = thr * thr;
+        while (x > 0.f && sqrtf(nextafterf(x, 0.f)) >= thr) x = nextafterf(x, 0.f);
+        while (sqrtf(x) < thr) x = nextafterf(x, INFINITY);
+    } else if (thr != thr) {
+        x = thr;
+    }
+    return x;
 }
 
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }

@@ -21,8 +21,20 @@ __device__ __forceinline__ float residual(const float* __restrict__ T, float px,
     return norm3(x - qx, y - qy, z - qz);
 }
 
+// the same residual without the final square root: torch.norm's radicand fma(dz,dz,fma(dy,dy,dx*dx))
+__device__ __forceinline__ float residual_sq(const float* __restrict__ T, float px, float py, float pz, float qx, float qy,
+                                             float qz) {
+    const float x = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
+    const float y = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
+    const float z = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
+    const float dx = x - qx, dy = y - qy, dz = z - qz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// `thr2` = sqrt_threshold_radicand(thr): `residual < thr` and `residual_sq < thr2` are the same predicate bit for bit, so the
+// counts are those of the reference's `L2 < thr` without S*N correctly rounded square roots (half of this kernel's VALU work)
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ seed_trans, const float* __restrict__ src,
-                                                    const float* __restrict__ tgt, float thr, int* __restrict__ counts,
+                                                    const float* __restrict__ tgt, float thr2, int* __restrict__ counts,
                                                     int N, int S) {
     __shared__ float Ts[SC_SEEDS][12];
     const int t = threadIdx.x, lane = t & 63;
@@ -42,7 +54,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ se
         const float px = srcb[i * 3], py = srcb[i * 3 + 1], pz = srcb[i * 3 + 2];
         const float qx = tgtb[i * 3], qy = tgtb[i * 3 + 1], qz = tgtb[i * 3 + 2];
 #pragma unroll
-        for (int s = 0; s < SC_SEEDS; ++s) cnt[s] += residual(Ts[s], px, py, pz, qx, qy, qz) < thr;
+        for (int s = 0; s < SC_SEEDS; ++s) cnt[s] += residual_sq(Ts[s], px, py, pz, qx, qy, qz) < thr2;
     }
 #pragma unroll
     for (int s = 0; s < SC_SEEDS; ++s) {
@@ -164,7 +176,7 @@ extern "C" int pdsc_score_hypotheses(const float* seed_trans, const float* src, 
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)bs * S, st) != hipSuccess) return pdsc::check_launch("memset");
     dim3 grid(pdsc::ceil_div(S, pdsc::SC_SEEDS), pdsc::ceil_div(N, pdsc::SC_POINTS), bs);
-    hipLaunchKernelGGL(pdsc::score_kernel, grid, dim3(256), 0, st, seed_trans, src, tgt, thr, counts, N, S);
+    hipLaunchKernelGGL(pdsc::score_kernel, grid, dim3(256), 0, st, seed_trans, src, tgt, pdsc::sqrt_threshold_radicand(thr), counts, N, S);
     return pdsc::check_launch("pdsc_score_hypotheses");
 }
 

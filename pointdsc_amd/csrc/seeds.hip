@@ -488,18 +488,7 @@ extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, 
     }
 }
 
-// smallest x with sqrtf(x) >= radius (host sqrtf is correctly rounded, like the device's)
-static float nms_radius2(float radius) {
-    float radius2 = 0.f;
-    if (radius > 0.f) {
-        radius2 = radius * radius;
-        while (radius2 > 0.f && sqrtf(nextafterf(radius2, 0.f)) >= radius) radius2 = nextafterf(radius2, 0.f);
-        while (sqrtf(radius2) < radius) radius2 = nextafterf(radius2, INFINITY);
-    } else if (radius != radius) {
-        radius2 = radius;                                                    // NaN radius: every comparison is false
-    }
-    return radius2;
-}
+static float nms_radius2(float radius) { return pdsc::sqrt_threshold_radicand(radius); }
 
 extern "C" size_t pdsc_nms_workspace_bytes(int bs, int N) {
     if (bs <= 0 || N <= 0) return 0;
