@@ -904,6 +904,25 @@ def test_bench_workload_matches_reference_golden(name, bs):
         assert re < 1.0 and te < (60.0 if "kitti" in name else 5.0), (i, re, te)
 
 
+@pytest.mark.parametrize("name", ["n5000_b32", "kitti_n5000_b16", "lomatch_n10000_b8", "n1000_b1"])
+def test_bench_workload_census_every_pair_matches_the_reference(name):
+    """The WHOLE batch bench.py times, every pair against the unmodified reference (census fixtures
+    tests/golden/bench_<name>_all.npz = `oracle/make_bench_goldens.py --all`: 32 + 16 + 8 + 1 pairs): inlier masks bit-exact
+    on every pair, R/t within 1e-4 on every pair the reference itself reproduces between fp32 and fp64 (2 of the 57 pairs
+    sit at 7e-5 / 9e-5 in the reference's own comparison and are held to 1e-3)."""
+    model, _ = _bench_model(name)
+    fx = np.load(GOLDEN / f"bench_{name}_all.npz", allow_pickle=False)
+    w = workloads.WORKLOADS[name]
+    n, bs = w["num_corr"], w["global_batch"]
+    assert fx["ref_final_trans"].shape[0] == bs
+    res = _forward(model, workloads.batch(name, 0, bs))
+    want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:, :n].astype(np.float32))
+    assert int((res["final_labels"].cpu() != want_lab).sum()) == 0
+    dT = (res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().amax(dim=(1, 2))
+    tol = torch.where(torch.from_numpy(fx["stable"]), 1e-4, 1e-3)
+    assert bool((dT < tol).all()), (dT.tolist(), fx["stable"].tolist())
+
+
 def test_bench_timed_path_uses_the_wave_layer_kernel_and_fused_merge():
     """Guards the claim above: at the headline configuration the forward goes through layer_wave_kernel and merges the
     key-split partials inside it (csrc/api.hip:run_forward), i.e. the golden test at bs=32 covers those kernels."""
