@@ -330,6 +330,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __
     // (k+1)-th smallest of the row from above (those k+1 minima are k+1 distinct elements), so only elements <= bound can
     // belong to the answer -- typically ~2(k+1) of them.  Composites are unique (index in the low bits): no ties anywhere.
     __shared__ unsigned long long tmin[KNN_THREADS];
+    __shared__ unsigned long long gmin[64];
     __shared__ unsigned long long fcand[KNN_FAST_CAP];
     __shared__ unsigned long long bound;
     __shared__ int fcand_n;
@@ -361,10 +362,24 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __
     tmin[t] = mymin;
     if (t == 0) { cand_n = 0; fcand_n = 0; }
     __syncthreads();
-    if ((N + 3) / 4 >= want && want <= KNN_THREADS) {        // at least k+1 threads own elements (a thread owns float4 groups)
-        int r = 0;
-        for (int u = 0; u < KNN_THREADS; ++u) r += tmin[u] < mymin;
-        if (r == want - 1) bound = mymin;                     // exactly one thread: minima are distinct
+    // The bound comes from 64 GROUP minima (group l = threads l, l+64, l+128, l+192), ranked by one wave: 64 comparisons for
+    // 64 lanes instead of 256 for 256 threads (that O(256^2) ranking was most of this kernel: ~1300 instructions per thread);
+    // the (k+1)-th smallest of 64 distinct elements still bounds the (k+1)-th smallest of the row from above, it just lets
+    // ~65 instead of ~43 survivors through to the exact ranking below.
+    if (min(64, (N + 3) / 4) >= want) {                       // at least k+1 groups own elements (a thread owns float4 groups)
+        if (wave == 0) {
+            unsigned long long gm = tmin[lane];
+#pragma unroll
+            for (int q = 1; q < KNN_THREADS / 64; ++q) { const unsigned long long o = tmin[64 * q + lane]; gm = o < gm ? o : gm; }
+            gmin[lane] = gm;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int r = 0;
+#pragma unroll 8
+            for (int u = 0; u < 64; ++u) r += gmin[u] < gm;
+            if (r == want - 1) bound = gm;                    // exactly one lane: group minima are distinct elements
+        }
         __syncthreads();
         const unsigned long long ub = bound;
         for (int j = t; j < N; j += KNN_THREADS) {
