@@ -932,6 +932,34 @@ def test_bench_timed_path_uses_the_wave_layer_kernel_and_fused_merge():
     assert 1 < ns <= 4, ns
 
 
+@pytest.mark.parametrize("n", [20000, 36864])
+def test_large_n_properties_up_to_the_documented_limit(n):
+    """multiway/test_multi_ate.py:245 feeds up to 20 000 correspondences; 36 864 is the documented maximum (kNN row in one
+    workgroup's LDS).  No oracle at these sizes (the CPU path needs tens of GB): size-independent properties instead -- a
+    rigid motion close to the ground truth, labels == the inliers of the pre-refinement hypothesis (recomputed on the host
+    from the returned initial_trans), inlier mask ~ the ground-truth mask."""
+    model, _ = _bench_model("n5000_b32")
+    pair = synthetic.make_pair(n, seed=77, inlier_ratio=0.2)
+    res = _forward(model, pair)
+    T = res["final_trans"][0].cpu().double()
+    assert (T[:3, :3] @ T[:3, :3].T - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5 and abs(float(torch.det(T[:3, :3])) - 1) < 1e-5
+    re, te = O.registration_errors(res["final_trans"][0].cpu(), pair["gt_trans"][0])
+    assert re < 1.0 and te < 5.0, (re, te)
+    init = model.workspace_view("initial_trans", 1, n)[:16].reshape(1, 4, 4).cpu()
+    L2 = O.residuals(init, pair["src_keypts"][0], pair["tgt_keypts"][0])[0]
+    lab = res["final_labels"][0].cpu()
+    assert torch.equal(lab, (L2 < KW["inlier_threshold"]).float())
+    tp = float((lab * pair["gt_labels"][0]).sum())
+    assert tp / float(pair["gt_labels"][0].sum()) > 0.95 and tp / float(lab.sum()) > 0.95
+
+
+def test_n_above_the_limit_is_rejected_loudly():
+    model, _ = _bench_model("n5000_b32")
+    pair = synthetic.make_pair(36865, seed=1, inlier_ratio=0.2)
+    with pytest.raises(RuntimeError):
+        _forward(model, pair)
+
+
 def test_forward_is_bitwise_repeatable():
     """Same inputs, same process: poses, labels, features and every seed hypothesis come out bit for bit the same (no
     order-dependent float atomics anywhere on the path), in both compat formats."""
