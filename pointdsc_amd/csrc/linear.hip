@@ -162,7 +162,7 @@ static int launch_linear(const LinearArgs& a, int batches, hipStream_t st) {
 // the column operand once per row block (the generic linear_kernel re-reads both per 64 x 128 output tile and fits one
 // workgroup per CU).  Accumulator lane = column, so each of the 16 stores of a tile writes 128 contiguous bytes per half
 // wave.  Exact fp32 MFMA; bound: MFMA (256 flop per output element) with the 4-byte output stream behind it.
-constexpr int GR_ROWS = 128, GR_COLS = 64, GR_LD = PDSC_CHANNELS + 4;
+constexpr int GR_ROWS = 128, GR_LD = PDSC_CHANNELS + 4;
 
 struct GramArgs {
     const float* X;          // [bs][N][128]
@@ -172,7 +172,8 @@ struct GramArgs {
     int R, N, tiles_per_split;
 };
 
-template <int MODE>
+// GR_COLS = columns per LDS stage: 64 (67.5 KiB, 2 workgroups per CU) or 32 (33.8 KiB, 4 per CU); same results bit for bit
+template <int MODE, int GR_COLS>
 __global__ __launch_bounds__(256, 2) void gram_rows_kernel(GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x [GR_COLS][GR_LD]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -196,11 +197,12 @@ __global__ __launch_bounds__(256, 2) void gram_rows_kernel(GramArgs a) {
     float sig2 = 1.f;
     if (MODE == 2) { const float sg = a.sigma[0]; sig2 = sg * sg; }
 
-    // stage loader: thread -> 8 float4 of a 64 x 128 tile
-    f32x4 stage[8];
+    // stage loader: thread -> NST float4 of a GR_COLS x 128 tile
+    constexpr int NST = GR_COLS * 32 / 256;
+    f32x4 stage[NST];
     auto load_tile = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NST; ++i) {
             const int f = t + 256 * i, r = f >> 5, c4 = (f & 31) * 4;
             const int col = min(tile * GR_COLS + r, a.N - 1);
             stage[i] = *reinterpret_cast<const f32x4*>(X + (size_t)col * PDSC_CHANNELS + c4);
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gram_rows_kernel(GramArgs a) {
     };
     auto store_tile = [&](float* buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NST; ++i) {
             const int f = t + 256 * i, r = f >> 5, c4 = (f & 31) * 4;
             *reinterpret_cast<f32x4*>(buf + r * GR_LD + c4) = stage[i];
         }
@@ -256,19 +258,23 @@ __global__ __launch_bounds__(256, 2) void gram_rows_kernel(GramArgs a) {
     }
 }
 
-template <int MODE>
-static int launch_gram(GramArgs a, int bs, hipStream_t st) {
-    const size_t lds_bytes = 2 * (size_t)GR_COLS * GR_LD * sizeof(float);     // 67 584 B
-    const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_rows_kernel<MODE>), lds_bytes, "gram_rows(dynamic LDS)");
+template <int MODE, int GR_COLS>
+static int launch_gram_cols(GramArgs a, int bs, hipStream_t st) {
+    const size_t lds_bytes = 2 * (size_t)GR_COLS * GR_LD * sizeof(float);     // 67 584 B (64 columns)
+    const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_rows_kernel<MODE, GR_COLS>), lds_bytes, "gram_rows(dynamic LDS)");
     if (rc_lds != PDSC_OK) return rc_lds;
     const int row_blocks = ceil_div(a.R, GR_ROWS), tiles = ceil_div(a.N, GR_COLS);
-    int splits = ceil_div(768, row_blocks * bs);                   // ~3 workgroups per CU in flight
+    int splits = ceil_div(GR_COLS == 32 ? 1536 : 768, row_blocks * bs);                   // ~3 workgroups per CU in flight
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     a.tiles_per_split = ceil_div(tiles, splits);
     splits = ceil_div(tiles, a.tiles_per_split);
-    hipLaunchKernelGGL((gram_rows_kernel<MODE>), dim3(splits, row_blocks, bs), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((gram_rows_kernel<MODE, GR_COLS>), dim3(splits, row_blocks, bs), dim3(256), lds_bytes, st, a);
     return check_launch("gram_rows_kernel");
+}
+template <int MODE>
+static int launch_gram(GramArgs a, int bs, hipStream_t st) {
+    return env_int("PDSC_GRAM_COLS", 64) == 32 ? launch_gram_cols<MODE, 32>(a, bs, st) : launch_gram_cols<MODE, 64>(a, bs, st);     // A/B knob
 }
 
 int knn_dist_rows(const float* normed, const int* seeds, float* dist, long long ldd, int bs, int N, int S,
