@@ -57,7 +57,27 @@ typedef struct pdsc_config {
     float refine_threshold;  /* 0.10 if inlier_threshold == 0.10 else 1.2 (:415-418) */
     int attention_precision; /* enum pdsc_attention_precision: how the two N x N x C contractions are evaluated */
     int compat_format;       /* enum pdsc_compat_format: how the forward stores the N x N spatial-consistency matrix  */
+    int layer_gemm;          /* enum pdsc_layer_gemm: arithmetic of the fc_message / PointCN GEMMs in the fused layer kernel */
 } pdsc_config;
+
+/* Arithmetic of the point-wise GEMMs whose results land on the residual stream (fc1..fc3 of fc_message, PointCN;
+ * models/PointDSC.py:12-23,56-61) inside the wavefront-resident fused layer kernel (split-precision modes, problems large
+ * enough for that kernel -- pdsc_layer_prefers_block(bs, N) == 0):
+ *   F32: v_mfma_f32_32x32x2_f32, exact fp32 products (600 MFMAs x 64 matrix-pipe cycles per 32-point tile).
+ *   H3 : every fp32 operand as fp16 hi + fp16 lo' (lo' = (x - hi) * 2048), product = hi*hi + (hi*lo' + lo'*hi) / 2048 on
+ *        v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative error per product (the bf16 hi/lo split of the
+ *        attention operands: 2^-16), 216 MFMAs x 32 cycles per tile.  Operands must stay inside the fp16 range
+ *        (|x| < 65504); the network's activations and weights are O(1). */
+enum pdsc_layer_gemm { PDSC_LAYER_GEMM_F32 = 0, PDSC_LAYER_GEMM_H3 = 1 };
+
+/* Order of the [rows][C] fp32 matrices handed from the attention to the fused layer kernel (key-split partials) and from
+ * one fused layer launch to the next (featB = the residual): plain rows, or point-fragment order (PF) -- rows in tiles of 32,
+ * a tile = [q = 0..15][lane = 0..63][4 floats] with lane (l31 = lane & 31, h = lane >> 5) holding channels 8q + 4h .. + 3 of
+ * row l31: exactly the registers of the producing and of the consuming wavefront, so every store / load instruction moves
+ * 1 KiB of consecutive memory and neither side transposes through LDS.  PF buffers are padded to whole tiles per pair
+ * (ceil(N / 32) * 32 rows); padding rows hold copies of the pair's last row.  Only the H3 layer kernel reads / writes PF. */
+enum pdsc_partial_layout { PDSC_PARTIALS_ROWS = 0, PDSC_PARTIALS_PF = 1 };
+enum pdsc_layer_io { PDSC_IO_PARTIALS_PF = 1, PDSC_IO_RES_PF = 2, PDSC_IO_FEATB_PF = 4 };
 
 /* Storage of the spatial-consistency matrix between its build and the 12 attention launches that stream it
  * (the split-precision modes only; PDSC_ATT_FP32 always uses fp32 storage):
@@ -127,6 +147,12 @@ size_t pdsc_workspace_bytes(const pdsc_config* cfg, int bs, int N, int num_seeds
  * src_dist: optional (may be NULL) [bs][N][ld]; the fused path never materialises it. */
 int pdsc_spatial_compat(const float* src_keypts, const float* tgt_keypts, const float* sigma_spat,
                         float* compat, float* src_dist, long long ld, int bs, int N, void* stream);
+
+/* Partials only (no merge: the fused layer kernel merges while it loads), compat in either storage format, partials in
+ * either order (enum pdsc_partial_layout); nsplit as above (0 = the plan's), must come out > 1. */
+int pdsc_sc_attention_split_partials(const void* q_split, const void* kv_tiles, const void* compat, int compat_format,
+                                     long long ld, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
+                                     int partial_layout, void* stream);
 
 /* unorm16 variant (enum pdsc_compat_format): compat_u16 [bs][N][ld] uint16, ld = pdsc_compat_ld(N) (multiple of 32),
  * value u = round(compat * 65535); inside every group of 32 columns, column 8g + 4h + e is stored at position
@@ -207,12 +233,31 @@ int pdsc_layer_fused_x3(const float* msg, const float* part_o, const float* part
  * pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_TAIL / PDSC_WS_FRAG_HEAD, layer). */
 #define PDSC_WS_FRAG_TAIL 100
 #define PDSC_WS_FRAG_HEAD 101
+#define PDSC_WS_FRAG_TAIL_H3 102   /* the same streams built with gemm_format = PDSC_LAYER_GEMM_H3 */
+#define PDSC_WS_FRAG_HEAD_H3 103
 int pdsc_layer_prefers_block(int bs, int N);   /* 1: pdsc_forward_* takes the workgroup-per-tile kernel for this size */
 size_t pdsc_wfrag_tail_bytes(void);
 size_t pdsc_wfrag_head_bytes(void);
 int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                           const float* b3, void* out, void* stream);
 int pdsc_wfrag_build_head(const float* wp, const float* bp, const float* wq, const float* bq, void* out, void* stream);
+/* ... with the format of the fc1..fc3 / pcn chunks chosen (enum pdsc_layer_gemm; the q|k|v chunks are bf16 hi / lo in
+ * both; the un-suffixed entries build PDSC_LAYER_GEMM_F32 streams).  pdsc_layer_fused_frag_fmt must be told the format. */
+int pdsc_wfrag_build_tail_fmt(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                              const float* b3, void* out, int gemm_format, void* stream);
+int pdsc_wfrag_build_head_fmt(const float* wp, const float* bp, const float* wq, const float* bq, void* out,
+                              int gemm_format, void* stream);
+int pdsc_layer_fused_frag_fmt(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                              const float* res, const float* feat_in, float* feat_out, float* featB_out, float* qkv_out,
+                              void* q_split, void* kv_tiles, const void* wfrag_tail, const void* wfrag_head,
+                              int gemm_format, int bs, int N, void* stream);
+/* ... with point-fragment hand-offs: io_flags = OR of enum pdsc_layer_io (which of part_o / res / featB_out are PF).
+ * Needs gemm_format = PDSC_LAYER_GEMM_H3 and the forward's output set (head: split streams only, no qkv_out; tail + head:
+ * no feat_out); PDSC_ERR_ARG otherwise.  PF res / featB_out buffers hold bs * ceil(N / 32) * 32 rows. */
+int pdsc_layer_fused_frag_io(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                             const float* res, const float* feat_in, float* feat_out, float* featB_out,
+                             void* q_split, void* kv_tiles, const void* wfrag_tail, const void* wfrag_head,
+                             int gemm_format, int io_flags, int bs, int N, void* stream);
 int pdsc_layer_fused_frag(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
                           const float* res, const float* feat_in, float* feat_out, float* featB_out, float* qkv_out,
                           void* q_split, void* kv_tiles, const void* wfrag_tail, const void* wfrag_head, int bs, int N,

@@ -24,7 +24,7 @@ class PdscConfig(C.Structure):
         ("in_dim", C.c_int), ("num_layers", C.c_int), ("num_channels", C.c_int),
         ("num_iterations", C.c_int), ("k", C.c_int), ("refine_iters", C.c_int),
         ("inlier_threshold", C.c_float), ("nms_radius", C.c_float), ("refine_threshold", C.c_float),
-        ("attention_precision", C.c_int), ("compat_format", C.c_int),
+        ("attention_precision", C.c_int), ("compat_format", C.c_int), ("layer_gemm", C.c_int),
     ]
 
 
@@ -63,6 +63,11 @@ SIGNATURES = {
     "pdsc_wfrag_head_bytes": (_sz, []),
     "pdsc_wfrag_build_tail": (_i, [_vp] * 8),
     "pdsc_wfrag_build_head": (_i, [_vp] * 6),
+    "pdsc_wfrag_build_tail_fmt": (_i, [_vp] * 7 + [_i, _vp]),
+    "pdsc_wfrag_build_head_fmt": (_i, [_vp] * 5 + [_i, _vp]),
+    "pdsc_layer_fused_frag_fmt": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 9 + [_i, _i, _i, _vp]),
+    "pdsc_layer_fused_frag_io": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 8 + [_i, _i, _i, _i, _vp]),
+    "pdsc_sc_attention_split_partials": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _sz, _i, _i, _i, _i, _vp]),
     "pdsc_layer_fused_frag": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 9 + [_i, _i, _vp]),
     "pdsc_split_q_bytes": (_sz, [_i, _i]),
     "pdsc_split_kv_bytes": (_sz, [_i, _i]),

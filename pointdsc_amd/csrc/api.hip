@@ -80,6 +80,7 @@ static bool config_ok(const pdsc_config* c) {
         set_error("attention_precision=%d", c->attention_precision); return false;
     }
     if (c->compat_format != PDSC_COMPAT_U16 && c->compat_format != PDSC_COMPAT_F32) { set_error("compat_format=%d", c->compat_format); return false; }
+    if (c->layer_gemm != PDSC_LAYER_GEMM_F32 && c->layer_gemm != PDSC_LAYER_GEMM_H3) { set_error("layer_gemm=%d", c->layer_gemm); return false; }
     return true;
 }
 
@@ -162,8 +163,9 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     const bool compat16 = c->attention_precision != PDSC_ATT_FP32 && c->compat_format == PDSC_COMPAT_U16;
     L.add("compat", (size_t)bs * N * ld * (compat16 ? sizeof(unsigned short) : f));
     L.add("featA", M * C * f);
-    L.add("featB", M * C * f);
-    L.add("featC", M * C * f);
+    const size_t Mpf = (size_t)bs * round_up(N, 32);          // featB / featC may be kept in point-fragment order: whole 32-row tiles per pair
+    L.add("featB", Mpf * C * f);
+    L.add("featC", Mpf * C * f);
     L.add("qkv", M * 3 * C * f);
     L.add("msg", M * C * f);
     L.add("t64a", M * (C / 2) * f);
@@ -332,23 +334,43 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         // tuning/A-B knob: PDSC_LAYER_FRAG = 0 = natural-layout weights (pdsc_layer_fused_split)
         const bool frag_env = env_int("PDSC_LAYER_FRAG", 1) && !(var && var[0] == 'b');
         // default: wavefront-resident layer kernel on fragment streams; small problems: the workgroup-per-tile kernel (layer.hip)
-        const bool frag = frag_env && !x3_gemm && !pdsc_layer_prefers_block(bs, N);
+        const bool frag = frag_env && !x3_gemm && ((var && var[0] == 'w') || !pdsc_layer_prefers_block(bs, N));
+        // arithmetic of fc1..fc3 / PointCN in that kernel (enum pdsc_layer_gemm); A/B knob PDSC_LAYER_GEMM = 0 / 1 overrides
+        const int gemm = env_int("PDSC_LAYER_GEMM", cfg->layer_gemm) == PDSC_LAYER_GEMM_H3 ? PDSC_LAYER_GEMM_H3 : PDSC_LAYER_GEMM_F32;
+        const int ws_tail = gemm == PDSC_LAYER_GEMM_H3 ? PDSC_WS_FRAG_TAIL_H3 : PDSC_WS_FRAG_TAIL;
+        const int ws_head = gemm == PDSC_LAYER_GEMM_H3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD;
+        // H3 + fused merge: the hand-offs attention -> layer kernel -> next layer kernel in point-fragment order (split_layout.h);
+        // A/B knob PDSC_LAYER_PF = 0: plain rows
+        const bool pf = frag && gemm == PDSC_LAYER_GEMM_H3 && fuse_merge && env_int("PDSC_LAYER_PF", 1) != 0 &&
+                        env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
         if (x3_gemm)
             PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
                                          WS(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), bs, N, stream));
+        else if (pf)
+            PDSC_TRY(pdsc_layer_fused_frag_io(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, q_split, kv_tiles,
+                                              nullptr, WS(ws_head, 0), gemm, PDSC_IO_FEATB_PF, bs, N, stream));
         else if (frag)
-            PDSC_TRY(pdsc_layer_fused_frag(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
-                                           nullptr, WS(PDSC_WS_FRAG_HEAD, 0), bs, N, stream));
+            PDSC_TRY(pdsc_layer_fused_frag_fmt(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
+                                               nullptr, WS(ws_head, 0), gemm, bs, N, stream));
         else
             PDSC_TRY(pdsc_layer_fused_split(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, W(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
                                             W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), WS(PDSC_W_QKV_W, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            PDSC_TRY(attention_split(fuse_merge ? nullptr : msg, ns));
+            if (pf)
+                PDSC_TRY(pdsc_sc_attention_split_partials(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld,
+                                                          att_scratch, att_bytes, bs, N, ns, PDSC_PARTIALS_PF, stream));
+            else
+                PDSC_TRY(attention_split(fuse_merge ? nullptr : msg, ns));
             const bool last = i + 1 == cfg->num_layers;
-            if (x3_gemm)
+            if (pf)
+                PDSC_TRY(pdsc_layer_fused_frag_io(nullptr, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
+                                                  last ? nullptr : nxt, last ? nullptr : q_split, last ? nullptr : kv_tiles,
+                                                  WS(ws_tail, i), last ? nullptr : WS(ws_head, i + 1), gemm,
+                                                  PDSC_IO_PARTIALS_PF | PDSC_IO_RES_PF | (last ? 0 : PDSC_IO_FEATB_PF), bs, N, stream));
+            else if (x3_gemm)
                 PDSC_TRY(pdsc_layer_fused_x3(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
                                              last ? nullptr : nxt, nullptr, last ? nullptr : q_split, last ? nullptr : kv_tiles,
                                              WS(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), WS(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
@@ -357,10 +379,10 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                              last ? nullptr : WS(PDSC_W_QKV_W, i + 1), last ? nullptr : W(PDSC_W_QKV_B, i + 1),
                                              bs, N, stream));
             else if (frag)
-                PDSC_TRY(pdsc_layer_fused_frag(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
-                                               last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,
-                                               last ? nullptr : kv_tiles, WS(PDSC_WS_FRAG_TAIL, i),
-                                               last ? nullptr : WS(PDSC_WS_FRAG_HEAD, i + 1), bs, N, stream));
+                PDSC_TRY(pdsc_layer_fused_frag_fmt(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
+                                                   last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,
+                                                   last ? nullptr : kv_tiles, WS(ws_tail, i),
+                                                   last ? nullptr : WS(ws_head, i + 1), gemm, bs, N, stream));
             else
                 PDSC_TRY(pdsc_layer_fused_split(fuse_merge ? nullptr : msg, part_o, part_ml, ns, Npad, cur, nullptr,
                                                 last ? featA : nullptr, last ? nullptr : nxt, nullptr, last ? nullptr : q_split,

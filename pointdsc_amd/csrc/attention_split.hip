@@ -414,6 +414,32 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // LDS (row pitch 528 B) and stores whole rows: one instruction = 2 rows = 8 full lines.
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int q0 = qb * (NW * 32) + wave * 32;
+    if (a.nsplit != 1 && a.part_frag) {
+        // point-fragment order (split_layout.h): the accumulator registers of lane (query l31, half h) ARE the 16-byte
+        // pieces the fused layer kernel's lane loads -- 1 KiB of consecutive memory per store instruction, no LDS
+        // transposition.  Lanes past N hold copies of query N-1 and fill the padding of the pair's last tile.
+        float* base = a.part_o + (((size_t)b * a.nsplit + sp) * a.Npad + q0) * PDSC_CHANNELS + lane * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(base + pf_offset_floats(4 * c + g)) = f32x4{o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]};
+        if (h == 0 && q0 + l31 < a.Npad) {
+            const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + q0 + l31;
+            a.part_ml[slot * 2 + 0] = m_run;
+            a.part_ml[slot * 2 + 1] = l_tot;
+        }
+        if (TRACE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PDSC_TRACE_STAMP(7)
+            if (lane == 0 && a.trace) {
+                long long* dst = a.trace + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dst[k] = tr[k];
+            }
+        }
+        return;
+    }
     __syncthreads();                                    // the other waves are done reading K / V
     constexpr int OPITCH = PDSC_CHANNELS * 4 + 16;
     unsigned char* const patch = lds + wave * (32 * OPITCH);
@@ -581,7 +607,8 @@ extern "C" int pdsc_attention_trace(long long* device_buffer) {   // diagnostics
 }
 
 static int launch_attention_split(const void* q_split, const void* kv_tiles, const void* compat, bool c16, long long ld,
-                                  float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream) {
+                                  float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream,
+                                  int partial_layout = PDSC_PARTIALS_ROWS) {
     PDSC_REQUIRE(q_split && kv_tiles && compat, "pdsc_sc_attention_split: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_split: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % (c16 ? 8 : 4) == 0,
@@ -606,6 +633,9 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.trace = g_att_trace;
     a.prio_mode = env_int("PDSC_ATT_PRIO", 0);
     a.compat_nt = c16 ? 0 : 1;                 // (the wide variant still takes it as an argument)
+    PDSC_REQUIRE(partial_layout == PDSC_PARTIALS_ROWS || partial_layout == PDSC_PARTIALS_PF, "pdsc_sc_attention_split: partial_layout=%d", partial_layout);
+    PDSC_REQUIRE(partial_layout == PDSC_PARTIALS_ROWS || (!msg && nsplit > 1), "pdsc_sc_attention_split: point-fragment partials are not merged here (msg must be NULL, key split > 1)");
+    a.part_frag = partial_layout == PDSC_PARTIALS_PF;
     hipStream_t st = (hipStream_t)stream;
     // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
     // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)
@@ -619,7 +649,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     const bool trace = nw == 8 && a.trace;
     // A/B knob PDSC_ATT_WIDE = 1: the one-wave-per-SIMD, 64-queries-per-wave variant (attention_wide.hip) where the plan
     // picks the 8-wave kernel
-    if (nw == 8 && !c16 && !creg && !trace && env_int("PDSC_ATT_WIDE", 0)) {
+    if (nw == 8 && !c16 && !creg && !trace && !a.part_frag && env_int("PDSC_ATT_WIDE", 0)) {
         rc = launch_attention_wide(a, grid, st);
         if (rc != PDSC_OK) return rc;
         if (nsplit > 1 && msg) {
@@ -663,6 +693,14 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
                                        float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                        void* stream) {
     return launch_attention_split(q_split, kv_tiles, compat, false, ld, msg, scratch, scratch_bytes, bs, N, nsplit, stream);
+}
+
+extern "C" int pdsc_sc_attention_split_partials(const void* q_split, const void* kv_tiles, const void* compat, int compat_format,
+                                                long long ld, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
+                                                int partial_layout, void* stream) {
+    PDSC_REQUIRE(compat_format == PDSC_COMPAT_F32 || compat_format == PDSC_COMPAT_U16, "pdsc_sc_attention_split_partials: compat_format=%d", compat_format);
+    return launch_attention_split(q_split, kv_tiles, compat, compat_format == PDSC_COMPAT_U16, ld, nullptr, scratch, scratch_bytes, bs, N,
+                                  nsplit, stream, partial_layout);
 }
 
 extern "C" int pdsc_sc_attention_split_u16(const void* q_split, const void* kv_tiles, const unsigned short* compat_u16,

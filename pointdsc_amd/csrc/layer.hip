@@ -414,7 +414,7 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
-                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, g_layer_trace};
+                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, PDSC_LAYER_GEMM_F32, 0, 0, 0, g_layer_trace};
     hipStream_t st = (hipStream_t)stream;
     // Two implementations.  layer_wave.hip (one wavefront per 32-point tile) wins once the tiles fill the chip; with few
     // tiles its serial 46k matrix-pipe cycles per tile are the launch time, and this file's kernel, which spreads a tile

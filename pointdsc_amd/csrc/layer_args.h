@@ -27,9 +27,15 @@ struct LayerArgs {
     // consumes them (pdsc_wfrag_build_tail / _head); when given they replace w1..w3 / wp, wq, wq_split
     const unsigned char* wf_tail;
     const unsigned char* wf_head;
+    int gemm_format;         // format the fragment streams were built in: PDSC_LAYER_GEMM_F32 (fc1..fc3, pcn as fp32 rows) or
+                             // PDSC_LAYER_GEMM_H3 (fp16 hi / scaled-lo pairs: those GEMMs run on v_mfma_f32_32x32x16_f16)
+    int io_flags;            // enum pdsc_layer_io: which of part_o / res / featB_out are in point-fragment order (layer_h3.hip only)
+    int stagger_cycles, stagger_mode;   // layer_h3.hip: start delay of half the first round's wavefronts (A/B knobs PDSC_LAYER_STAGGER, _MODE)
     long long* trace;        // diagnostics (pdsc_layer_trace): [workgroup][wave][16] shader-clock stamps, else NULL
 };
 
 int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st);      // layer_wave.hip
+int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st);        // layer_h3.hip (H3 fragment streams only)
+bool launch_layer_h3_fits(const LayerArgs& a, bool tail, bool head);                  // ... and only this output set
 
 }  // namespace pdsc

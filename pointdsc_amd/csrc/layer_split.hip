@@ -304,13 +304,17 @@ static long long wsplit_layer_elems() {
 }
 
 // after the hi|lo matrices of all layers: the fragment-ordered streams of layer_wave.hip, per layer [tail][head]
-static long long wsplit_frag_layer_elems() { return (long long)(pdsc_wfrag_tail_bytes() + pdsc_wfrag_head_bytes()) / 2; }
+// ... in both GEMM formats (enum pdsc_layer_gemm): [tail F32][head F32][tail H3][head H3]
+static long long wsplit_frag_layer_elems() { return (long long)(pdsc_wfrag_tail_bytes() + pdsc_wfrag_head_bytes()); }
 
 extern "C" long long pdsc_wsplit_offset(const pdsc_config* cfg, int section, int layer) {
     if (!cfg || layer < 0 || layer >= cfg->num_layers) return -1;
-    if (section == PDSC_WS_FRAG_TAIL || section == PDSC_WS_FRAG_HEAD)
-        return (long long)cfg->num_layers * wsplit_layer_elems() + (long long)layer * wsplit_frag_layer_elems() +
-               (section == PDSC_WS_FRAG_HEAD ? (long long)pdsc_wfrag_tail_bytes() / 2 : 0);
+    if (section >= PDSC_WS_FRAG_TAIL && section <= PDSC_WS_FRAG_HEAD_H3) {
+        const long long tail = (long long)pdsc_wfrag_tail_bytes() / 2, head = (long long)pdsc_wfrag_head_bytes() / 2;
+        const long long inside = section == PDSC_WS_FRAG_TAIL ? 0 : section == PDSC_WS_FRAG_HEAD ? tail
+                               : section == PDSC_WS_FRAG_TAIL_H3 ? tail + head : 2 * tail + head;
+        return (long long)cfg->num_layers * wsplit_layer_elems() + (long long)layer * wsplit_frag_layer_elems() + inside;
+    }
     long long off = (long long)layer * wsplit_layer_elems();
     for (int i = 0; i < 5; ++i) {
         if (kWsplitSection[i] == section) return off;
@@ -335,12 +339,17 @@ extern "C" int pdsc_wsplit_build(const pdsc_config* cfg, const float* wpack, voi
                                (__bf16*)wsplit + dst, n);
         }
         auto W = [&](int section) { return wpack + pdsc_wpack_offset(cfg, section, layer); };
-        int rc = pdsc_wfrag_build_tail(W(PDSC_W_FC1_W), W(PDSC_W_FC1_B), W(PDSC_W_FC2_W), W(PDSC_W_FC2_B), W(PDSC_W_FC3_W), W(PDSC_W_FC3_B),
-                                       (__bf16*)wsplit + pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_TAIL, layer), stream);
-        if (rc != PDSC_OK) return rc;
-        rc = pdsc_wfrag_build_head(W(PDSC_W_PCN_W), W(PDSC_W_PCN_B), W(PDSC_W_QKV_W), W(PDSC_W_QKV_B),
-                                   (__bf16*)wsplit + pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_HEAD, layer), stream);
-        if (rc != PDSC_OK) return rc;
+        for (int fmt = PDSC_LAYER_GEMM_F32; fmt <= PDSC_LAYER_GEMM_H3; ++fmt) {
+            const bool h3 = fmt == PDSC_LAYER_GEMM_H3;
+            int rc = pdsc_wfrag_build_tail_fmt(W(PDSC_W_FC1_W), W(PDSC_W_FC1_B), W(PDSC_W_FC2_W), W(PDSC_W_FC2_B), W(PDSC_W_FC3_W), W(PDSC_W_FC3_B),
+                                               (__bf16*)wsplit + pdsc_wsplit_offset(cfg, h3 ? PDSC_WS_FRAG_TAIL_H3 : PDSC_WS_FRAG_TAIL, layer),
+                                               fmt, stream);
+            if (rc != PDSC_OK) return rc;
+            rc = pdsc_wfrag_build_head_fmt(W(PDSC_W_PCN_W), W(PDSC_W_PCN_B), W(PDSC_W_QKV_W), W(PDSC_W_QKV_B),
+                                           (__bf16*)wsplit + pdsc_wsplit_offset(cfg, h3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD, layer),
+                                           fmt, stream);
+            if (rc != PDSC_OK) return rc;
+        }
     }
     return check_launch("pdsc_wsplit_build");
 }

@@ -12,6 +12,9 @@ namespace pdsc {
 constexpr int LW_WAVES = 4;      // independent wavefronts per workgroup
 constexpr int LW_VLD = 36;       // floats per key row of the V transpose patch (32 channels + 4 pad)
 constexpr int LW_QKV_BUFS = 4;   // weight-chunk buffers (32 registers each) during the split q|k|v projection
+#ifndef LW_H3_BUFS
+#define LW_H3_BUFS 3             // ... during every stage of the H3 variant (4 spills: 256 registers with 3)
+#endif
 
 struct WChunk {
     f32x4 v[8];      // 8 fp32 k-steps (q) of a weight tile, or 4 bf16 k-steps as (hi, lo) pairs
@@ -149,6 +152,30 @@ __device__ __forceinline__ void split4(const f32x4& v, unsigned (&hi)[2], unsign
     split2(v[2], v[3], hi[1], lo[1]);
 }
 
+// ---- fp16 hi / scaled-lo split (the H3 arithmetic of the fc1..fc3 / PointCN GEMMs) -----------------------------------
+// x = hi + lo' / 2048 with hi = f16(x), lo' = f16((x - hi) * 2048), both round-to-nearest-even.  hi carries 11
+// significant bits, lo' the next 11: a product a*b evaluated as  a_hi*b_hi + (a_hi*b_lo' + a_lo'*b_hi) / 2048  on
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate, the two cross terms in their own accumulator) is exact to ~2^-21 relative --
+// 32x tighter than the bf16 hi/lo split of split_layout.h at the same three MFMAs per operand pair, which is what lets the
+// GEMMs that land on the residual stream leave the fp32 MFMA (1/16 of the f16 rate).  The scale keeps lo' in the normal
+// range of fp16 whenever hi is.  Range: |x| < 65504 (fp16); activations and weights of this network are O(1).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f16x2 hv = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    hi = __builtin_bit_cast(unsigned, hv);
+    const f32x2 hf = __builtin_convertvector(hv, f32x2);
+    const f16x2 lv = __builtin_convertvector(f32x2{(x0 - hf[0]) * H3_SCALE, (x1 - hf[1]) * H3_SCALE}, f16x2);
+    lo = __builtin_bit_cast(unsigned, lv);
+}
+
+__device__ __forceinline__ void split4h(const f32x4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    split2h(v[0], v[1], hi[0], lo[0]);
+    split2h(v[2], v[3], hi[1], lo[1]);
+}
+
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.
 // afterwards, per lane: lower half (a, b) = (own a, partner's a);  upper half (a, b) = (partner's b, own b).
 __device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {
@@ -165,6 +192,34 @@ __device__ __forceinline__ u32x4 chunk_for_store(const unsigned (&hi)[2], const 
     half_swap(a1, b1);
     // lower half: own = channels 0..3, partner = 4..7 -> (a0, a1, b0, b1); upper: partner = 0..3 (a), own = 4..7 (b)
     return u32x4{a0, a1, b0, b1};
+}
+
+// B operand of one 16-wide k-step kk from the fp32 accumulator layout: lane-half h holds `a` = channels 16kk + 4h + e and
+// `b` = channels 16kk + 8 + 4h + e of its point; the k-step wants channels 16kk + 8h .. +7 in lane-half h.  F16 selects the
+// fp16 hi / scaled-lo split (H3) instead of the bf16 hi / lo split.
+template <bool F16>
+__device__ __forceinline__ void make_kstep(const f32x4& a, const f32x4& b, u32x4& oh, u32x4& ol) {
+    unsigned ha[2], la[2], hb[2], lb[2];
+    if constexpr (F16) { split4h(a, ha, la); split4h(b, hb, lb); }
+    else { split4(a, ha, la); split4(b, hb, lb); }
+    half_swap(ha[0], hb[0]); half_swap(ha[1], hb[1]);
+    half_swap(la[0], lb[0]); half_swap(la[1], lb[1]);
+    oh = u32x4{ha[0], ha[1], hb[0], hb[1]};
+    ol = u32x4{la[0], la[1], lb[0], lb[1]};
+}
+
+// one weight chunk (4 k-steps as (hi, lo') slot pairs) in the H3 arithmetic: main accumulator <- hi*hi, cross <- the two
+// hi*lo' terms (scaled by 2048; folded in by the tile epilogue)
+__device__ __forceinline__ void mma_h3(f32x16& acc, f32x16& cross, const WChunk& w, const u32x4* xh, const u32x4* xl, bool first) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, w.v[2 * i]), wl = __builtin_bit_cast(f16x8, w.v[2 * i + 1]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, xh[i]), bl = __builtin_bit_cast(f16x8, xl[i]);
+        cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, (first && i == 0) ? zero : cross, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc, 0, 0, 0);
+        cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, cross, 0, 0, 0);
+    }
 }
 
 // ---- output staging ---------------------------------------------------------------------------------------------------

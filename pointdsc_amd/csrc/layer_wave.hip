@@ -31,8 +31,11 @@ namespace pdsc {
 #define LW_STAMP(k) \
     if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
 
-template <bool T, bool H, bool X3, bool FRAG, bool TRACE = false>
+// HX: fc1..fc3 and PointCN in the fp16 hi / scaled-lo arithmetic (H3, layer_wave.h) on fragment streams built with
+// format PDSC_LAYER_GEMM_H3 -- 504 f16/bf16 MFMAs (16.1 k matrix-pipe cycles) per tile instead of 600 fp32 + 288 bf16 (46 k).
+template <bool T, bool H, bool X3, bool FRAG, bool TRACE = false, bool HX = false>
 __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs a) {
+    static_assert(!HX || (FRAG && (X3 || !H)), "H3 GEMMs read fragment streams");
     __shared__ __attribute__((aligned(16))) float Vs_all[LW_WAVES][32 * LW_VLD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -52,18 +55,24 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
     constexpr int NCH = num_chunks<T, H>();
     // weight ring: the fp32 chunks (2048 matrix-pipe cycles each) are fetched one chunk ahead in two buffers; the split
     // q|k|v chunks (384 cycles each, far less than an L2 round trip) NQB-1 chunks ahead in NQB buffers
-    constexpr int Q0 = (H && X3) ? (T ? 10 : 0) + 8 : NCH;           // first split q|k|v chunk
-    constexpr int NQB = (H && X3) ? (FRAG ? LW_QKV_BUFS : LW_QKV_BUFS - 1) : 2;     // (natural layout: more address registers)
+    // (HX: every chunk is 12 short MFMAs, so the deep ring serves all of them)
+    constexpr int Q0 = HX ? 0 : (H && X3) ? (T ? 10 : 0) + 8 : NCH;  // first chunk on the deep ring
+    constexpr int NQB = HX ? LW_H3_BUFS : (H && X3) ? (FRAG ? LW_QKV_BUFS : LW_QKV_BUFS - 1) : 2;     // (natural layout: more address registers)
     WChunk w[NQB];
     auto buf_of = [](int i) constexpr { return i < Q0 ? (i & 1) : (i - Q0) % NQB; };
     load_chunk<T, X3, FRAG>(w[0], a, 0, lane);
 
     f32x4 x0[16], x1[8], x2[8], y3[16], x4[16];
     bf16x8 xh[8], xl[8];
+    u32x4 a0h[8], a0l[8], a1h[4], a1l[4], a2h[4], a2l[4], ayh[8], ayl[8];     // HX: B operands of fc1 / fc2 / fc3 / PointCN
     if (T) {
         if (a.msg) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) x0[q] = *reinterpret_cast<const f32x4*>(a.msg + row * PDSC_CHANNELS + 8 * q + 4 * h);
+            if constexpr (HX) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) make_kstep<true>(x0[2 * kk], x0[2 * kk + 1], a0h[kk], a0l[kk]);
+            }
         } else {
             // merge of the attention's key-split partials, the arithmetic of merge_partials_finish (merge_partials.h)
             auto run = [&](auto ns_tag) {
@@ -108,6 +117,10 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
                             asm volatile("" : "+v"(x0[q0 + q][e]));     // materialise here (else the compiler sinks the arithmetic
                         }                                               // to the first MFMA and keeps every batch of loads live)
                     }
+                    if constexpr (HX) {
+#pragma unroll
+                        for (int kk = q0 / 2; kk < (q0 + GQ) / 2; ++kk) make_kstep<true>(x0[2 * kk], x0[2 * kk + 1], a0h[kk], a0l[kk]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);               // keep the next batch's loads behind this batch's use
                 }
             };
@@ -121,11 +134,15 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) y3[q] = *reinterpret_cast<const f32x4*>(a.feat_in + row * PDSC_CHANNELS + 8 * q + 4 * h);
+        if constexpr (HX) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) make_kstep<true>(y3[2 * kk], y3[2 * kk + 1], ayh[kk], ayl[kk]);
+        }
     }
     LW_STAMP(1)
 
     unsigned char* img = (H && a.kv) ? a.kv + (size_t)gw * SPL_TILE_BYTES : nullptr;
-    f32x16 acc;
+    f32x16 acc, cross;
 
     static_for<0, NCH>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -153,7 +170,11 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.bias, 1.0f, zero, 0, 0, 0);
         }
-        if constexpr (d.stage == ST_FC1) mma_f32(acc, wc, x0 + 8 * d.chunk);
+        if constexpr (HX && d.stage == ST_FC1) mma_h3(acc, cross, wc, a0h + 4 * d.chunk, a0l + 4 * d.chunk, d.chunk == 0);
+        else if constexpr (HX && d.stage == ST_FC2) mma_h3(acc, cross, wc, a1h, a1l, true);
+        else if constexpr (HX && d.stage == ST_FC3) mma_h3(acc, cross, wc, a2h, a2l, true);
+        else if constexpr (HX && d.stage == ST_PCN) mma_h3(acc, cross, wc, ayh + 4 * d.chunk, ayl + 4 * d.chunk, d.chunk == 0);
+        else if constexpr (d.stage == ST_FC1) mma_f32(acc, wc, x0 + 8 * d.chunk);
         else if constexpr (d.stage == ST_FC2) mma_f32(acc, wc, x1);
         else if constexpr (d.stage == ST_FC3) mma_f32(acc, wc, x2);
         else if constexpr (d.stage == ST_PCN) mma_f32(acc, wc, y3 + 8 * d.chunk);
@@ -166,8 +187,17 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[g][e] = acc[4 * g + e];
-            if constexpr (d.stage == ST_FC1 || d.stage == ST_FC2) {
+                for (int e = 0; e < 4; ++e) v[g][e] = (HX && d.stage != ST_QKV) ? fmaf(cross[4 * g + e], H3_INV, acc[4 * g + e]) : acc[4 * g + e];
+            if constexpr (HX && (d.stage == ST_FC1 || d.stage == ST_FC2)) {
+                // relu, then straight into the next GEMM's k-steps 2*tile, 2*tile + 1 (this tile's 32 channels)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    make_kstep<true>(v[2 * j], v[2 * j + 1], (d.stage == ST_FC1 ? a1h : a2h)[2 * d.tile + j], (d.stage == ST_FC1 ? a1l : a2l)[2 * d.tile + j]);
+            } else if constexpr (d.stage == ST_FC1 || d.stage == ST_FC2) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -179,6 +209,11 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
                     for (int e = 0; e < 4; ++e) y3[4 * d.tile + g][e] = y3[4 * d.tile + g][e] + v[g][e];
                     if (a.feat_out && live)
                         *reinterpret_cast<f32x4*>(a.feat_out + row * PDSC_CHANNELS + n0 + 8 * g + 4 * h) = y3[4 * d.tile + g];
+                }
+                if constexpr (HX && H) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        make_kstep<true>(y3[4 * d.tile + 2 * j], y3[4 * d.tile + 2 * j + 1], ayh[2 * d.tile + j], ayl[2 * d.tile + j]);
                 }
             } else if constexpr (d.stage == ST_PCN) {
 #pragma unroll
@@ -303,10 +338,22 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
 
 // ---- fragment-ordered weight streams -------------------------------------------------------------------------------
 // element (chunk c, slot s, lane l = (l31, h), e) of a stream <- the weight the natural-layout load_chunk puts there
+// H3 slot (layer_wave.h): 8 consecutive input channels of one weight row as fp16 hi (part 0) or scaled lo' (part 1)
+__device__ __forceinline__ u32x4 wfrag_h3_slot(const float* __restrict__ src, int part) {
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hi, lo;
+        split2h(src[2 * e], src[2 * e + 1], hi, lo);
+        w[e] = part ? lo : hi;
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
 __global__ __launch_bounds__(256) void wfrag_tail_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          const float* __restrict__ w3, const float* __restrict__ b3,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, int fmt) {
     const int idx = blockIdx.x * 256 + threadIdx.x;                  // one float4 = (chunk, slot, lane)
     if (idx < LW_TAIL_TILES * 64) {                                  // bias fragments behind the chunks
         const int t = idx >> 6, lane = idx & 63;
@@ -318,12 +365,15 @@ __global__ __launch_bounds__(256) void wfrag_tail_kernel(const float* __restrict
     const ChunkDesc d = chunk_desc<true>(c);
     const int n = 32 * d.tile + l31;
     const float* src = d.stage == ST_FC1 ? w1 + (size_t)n * 128 + 64 * d.chunk : d.stage == ST_FC2 ? w2 + (size_t)n * 64 : w3 + (size_t)n * 64;
-    *reinterpret_cast<f32x4*>(out + (size_t)idx * 4) = *reinterpret_cast<const f32x4*>(src + 8 * s + 4 * h);
+    if (fmt == PDSC_LAYER_GEMM_H3)      // slot 2k = hi, 2k+1 = lo' of the chunk's k-step k: channels 16k + 8h .. +7
+        *reinterpret_cast<u32x4*>(out + (size_t)idx * 4) = wfrag_h3_slot(src + 16 * (s >> 1) + 8 * h, s & 1);
+    else
+        *reinterpret_cast<f32x4*>(out + (size_t)idx * 4) = *reinterpret_cast<const f32x4*>(src + 8 * s + 4 * h);
 }
 
 __global__ __launch_bounds__(256) void wfrag_head_kernel(const float* __restrict__ wp, const float* __restrict__ bp,
                                                          const float* __restrict__ wq, const float* __restrict__ bq,
-                                                         unsigned char* __restrict__ out) {
+                                                         unsigned char* __restrict__ out, int fmt) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < LW_HEAD_TILES * 64) {
         const int t = idx >> 6, lane = idx & 63;
@@ -334,7 +384,9 @@ __global__ __launch_bounds__(256) void wfrag_head_kernel(const float* __restrict
     const int c = idx >> 9, s = (idx >> 6) & 7, lane = idx & 63, l31 = lane & 31, h = lane >> 5;
     const ChunkDesc d = chunk_desc<false>(c);
     const int n = 32 * d.tile + l31;
-    if (d.stage == ST_PCN) {
+    if (d.stage == ST_PCN && fmt == PDSC_LAYER_GEMM_H3) {
+        *reinterpret_cast<u32x4*>(out + (size_t)idx * 16) = wfrag_h3_slot(wp + (size_t)n * 128 + 64 * d.chunk + 16 * (s >> 1) + 8 * h, s & 1);
+    } else if (d.stage == ST_PCN) {
         *reinterpret_cast<f32x4*>(out + (size_t)idx * 16) = *reinterpret_cast<const f32x4*>(wp + (size_t)n * 128 + 64 * d.chunk + 8 * s + 4 * h);
     } else {                                                         // slot 2k = hi, 2k+1 = lo of bf16 k-step 4*chunk + k
         const float* src = wq + (size_t)n * 128 + 64 * d.chunk + 16 * (s >> 1) + 8 * h;
@@ -354,18 +406,23 @@ int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st) 
     const dim3 grid(ceil_div(waves, LW_WAVES)), block(64 * LW_WAVES);
     const bool frag = (!tail || a.wf_tail) && (!head || a.wf_head);
     const bool x3 = head && (a.wq_split || frag);
+    const bool h3 = frag && a.gemm_format == PDSC_LAYER_GEMM_H3;
     if (tail && head) {
         profile_mark_begin(PDSC_PROF_LAYER, st);
-        if (frag && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true>), grid, block, 0, st, a);
+        if (h3 && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true, true>), grid, block, 0, st, a);
+        else if (h3) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, false, true>), grid, block, 0, st, a);
+        else if (frag && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true>), grid, block, 0, st, a);
         else if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true>), grid, block, 0, st, a);
         else if (x3) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<true, true, false, false>), grid, block, 0, st, a);
         profile_mark_end(PDSC_PROF_LAYER, st);
     } else if (tail) {
-        if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true>), grid, block, 0, st, a);
+        if (h3) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true, false, true>), grid, block, 0, st, a);
+        else if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<true, false, false, false>), grid, block, 0, st, a);
     } else {
-        if (frag) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true>), grid, block, 0, st, a);
+        if (h3) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true, false, true>), grid, block, 0, st, a);
+        else if (frag) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true>), grid, block, 0, st, a);
         else if (x3) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<false, true, false, false>), grid, block, 0, st, a);
     }
@@ -379,27 +436,40 @@ using namespace pdsc;
 extern "C" size_t pdsc_wfrag_tail_bytes(void) { return (size_t)LW_TAIL_CHUNKS * LW_CHUNK_BYTES + LW_TAIL_TILES * 256; }
 extern "C" size_t pdsc_wfrag_head_bytes(void) { return (size_t)LW_HEAD_CHUNKS * LW_CHUNK_BYTES + LW_HEAD_TILES * 256; }
 
-extern "C" int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
-                                     const float* b3, void* out, void* stream) {
+extern "C" int pdsc_wfrag_build_tail_fmt(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                         const float* b3, void* out, int gemm_format, void* stream) {
     PDSC_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && out, "pdsc_wfrag_build_tail: null pointer");
+    PDSC_REQUIRE(gemm_format == PDSC_LAYER_GEMM_F32 || gemm_format == PDSC_LAYER_GEMM_H3, "pdsc_wfrag_build_tail: gemm_format=%d", gemm_format);
     hipLaunchKernelGGL(wfrag_tail_kernel, dim3(LW_TAIL_CHUNKS * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3,
-                       (float*)out);
+                       (float*)out, gemm_format);
     return check_launch("pdsc_wfrag_build_tail");
 }
 
-extern "C" int pdsc_wfrag_build_head(const float* wp, const float* bp, const float* wq, const float* bq, void* out, void* stream) {
+extern "C" int pdsc_wfrag_build_head_fmt(const float* wp, const float* bp, const float* wq, const float* bq, void* out,
+                                         int gemm_format, void* stream) {
     PDSC_REQUIRE(wp && bp && wq && bq && out, "pdsc_wfrag_build_head: null pointer");
+    PDSC_REQUIRE(gemm_format == PDSC_LAYER_GEMM_F32 || gemm_format == PDSC_LAYER_GEMM_H3, "pdsc_wfrag_build_head: gemm_format=%d", gemm_format);
     hipLaunchKernelGGL(wfrag_head_kernel, dim3(LW_HEAD_CHUNKS * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream, wp, bp, wq, bq,
-                       (unsigned char*)out);
+                       (unsigned char*)out, gemm_format);
     return check_launch("pdsc_wfrag_build_head");
+}
+
+extern "C" int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                     const float* b3, void* out, void* stream) {
+    return pdsc_wfrag_build_tail_fmt(w1, b1, w2, b2, w3, b3, out, PDSC_LAYER_GEMM_F32, stream);
+}
+
+extern "C" int pdsc_wfrag_build_head(const float* wp, const float* bp, const float* wq, const float* bq, void* out, void* stream) {
+    return pdsc_wfrag_build_head_fmt(wp, bp, wq, bq, out, PDSC_LAYER_GEMM_F32, stream);
 }
 
 extern long long* pdsc_layer_trace_buffer(void);
 
-extern "C" int pdsc_layer_fused_frag(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
-                                     const float* res, const float* feat_in, float* feat_out, float* featB_out,
-                                     float* qkv_out, void* q_split, void* kv_tiles, const void* wfrag_tail,
-                                     const void* wfrag_head, int bs, int N, void* stream) {
+extern "C" int pdsc_layer_fused_frag_fmt(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                                         const float* res, const float* feat_in, float* feat_out, float* featB_out,
+                                         float* qkv_out, void* q_split, void* kv_tiles, const void* wfrag_tail,
+                                         const void* wfrag_head, int gemm_format, int bs, int N, void* stream) {
+    PDSC_REQUIRE(gemm_format == PDSC_LAYER_GEMM_F32 || gemm_format == PDSC_LAYER_GEMM_H3, "pdsc_layer_fused_frag: gemm_format=%d", gemm_format);
     const bool tail = msg != nullptr || part_o != nullptr, head = featB_out != nullptr;
     PDSC_REQUIRE(tail || head, "pdsc_layer_fused_frag: neither tail (msg / partials) nor head (featB_out) requested");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused_frag: bs=%d N=%d", bs, N);
@@ -417,6 +487,20 @@ extern "C" int pdsc_layer_fused_frag(const float* msg, const float* part_o, cons
     a.qs = (__bf16*)q_split; a.kv = (unsigned char*)kv_tiles;
     a.N = N; a.bs = bs;
     a.wf_tail = (const unsigned char*)wfrag_tail; a.wf_head = (const unsigned char*)wfrag_head;
+    a.gemm_format = gemm_format;
+    a.stagger_cycles = env_int("PDSC_LAYER_STAGGER", 0);
+    a.stagger_mode = env_int("PDSC_LAYER_STAGGER_MODE", 1);
     a.trace = pdsc_layer_trace_buffer();
+    // H3: the pipelined kernel of layer_h3.hip; A/B knob PDSC_LAYER_H3_VARIANT = 0: this file's kernel with the H3 GEMMs
+    if (gemm_format == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0 && launch_layer_h3_fits(a, tail, head))
+        return launch_layer_h3(a, tail, head, (hipStream_t)stream);
     return launch_layer_wave(a, tail, head, (hipStream_t)stream);
+}
+
+extern "C" int pdsc_layer_fused_frag(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
+                                     const float* res, const float* feat_in, float* feat_out, float* featB_out,
+                                     float* qkv_out, void* q_split, void* kv_tiles, const void* wfrag_tail,
+                                     const void* wfrag_head, int bs, int N, void* stream) {
+    return pdsc_layer_fused_frag_fmt(msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, q_split, kv_tiles,
+                                     wfrag_tail, wfrag_head, PDSC_LAYER_GEMM_F32, bs, N, stream);
 }

@@ -55,4 +55,14 @@ __device__ __forceinline__ void spl_zero_pads(unsigned char* __restrict__ img, i
 
 static inline int spl_num_tiles(int N) { return ceil_div(N, SPL_BK); }
 
+// ---- point-fragment order (PF) of a [rows][128] fp32 matrix -----------------------------------------------------------
+// Hand-off format between kernels whose lanes ARE points (the attention's accumulators -> the fused layer kernel's MFMA
+// operands -> the next layer kernel's residual).  Rows are taken in tiles of 32; a tile is 16 KiB (as in row order) laid
+// out as [q = 0..15][lane = 0..63][4 floats]: lane (l31 = lane & 31, h = lane >> 5) holds channels 8q + 4h .. + 3 of row
+// l31 of the tile.  One wave instruction (q fixed) moves 1 KiB of consecutive memory -- in row order the same instruction
+// touches 32 different cache lines for 32 bytes each.  Buffers are padded to whole tiles per pair; padding rows hold
+// copies of the pair's last row.
+__host__ __device__ __forceinline__ int pf_offset_floats(int q) { return q * 256; }     // + lane * 4 from the tile base
+constexpr int PF_TILE_FLOATS = 32 * PDSC_CHANNELS;
+
 }  // namespace pdsc

@@ -32,6 +32,8 @@ _NUM_CHANNELS = 128
 ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1, "bf16x3_all": 2}
 # enum pdsc_compat_format
 COMPAT_FORMATS = {"f32": 0, "u16": 1}
+# enum pdsc_layer_gemm
+LAYER_GEMMS = {"f32": 0, "h3": 1}
 
 
 def _conv(cin: int, cout: int) -> nn.Conv1d:
@@ -120,6 +122,11 @@ class PointDSC(nn.Module):
         # path as with "f32" (2e-6) -- opt-in because any change of round-off can move a near-tie among the seed
         # hypotheses (DESIGN.md "hard thresholds") and the committed reference goldens are met with more margin by "f32"
         self.compat_format = os.environ.get("POINTDSC_COMPAT_FORMAT", "f32")
+        # arithmetic of the fc_message / PointCN GEMMs in the fused layer kernel (enum pdsc_layer_gemm): "h3" = fp16 hi /
+        # scaled-lo split on the f16 matrix cores (default: ~2^-21 per product, measured closer to the fp64 chain than the
+        # fp32 MFMA's own round-off; with it the attention -> layer -> layer hand-offs go in point-fragment order);
+        # "f32" = v_mfma_f32_32x32x2_f32
+        self.layer_gemm = os.environ.get("POINTDSC_LAYER_GEMM", "h3")
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
@@ -133,9 +140,12 @@ class PointDSC(nn.Module):
             raise ValueError(f"attention_precision must be one of {sorted(ATTENTION_PRECISIONS)}, got {self.attention_precision!r}")
         if self.compat_format not in COMPAT_FORMATS:
             raise ValueError(f"compat_format must be one of {sorted(COMPAT_FORMATS)}, got {self.compat_format!r}")
+        if self.layer_gemm not in LAYER_GEMMS:
+            raise ValueError(f"layer_gemm must be one of {sorted(LAYER_GEMMS)}, got {self.layer_gemm!r}")
         return _lib.PdscConfig(self.in_dim, self.num_layers, self.num_channels, self.num_iterations, self.k, 20,
                                float(self.inlier_threshold), float(self.nms_radius), float(refine_thr),
-                               ATTENTION_PRECISIONS[self.attention_precision], COMPAT_FORMATS[self.compat_format])
+                               ATTENTION_PRECISIONS[self.attention_precision], COMPAT_FORMATS[self.compat_format],
+                               LAYER_GEMMS[self.layer_gemm])
 
     # The packed buffer is rebuilt after anything that can change weights through the nn.Module API
     # (load_state_dict, .to()/.cuda()/.float(), train()); after editing parameters in place call

@@ -165,9 +165,10 @@ def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
 
 @_on_device
 def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: torch.Tensor, bs: int, n: int,
-                       nsplit: int = 0, merge: bool = True):
+                       nsplit: int = 0, merge: bool = True, layout: str = "rows"):
     """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128].
-    merge=False (needs a key split > 1): returns (scratch, nsplit) with the un-merged partials for layer_fused_x3."""
+    merge=False (needs a key split > 1): returns (scratch, nsplit) with the un-merged partials for layer_fused_x3;
+    layout="pf": those partials in point-fragment order (csrc/split_layout.h) for layer_fused_io."""
     lib = _lib.load()
     c16 = compat.dtype == torch.int16                  # unorm16 matrix of spatial_compat_u16
     compat = _chk(compat, "compat", torch.int16 if c16 else torch.float32)
@@ -177,50 +178,66 @@ def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: to
     msg = torch.empty(bs * n, 128, device=compat.device, dtype=torch.float32) if merge else None
     nb = int(lib.pdsc_attention_split_scratch_bytes(bs, n, nsplit))
     scratch = torch.empty(max(nb, 16), device=compat.device, dtype=torch.uint8)
+    if layout == "pf":       # un-merged partials in point-fragment order (enum pdsc_partial_layout)
+        assert not merge, "point-fragment partials are merged by the fused layer kernel"
+        _lib.check(lib.pdsc_sc_attention_split_partials(_p(qs), _p(kv), _p(compat), 1 if c16 else 0, compat.shape[-1], _p(scratch), nb,
+                                                        bs, n, nsplit, 1, _stream()), "pdsc_sc_attention_split_partials")
+        return scratch, nsplit
     fn = lib.pdsc_sc_attention_split_u16 if c16 else lib.pdsc_sc_attention_split
     _lib.check(fn(_p(qs), _p(kv), _p(compat), compat.shape[-1], _p(msg), _p(scratch), nb, bs, n, nsplit, _stream()),
                "pdsc_sc_attention_split")
     return msg if merge else (scratch, nsplit)
 
 
+LAYER_GEMMS = {"f32": 0, "h3": 1}      # enum pdsc_layer_gemm
+
+
 @_on_device
-def frag_weights_tail(tail_w) -> torch.Tensor:
-    """(fc1 w, b, fc2 w, b, fc3 w, b) fp32 [out][in] -> the fragment-ordered tail stream of pdsc_layer_fused_frag."""
+def frag_weights_tail(tail_w, gemm: str = "f32") -> torch.Tensor:
+    """(fc1 w, b, fc2 w, b, fc3 w, b) fp32 [out][in] -> the fragment-ordered tail stream of pdsc_layer_fused_frag(_fmt);
+    gemm = "h3": the chunks as fp16 hi / scaled-lo pairs (enum pdsc_layer_gemm)."""
     lib = _lib.load()
     out = torch.empty(int(lib.pdsc_wfrag_tail_bytes()), dtype=torch.uint8, device=tail_w[0].device)
-    _lib.check(lib.pdsc_wfrag_build_tail(*[_p(_chk(w, "tail_w")) for w in tail_w], _p(out), _stream()), "pdsc_wfrag_build_tail")
+    _lib.check(lib.pdsc_wfrag_build_tail_fmt(*[_p(_chk(w, "tail_w")) for w in tail_w], _p(out), LAYER_GEMMS[gemm], _stream()),
+               "pdsc_wfrag_build_tail_fmt")
     return out
 
 
 @_on_device
-def frag_weights_head(head_w) -> torch.Tensor:
-    """(pcn w, b, qkv w, b): pcn kept fp32, q|k|v -> bf16 hi / lo, biases as one more k-step -> the head stream."""
+def frag_weights_head(head_w, gemm: str = "f32") -> torch.Tensor:
+    """(pcn w, b, qkv w, b): pcn kept fp32 (gemm "f32") or fp16 hi / scaled lo ("h3"), q|k|v -> bf16 hi / lo, biases as
+    one more k-step -> the head stream."""
     lib = _lib.load()
     out = torch.empty(int(lib.pdsc_wfrag_head_bytes()), dtype=torch.uint8, device=head_w[0].device)
-    _lib.check(lib.pdsc_wfrag_build_head(*[_p(_chk(w, "head_w")) for w in head_w], _p(out), _stream()), "pdsc_wfrag_build_head")
+    _lib.check(lib.pdsc_wfrag_build_head_fmt(*[_p(_chk(w, "head_w")) for w in head_w], _p(out), LAYER_GEMMS[gemm], _stream()),
+               "pdsc_wfrag_build_head_fmt")
     return out
 
 
 @_on_device
 def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_qkv: bool = False, partials=None,
-                      qkv_split: bool = False, frag: bool = False):
+                      qkv_split: bool = False, frag: bool = False, gemm: str = "f32", want_feat: bool = True):
     """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
     partials = (scratch, nsplit) from sc_attention_split(..., merge=False) replaces msg.
     qkv_split: run the q|k|v projection in split precision (bf16 hi/lo weights).
     frag: go through pdsc_layer_fused_frag (weights as fragment-ordered streams; implies qkv_split) -- the entry the
-    forward uses.
-    Returns (feat or None, featB, qkv or None, q_split, kv_tiles)."""
+    forward uses; gemm = "h3" (frag only): fc1..fc3 / PointCN in the fp16 hi / scaled-lo arithmetic.
+    want_feat = False: no feat output (what the forward asks of every layer but the last); head_w = None (frag only):
+    tail only (the forward's last layer).
+    Returns (feat or None, featB or None, qkv or None, q_split or None, kv_tiles or None)."""
     lib = _lib.load()
     src = res if res is not None else feat_in
     m, dev = src.shape[0], src.device
     assert m == bs * n
     tail = [_chk(w, "tail_w") for w in tail_w] if tail_w is not None else [None] * 6
-    head = [_chk(w, "head_w") for w in head_w]
-    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if tail_w is not None else None
-    featB = torch.empty(m, 128, device=dev, dtype=torch.float32)
-    qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if want_qkv else None
-    qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8)
-    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8)
+    has_head = head_w is not None
+    assert has_head or frag, "tail-only launches exist on fragment streams only"
+    head = [_chk(w, "head_w") for w in head_w] if has_head else [None] * 4
+    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if tail_w is not None and (want_feat or not has_head) else None
+    featB = torch.empty(m, 128, device=dev, dtype=torch.float32) if has_head else None
+    qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if want_qkv and has_head else None
+    qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
     part_o = part_ml = None
     nsplit = npad = 0
     if partials is not None:
@@ -232,15 +249,71 @@ def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_q
             _p(_chk(res, "res")) if res is not None else None,
             _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB), _p(qkv), _p(qs), _p(kv)]
     if frag:
-        wf_tail = frag_weights_tail(tail) if tail_w is not None else None
-        wf_head = frag_weights_head(head)
+        wf_tail = frag_weights_tail(tail, gemm) if tail_w is not None else None
+        wf_head = frag_weights_head(head, gemm) if has_head else None
         args += [_p(wf_tail), _p(wf_head)]
-        _lib.check(lib.pdsc_layer_fused_frag(*args, bs, n, _stream()), "pdsc_layer_fused_frag")
+        _lib.check(lib.pdsc_layer_fused_frag_fmt(*args, LAYER_GEMMS[gemm], bs, n, _stream()), "pdsc_layer_fused_frag_fmt")
         return feat, featB, qkv, qs, kv
+    assert gemm == "f32", "the H3 arithmetic exists on fragment streams only"
     args += [_p(w) for w in tail] + [_p(w) for w in head]
     wqs = split_weight(head[2]) if qkv_split else None
     _lib.check(lib.pdsc_layer_fused_split(*args, _p(wqs), bs, n, _stream()), "pdsc_layer_fused_split")
     return feat, featB, qkv, qs, kv
+
+
+PF_PARTIALS, PF_RES, PF_FEATB = 1, 2, 4      # enum pdsc_layer_io
+
+
+def pf_rows(n: int) -> int:
+    """rows per pair of a point-fragment buffer: whole tiles of 32."""
+    return (n + 31) // 32 * 32
+
+
+def rows_to_pf(x: torch.Tensor, bs: int, n: int) -> torch.Tensor:
+    """[bs*n,128] rows -> point-fragment order [bs * pf_rows(n) * 128] (padding rows = copies of the pair's last row)."""
+    t = pf_rows(n) // 32
+    x = x.reshape(bs, n, 128)
+    x = torch.cat([x, x[:, -1:].expand(bs, t * 32 - n, 128)], dim=1)            # [bs, t*32, 128]
+    x = x.reshape(bs, t, 32, 16, 2, 4)                                          # [b, tile, l31, q, h, e]
+    return x.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)                 # [b, tile, q, h, l31, e]: lane = 32 h + l31
+
+
+def pf_to_rows(x: torch.Tensor, bs: int, rows_per_pair: int) -> torch.Tensor:
+    """point-fragment buffer with rows_per_pair (multiple of 32) rows per pair -> [bs, rows_per_pair, 128]."""
+    t = rows_per_pair // 32
+    x = x.reshape(bs, t, 16, 2, 32, 4)
+    return x.permute(0, 1, 4, 2, 3, 5).contiguous().reshape(bs, rows_per_pair, 128)
+
+
+@_on_device
+def layer_fused_io(res, feat_in, tail_w, head_w, bs: int, n: int, io_flags: int, partials=None):
+    """pdsc_layer_fused_frag_io (H3 GEMMs, the forward's output set, hand-offs in point-fragment order per io_flags):
+    partials = (scratch, nsplit) of sc_attention_split(merge=False, layout "pf" if io_flags & PF_PARTIALS);
+    res in PF order if io_flags & PF_RES; featB comes back in PF order if io_flags & PF_FEATB.
+    tail_w None = head only (feat_in rows), head_w None = tail only.  Returns (feat or None, featB or None, q_split, kv_tiles)."""
+    lib = _lib.load()
+    dev = (res if res is not None else feat_in).device
+    m = bs * n
+    has_tail, has_head = tail_w is not None, head_w is not None
+    feat = torch.empty(m, 128, device=dev, dtype=torch.float32) if has_tail and not has_head else None
+    fb_rows = bs * pf_rows(n) if io_flags & PF_FEATB else m
+    featB = torch.empty(fb_rows * 128, device=dev, dtype=torch.float32) if has_head else None
+    qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    part_o = part_ml = None
+    nsplit = npad = 0
+    if partials is not None:
+        scratch, nsplit = partials
+        npad = (n + 255) // 256 * 256
+        part_o = C.c_void_p(scratch.data_ptr())
+        part_ml = C.c_void_p(scratch.data_ptr() + bs * nsplit * npad * 128 * 4)
+    wf_tail = frag_weights_tail([_chk(w, "tail_w") for w in tail_w], "h3") if has_tail else None
+    wf_head = frag_weights_head([_chk(w, "head_w") for w in head_w], "h3") if has_head else None
+    _lib.check(lib.pdsc_layer_fused_frag_io(None, part_o, part_ml, nsplit, npad, _p(res) if res is not None else None,
+                                            _p(_chk(feat_in, "feat_in")) if feat_in is not None else None, _p(feat), _p(featB),
+                                            _p(qs), _p(kv), _p(wf_tail), _p(wf_head), LAYER_GEMMS["h3"], io_flags, bs, n, _stream()),
+               "pdsc_layer_fused_frag_io")
+    return feat, featB, qs, kv
 
 
 def split_weight(w: torch.Tensor) -> torch.Tensor:

@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=5000)
     ap.add_argument("--bs", type=int, default=4)
+    ap.add_argument("--gemm", default="f32", help="f32 | h3 (enum pdsc_layer_gemm; fragment streams only)")
     args = ap.parse_args()
     lib = _lib.load()
     n, bs, dev = args.n, args.bs, "cuda:0"
@@ -33,7 +34,8 @@ def main():
     tail_w = [rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128)]
     head_w = [rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384)]
     frag = os.environ.get("PDSC_LAYER_FRAG", "1") != "0" and not os.environ.get("PDSC_LAYER_VARIANT", "w").startswith("b")
-    run = lambda: ops.layer_fused_split(None, res, None, tail_w, head_w, bs, n, partials=partials, qkv_split=True, frag=frag)  # noqa: E731
+    run = lambda: ops.layer_fused_split(None, res, None, tail_w, head_w, bs, n, partials=partials, qkv_split=True, frag=frag,  # noqa: E731
+                                        gemm=args.gemm if frag else "f32")
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -67,11 +69,18 @@ def main():
         print(f"{nwg} waves; kernel span {float(t[:, 63].max() - t0):.0f} clocks; start spread {float(t[:, 0].max() - t0):.0f}")
         print(f"wave lifetime mean {float(life.mean()):.0f}  min {float(life.min()):.0f}  max {float(life.max()):.0f}")
         names = ["input"] + ["fc1"] * 4 + ["fc2"] * 2 + ["fc3"] * 4 + ["pcn"] * 8 + ["qkv"] * 24
-        mma = [0] + [2048] * 18 + [384] * 24
+        mma = [0] + [384 if args.gemm == "h3" else 2048] * 18 + [384] * 24
         d = (t[:, 1:44] - t[:, 0:43])
+        # waves of the first round (resident from the start) vs the later ones (start when a slot frees up)
+        first = t[:, 0] < t0 + 2000
+        print(f"first-round waves {int(first.sum())}: lifetime mean {float(life[first].mean()):.0f};  later waves {int((~first).sum())}: "
+              f"lifetime mean {float(life[~first].mean()) if (~first).any() else 0:.0f}; last start {float(t[:, 0].max() - t0):.0f}")
         for k in range(43):
-            print(f"   {k:2d} {names[k]:6s} mean {float(d[:, k].mean()):7.0f}  min {float(d[:, k].min()):7.0f}  max {float(d[:, k].max()):7.0f}   (mfma {mma[k]})")
+            print(f"   {k:2d} {names[k]:6s} mean {float(d[:, k].mean()):7.0f}  min {float(d[:, k].min()):7.0f}  max {float(d[:, k].max()):7.0f}   "
+                  f"first-round mean {float(d[first, k].mean()):7.0f}   (mfma {mma[k]})")
         print(f"   tail (pads, drain)  mean {float((t[:, 63] - t[:, 43]).mean()):7.0f}")
+        grp = {"input": [0], "fc1": range(1, 5), "fc2": range(5, 7), "fc3": range(7, 11), "pcn": range(11, 19), "qkv": range(19, 43)}
+        print("   per stage (mean clocks per wave): " + "  ".join(f"{k} {float(d[:, list(v)].sum(1).mean()):.0f}" for k, v in grp.items()))
 
 if __name__ == "__main__":
     main()
