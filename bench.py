@@ -134,6 +134,10 @@ def parse():
     return ap.parse_args()
 
 
+def fp32_att(args):
+    return args.attention_precision == "fp32"
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -253,6 +257,13 @@ def main():
     lay_avg = lay_ms / max(lay_n, 1) * 1e-3
     lay_pipe_cycles = (600 * 64 + 288 * 32) * math.ceil(N / 32) * B / 1024.0      # per SIMD (256 CUs x 4)
     lay_ghz = lay_pipe_cycles / lay_avg / 1e9 if lay_n else None
+    # with the H3 GEMMs (model.layer_gemm = "h3", wavefront-resident kernel) the launch needs 16 k matrix-pipe cycles per tile
+    # and is bound by HBM: per point it reads the key-split partials (ns x (512 + 8) B) and the residual row (512 B) and
+    # writes featB (512 B), the Q rows (512 B) and its share of the K/V tile image (37 KiB / 32)
+    lay_h3 = (not fp32_att(args)) and model.layer_gemm == "h3" and not lib.pdsc_layer_prefers_block(B, N)
+    lay_ns = int(lib.pdsc_attention_split_default_split(B, N))
+    lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 37888 / 32.0) * N * B
+    lay_gbs = lay_bytes / lay_avg / 1e9 if lay_n else None
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
     att_avg = att_ms / max(att_n, 1) * 1e-3
     att_tflops = att_flops / att_avg / 1e12 if att_n else None
@@ -288,12 +299,17 @@ def main():
         "roofline": roof,
         # matrix-pipe issue cycles the launch needs per SIMD / its duration, against a pipe that is busy every cycle at
         # the maximum clock (the chip runs this kernel at 1.6-2.0 GHz: PMC summaries under profiles/)
-        "roofline_layer": {"kernel": "layer_wave_kernel" if not lib.pdsc_layer_prefers_block(B, N) else "layer_fused_kernel",
-                           "bound": "mfma", "achieved": None if lay_ghz is None else round(lay_ghz, 4), "peak": MAX_CLOCK_GHZ,
-                           "unit": "G matrix-pipe cycles/s per SIMD",
-                           "frac": None if lay_ghz is None else round(lay_ghz / MAX_CLOCK_GHZ, 4),
-                           "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
-                           "flops_per_launch": lay_flops},
+        "roofline_layer": ({"kernel": "layer_h3_kernel", "bound": "hbm",
+                            "achieved": None if lay_gbs is None else round(lay_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": None if lay_gbs is None else round(lay_gbs / PEAK_HBM_GBS, 4),
+                            "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
+                            "bytes_per_launch": lay_bytes, "flops_per_launch": lay_flops} if lay_h3 else
+                           {"kernel": "layer_wave_kernel" if not lib.pdsc_layer_prefers_block(B, N) else "layer_fused_kernel",
+                            "bound": "mfma", "achieved": None if lay_ghz is None else round(lay_ghz, 4), "peak": MAX_CLOCK_GHZ,
+                            "unit": "G matrix-pipe cycles/s per SIMD",
+                            "frac": None if lay_ghz is None else round(lay_ghz / MAX_CLOCK_GHZ, 4),
+                            "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
+                            "flops_per_launch": lay_flops}),
         "roofline_compat": {"kernel": "compat_sym_kernel", "bound": "hbm",
                             "achieved": None if cmp_gbs is None else round(cmp_gbs, 1), "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": None if cmp_gbs is None else round(cmp_gbs / PEAK_HBM_GBS, 4),

@@ -682,7 +682,7 @@ def test_layer_gemm_h3_agrees_with_fp32_gemms_through_the_encoder(n, monkeypatch
         res = _forward(model, c["pair"])
         out[gemm] = (model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
                      model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
-    model.layer_gemm = "f32"
+    model.layer_gemm = LAYER_GEMM_DEFAULT
     scale = max(1.0, float(out["f32"][0].abs().max()))
     err = float((out["f32"][0] - out["h3"][0]).abs().max()) / scale
     print(f"feature difference h3 vs f32 GEMMs: {err:.2e}")
