@@ -23,7 +23,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the kernels spell out every fused multiply-add (fmaf) themselves, so the arithmetic
 # that decides thresholds is exactly what the source says (see DESIGN.md "numerics").
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function"] + os.environ.get("PDSC_HIPCC_EXTRA", "").split()     # e.g. -DPDSC_LAYER_DIAG (diagnostic kernels)
 
 
 def _hipcc() -> str:

@@ -33,8 +33,9 @@ constexpr int stage_tiles(int stage) { return stage == ST_FC1 || stage == ST_FC2
 // tail + head => feat_out NULL; tail only => feat_out given.  With that the chunk loop has no branch at all: every chunk is
 // one basic block the scheduler can interleave freely.  Anything else takes layer_wave.hip's kernel (same arithmetic).
 // PIPE: vector instructions the scheduler is asked to place after every MFMA of a chunk (sched_group_barrier; 0 = its own choice)
-// EXP (diagnostics, wrong results): knock-outs that tell which unit bounds the launch -- 1: weights loaded once,
-// 2: no global stores, 4: no partial / residual loads
+// EXP (diagnostics, wrong results; instantiated only with -DPDSC_LAYER_DIAG): knock-outs that tell which unit bounds the
+// launch -- 1: weights loaded once, 2: no global stores (8 / 16 / 32 / 64: no Q / K / V / featB stores), 4: no partial /
+// residual loads.  profiles/r02_j_layer_knockout*.txt: all three off = 30 us of 181; loads 69, stores 54, weights 21.
 // FB_PF: featB leaves in point-fragment order (split_layout.h) instead of rows
 template <bool T, bool H, bool TRACE = false, int PIPE = 6, int EXP = 0, bool FB_PF = false>
 __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a) {
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
                 for (int e = 0; e < 4; ++e) v[s][e] = fmaxf(v[s][e], 0.f);
                 if constexpr (FB_PF) {
                     // point-fragment order: this lane's registers are the next launch's residual registers (1 KiB per instruction)
-                    if constexpr (!(EXP & 2)) *reinterpret_cast<f32x4*>(a.featB_out + (size_t)gw * PF_TILE_FLOATS + pf_offset_floats(4 * d.tile + s) + lane * 4) = v[s];
+                    if constexpr (!(EXP & (2 | 64))) *reinterpret_cast<f32x4*>(a.featB_out + (size_t)gw * PF_TILE_FLOATS + pf_offset_floats(4 * d.tile + s) + lane * 4) = v[s];
                 } else
                     *reinterpret_cast<f32x4*>(patch + l31 * LW_PROW + 32 * s + 16 * h) = v[s];
             }
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
                         const int pt = 8 * (s - 4) + (lane >> 3), piece = lane & 7;
                         if constexpr (d.tile < 4) {      // Q rows: (hi[128] | lo[128]) bf16
                             __bf16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
-                            if constexpr (!(EXP & 2)) *reinterpret_cast<u32x4*>(dst) = ev;
+                            if constexpr (!(EXP & (2 | 8))) *reinterpret_cast<u32x4*>(dst) = ev;
                             else asm volatile("" :: "v"(ev), "v"(dst));
                         } else {                         // K image: 64-byte runs, chunks 4t..4t+3 of a key, hi plane then lo plane
-                            if constexpr (!(EXP & 2)) *reinterpret_cast<u32x4*>(img + ((piece >> 2) ? SPL_KL : SPL_KH) + spl_k_offset(pt, 4 * (d.tile - 4) + (piece & 3))) = ev;
+                            if constexpr (!(EXP & (2 | 16))) *reinterpret_cast<u32x4*>(img + ((piece >> 2) ? SPL_KL : SPL_KH) + spl_k_offset(pt, 4 * (d.tile - 4) + (piece & 3))) = ev;
                             else asm volatile("" :: "v"(ev));
                         }
                     }
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) split2(vt[e], vt[e + 1], chi[e / 2], clo[e / 2]);
                         const int off = spl_v_offset(32 * (d.tile - 8) + cl, jh);
-                        if constexpr (!(EXP & 2)) {
+                        if constexpr (!(EXP & (2 | 32))) {
                             *reinterpret_cast<u32x4*>(img + SPL_VH + off) = u32x4{chi[0], chi[1], chi[2], chi[3]};
                             *reinterpret_cast<u32x4*>(img + SPL_VL + off) = u32x4{clo[0], clo[1], clo[2], clo[3]};
                         } else asm volatile("" :: "v"(chi[0]), "v"(chi[1]), "v"(chi[2]), "v"(chi[3]), "v"(clo[0]), "v"(clo[1]), "v"(clo[2]), "v"(clo[3]), "v"(off));
@@ -365,6 +366,18 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     const bool fb_pf = a.io_flags & PDSC_IO_FEATB_PF;
     if (tail && head && fb_pf) {
         profile_mark_begin(PDSC_PROF_LAYER, st);
+#ifdef PDSC_LAYER_DIAG      // knock-out build (PDSC_HIPCC_EXTRA=-DPDSC_LAYER_DIAG python -m pointdsc_amd.build --force; tools/layer_bench.py)
+        const int ex = env_int("PDSC_LAYER_H3_EXP", 0);
+        if (ex == 1) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 1, true>), grid, block, 0, st, a);
+        else if (ex == 2) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 2, true>), grid, block, 0, st, a);
+        else if (ex == 4) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 4, true>), grid, block, 0, st, a);
+        else if (ex == 7) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 7, true>), grid, block, 0, st, a);
+        else if (ex == 8) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 8, true>), grid, block, 0, st, a);
+        else if (ex == 16) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 16, true>), grid, block, 0, st, a);
+        else if (ex == 32) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 32, true>), grid, block, 0, st, a);
+        else if (ex == 64) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 64, true>), grid, block, 0, st, a);
+        else
+#endif
         hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 0, true>), grid, block, 0, st, a);
         profile_mark_end(PDSC_PROF_LAYER, st);
     } else if (head && !tail && fb_pf) {
@@ -373,10 +386,6 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
         profile_mark_begin(PDSC_PROF_LAYER, st);
         if (a.trace) hipLaunchKernelGGL((layer_h3_kernel<true, true, true>), grid, block, 0, st, a);
         else if (env_int("PDSC_LAYER_H3_PIPE", 6) == 0) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 0>), grid, block, 0, st, a);   // A/B knob
-        else if (env_int("PDSC_LAYER_H3_EXP", 0) == 1) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 1>), grid, block, 0, st, a);
-        else if (env_int("PDSC_LAYER_H3_EXP", 0) == 2) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 2>), grid, block, 0, st, a);
-        else if (env_int("PDSC_LAYER_H3_EXP", 0) == 4) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 4>), grid, block, 0, st, a);
-        else if (env_int("PDSC_LAYER_H3_EXP", 0) == 7) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 7>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_h3_kernel<true, true>), grid, block, 0, st, a);
         profile_mark_end(PDSC_PROF_LAYER, st);
     } else if (tail) {

@@ -22,6 +22,7 @@ ap.add_argument("--bs", type=int, default=32)
 ap.add_argument("--variants", nargs="+", default=["PDSC_LAYER_GEMM=0", "PDSC_LAYER_GEMM=1"])
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--calls", type=int, default=20)
+ap.add_argument("--pf", action="store_true", help="hand-offs in point-fragment order (pdsc_layer_fused_frag_io, H3 only)")
 a = ap.parse_args()
 lib = _lib.load()
 n, bs, dev = a.n, a.bs, "cuda:0"
@@ -31,14 +32,16 @@ m = n * bs
 batch = synthetic.make_batch(bs, n, seed=1)
 compat = ops.spatial_compat(batch["src_keypts"].to(dev), batch["tgt_keypts"].to(dev), torch.tensor([0.1], device=dev))
 qs, kv = ops.pack_qkv_split(rnd(m, 384) * 0.3, bs, n)
-scratch, nsplit = ops.sc_attention_split(qs, kv, compat, bs, n, merge=False)
+scratch, nsplit = ops.sc_attention_split(qs, kv, compat, bs, n, merge=False, layout="pf" if a.pf else "rows")
 del compat
 npad = (n + 255) // 256 * 256
 res = rnd(m, 128)
 tail_w = [rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128)]
 head_w = [rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384)]
 streams = {g: (ops.frag_weights_tail(tail_w, g), ops.frag_weights_head(head_w, g)) for g in ("f32", "h3")}
-featB = torch.empty(m, 128, device=dev)
+featB = torch.empty(bs * ops.pf_rows(n), 128, device=dev)
+if a.pf:
+    res = ops.rows_to_pf(res, bs, n)
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 part_o = C.c_void_p(scratch.data_ptr())
 part_ml = C.c_void_p(scratch.data_ptr() + bs * nsplit * npad * 128 * 4)
@@ -48,6 +51,10 @@ stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def call():
     gemm = int(os.environ.get("PDSC_LAYER_GEMM", "0"))
     wt, wh = streams["h3" if gemm else "f32"]
+    if a.pf:
+        _lib.check(lib.pdsc_layer_fused_frag_io(None, part_o, part_ml, nsplit, npad, p(res), None, None, p(featB), p(qs), p(kv),
+                                                p(wt), p(wh), gemm, 7, bs, n, stream), "pdsc_layer_fused_frag_io")
+        return
     _lib.check(lib.pdsc_layer_fused_frag_fmt(None, part_o, part_ml, nsplit, npad, p(res), None, None, p(featB), None, p(qs), p(kv),
                                              p(wt), p(wh), gemm, bs, n, stream), "pdsc_layer_fused_frag_fmt")
 
