@@ -392,8 +392,12 @@ extern "C" int pdsc_layer_trace(long long* device_buffer) {       // diagnostics
 // Size rule, from the hipEvent-timed fused layer launch at N = 5000 (us, block / wave; tiles = pairs x 157): 2 pairs 37 / 55,
 // 3 pairs (471 tiles) 43 / 61, 4 pairs (628) 56 / 53, 6 pairs (942) 70 / 56, 8 pairs 93 / 94, 16 pairs 190 / 163,
 // 32 pairs 347 / 250.  Block up to two workgroups per CU.
+// r02, wavefront-resident kernel with the H3 GEMMs (layer_h3.hip; whole forward, ms per step, block / wave,
+// profiles/r02_j_ab_block_vs_h3.txt): N = 5000 x 1 pair (157 tiles) 1.200 / 1.235, 2 pairs (314) 1.708 / 1.664, 3 pairs (471)
+// 1.985 / 1.929; N = 10000 x 1 (313) 2.682 / 2.682; N = 1000 x 1 (32) 0.572 / 0.659, x 4 (128) 0.641 / 0.712: block while the
+// tiles leave CUs empty (about one workgroup per CU).
 extern "C" int pdsc_layer_prefers_block(int bs, int N) {
-    return (long long)bs * pdsc::ceil_div(N, pdsc::LF_ROWS) <= 2 * 256;
+    return (long long)bs * pdsc::ceil_div(N, pdsc::LF_ROWS) <= 288;
 }
 
 extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,

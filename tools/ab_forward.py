@@ -4,7 +4,8 @@ processes and boxes, so variants are compared as A B C A B C ... rounds of the s
 
     python tools/ab_forward.py --config n5000_b32 --variants f32 u16 f32+PDSC_ATT_WIDE=1 [--rounds 7] [--steps 25]
 
-A variant is `<compat_format>[+<ENV>=<value>...]`: model.compat_format and any per-call environment knob of the library.
+A variant is `<compat_format>[+<ENV>=<value>...][+@<attribute>=<value>...]`: model.compat_format, per-call environment knobs
+of the library, attributes of the module (attention_precision, layer_gemm).
 """
 import argparse
 import os
@@ -41,6 +42,9 @@ def apply(variant):
     env = {}
     for p in parts[1:]:
         k, v = p.split("=")
+        if k.startswith("@"):            # model attribute, e.g. @attention_precision=bf16x3_all, @layer_gemm=f32
+            setattr(model, k[1:], v)
+            continue
         env[k] = v
     os.environ.update(env)
     return env
