@@ -24,11 +24,14 @@ from pointdsc_amd import PointDSC, workloads  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--compat-format", default="f32")
 ap.add_argument("--json", action="store_true")
+ap.add_argument("--layer-gemm", default=None, help="f32 | h3 (default: the module's)")
+ap.add_argument("--batch", type=int, default=0, help="run the workload's pairs in consecutive batches of this size (0 = the global batch)")
+ap.add_argument("--only", default=None, help="one workload name")
 a = ap.parse_args()
 out = {}
 for name, w in workloads.WORKLOADS.items():
     fxp = ROOT / "tests" / "golden" / f"bench_{name}_all.npz"
-    if not fxp.exists():
+    if not fxp.exists() or (a.only and name != a.only):
         continue
     fx = np.load(fxp, allow_pickle=False)
     bs, n = w["global_batch"], w["num_corr"]
@@ -36,11 +39,19 @@ for name, w in workloads.WORKLOADS.items():
     model.load_state_dict(workloads.state_dict(name, model.state_dict()))
     model = model.eval().cuda()
     model.compat_format = a.compat_format
-    batch = workloads.batch(name, 0, bs)
-    data = {k: batch[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
-    data["testing"] = True
-    with torch.no_grad():
-        res = model(data)
+    if a.layer_gemm:
+        model.layer_gemm = a.layer_gemm
+    step = a.batch if 0 < a.batch < bs else bs
+    parts = {"final_trans": [], "final_labels": []}
+    for first in range(0, bs, step):
+        batch = workloads.batch(name, first, min(step, bs - first))
+        data = {k: batch[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+        data["testing"] = True
+        with torch.no_grad():
+            r = model(data)
+        for k in parts:
+            parts[k].append(r[k].cpu())
+    res = {k: torch.cat(v) for k, v in parts.items()}
     want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:, :n].astype(np.float32))
     dT = (res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().amax(dim=(1, 2)).numpy()
     flips = (res["final_labels"].cpu() != want_lab).sum(dim=1).numpy()
@@ -53,7 +64,7 @@ for name, w in workloads.WORKLOADS.items():
            "dT_sorted_top5": [float(x) for x in np.sort(dT)[::-1][:5]]}
     out[name] = rep
     if not a.json:
-        print(f"{name}: {bs} pairs, label flips {rep['label_flips_total']} (in {rep['pairs_with_label_flips']} pairs), "
+        print(f"{name} (batches of {step}, layer_gemm {model.layer_gemm}): {bs} pairs, label flips {rep['label_flips_total']} (in {rep['pairs_with_label_flips']} pairs), "
               f"max|dT| median {rep['median_dT']:.2e} max {rep['max_dT']:.2e}; >= 1e-4: {rep['pairs_dT_above_1e-4']} "
               f"(reference itself unstable on {rep['pairs_unstable_in_reference']}); top5 {['%.1e' % x for x in rep['dT_sorted_top5']]}")
 if a.json:
