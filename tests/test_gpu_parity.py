@@ -1111,6 +1111,33 @@ def test_bench_workload_census_every_pair_matches_the_reference(name, gemm):
     assert bool((dT < tol).all()), (dT.tolist(), fx["stable"].tolist())
 
 
+@pytest.mark.parametrize("fmt", ["f32", "u16"])
+@pytest.mark.parametrize("name,bs", [("n5000_b32", 4), ("kitti_n5000_b16", 3)])
+def test_forward_is_bit_identical_with_row_order_and_point_fragment_hand_offs(name, bs, fmt, monkeypatch):
+    """Whole forward, layer_gemm = "h3": partials / featB handed over in point-fragment order (default) vs plain rows
+    (PDSC_LAYER_PF=0) vs the generic H3 kernel (PDSC_LAYER_H3_VARIANT=0): same arithmetic in the same order, so poses and
+    labels agree bit for bit, with either storage format of the spatial-consistency matrix."""
+    model, _ = _bench_model(name)
+    batch = workloads.batch(name, 0, bs)
+    model.compat_format, model.layer_gemm = fmt, "h3"
+    out = []
+    try:
+        for env in ({}, {"PDSC_LAYER_PF": "0"}, {"PDSC_LAYER_H3_VARIANT": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            res = _forward(model, batch)
+            out.append((res["final_trans"].cpu().clone(), res["final_labels"].cpu().clone()))
+            for k in env:
+                monkeypatch.delenv(k)
+    finally:
+        model.compat_format, model.layer_gemm = "f32", LAYER_GEMM_DEFAULT
+    for T, L in out[1:]:
+        assert torch.equal(T, out[0][0]) and torch.equal(L, out[0][1])
+    for i in range(bs):
+        re, te = O.registration_errors(out[0][0][i], batch["gt_trans"][i])
+        assert re < 1.0 and te < (60.0 if "kitti" in name else 5.0), (i, re, te)
+
+
 def test_bench_timed_path_uses_the_wave_layer_kernel_and_fused_merge():
     """Guards the claim above: at the headline configuration the forward goes through layer_wave_kernel and merges the
     key-split partials inside it (csrc/api.hip:run_forward), i.e. the golden test at bs=32 covers those kernels."""
