@@ -26,6 +26,7 @@ struct AttSplitArgs {
     int N, Npad, nsplit, num_tiles, nq, bs;
     int prio_mode;               // A/B knob PDSC_ATT_PRIO: 1 = s_setprio 1 for the younger half of the waves, 2 = for the older half
     int compat_nt;               // A/B knob PDSC_ATT_COMPAT_NT: stream the compat slices with the non-temporal policy
+    int items;                   // persistent form: number of (pair, key split, query block) items (= the one-item form's grid)
     int part_frag;               // key-split partials in point-fragment order (split_layout.h: PF), straight from the accumulators
     long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
 };

@@ -74,9 +74,14 @@ constexpr int SPL_V_BYTES = 2 * 128 * SPL_V_STRIDE;   // Vh | Vl   20 KiB
 // CM (compat mode): 0 = fp32 matrix, slices staged in LDS by LDS-DMA (default);  1 = unorm16 matrix, staged in LDS (C16);
 // 2 = fp32 matrix, every lane loads the 16 values of its query straight into registers (CREG: no compat LDS stage -- 74 KiB
 // per workgroup, so two 4-wave workgroups fit a CU and one's prologue / epilogue overlaps the other's main loop).
-template <int NW, int CM = 0, bool TRACE = false>
+// PS (persistent): one workgroup per CU walks several (pair, key split, query block) items.  The loads that run ahead of an
+// item's last tiles fetch the NEXT item's first K / compat / V tiles (today they fetch tiles nobody reads), so the
+// prologue's HBM round trip and the first tile's wait (5 % of a workgroup's life, tools/attention_trace.py) sit behind the
+// previous item's last tiles.  Point-fragment partials only: that epilogue needs no LDS, the stages stay live across items.
+template <int NW, int CM = 0, bool TRACE = false, bool PS = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
     constexpr bool C16 = CM == 1, CREG = CM == 2;
+    static_assert(!PS || (!CREG && !TRACE), "the persistent form exists for the LDS-staged compat formats, untraced");
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = TRACE ? (long long)__builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -95,28 +100,49 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // a contiguous run of the (pair, split, query block) list, so that the workgroups streaming the same K/V tiles
     // -- same pair, same split -- sit on one or two XCDs instead of all eight.
     int qb, grp;
-    {
+    int item = 0, item_end = 0, item_step = 0;   // PS: this workgroup's items = item, item + item_step, ... < item_end
+    if constexpr (PS) {
+        // XCD x (= blockIdx.x & 7) owns the contiguous run [x * items / 8, (x + 1) * items / 8) of the item list (same pair,
+        // same split -> same L2, as in the one-item form); its workgroups take every (gridDim.x / 8)-th item of it
+        const int id = blockIdx.x, per_xcd = a.items >> 3;
+        item = (id & 7) * per_xcd + (id >> 3);
+        item_end = (id & 7) * per_xcd + per_xcd;
+        item_step = gridDim.x >> 3;
+        if (item >= item_end) return;
+        grp = item / a.nq;
+        qb = item % a.nq;
+    } else {
         const int id = blockIdx.x, W = gridDim.x;
         const int rank = (W & 7) == 0 ? (id & 7) * (W >> 3) + (id >> 3) : id;
         grp = rank / a.nq;
         qb = rank % a.nq;
     }
-    const int sp = grp % a.nsplit, b = grp / a.nsplit;
+    int sp = grp % a.nsplit, b = grp / a.nsplit;
 
     const int per = a.num_tiles / a.nsplit, rem = a.num_tiles % a.nsplit;
-    const int kt0 = sp * per + min(sp, rem);
-    const int kt1 = kt0 + per + (sp < rem ? 1 : 0);
+    int kt0 = sp * per + min(sp, rem);
+    int kt1 = kt0 + per + (sp < rem ? 1 : 0);
 
     // buffer descriptor of this pair's K/V tile stream (< 4 GiB)
-    const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.kv + (size_t)b * a.num_tiles * SPL_TILE_BYTES), 0, a.num_tiles * SPL_TILE_BYTES, 0x00020000);
-    // compat: the descriptor covers only this workgroup's query rows, so every offset fits 32 bits whatever N is
-    const int q_first = qb * (NW * 32);
-    const int q_rows = min(NW * 32, N - q_first);
     constexpr unsigned CEL = C16 ? 2u : 4u;      // bytes per compat element
-    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const unsigned char*)a.compat + ((size_t)b * N + q_first) * a.ld * CEL), 0,
-        (int)((unsigned)q_rows * (unsigned)a.ld * CEL), 0x00020000);
+    // (macros, not lambdas: with a lambda that returns a buffer resource hipcc 7.2's host pass silently drops every launch stub
+    //  of this template)
+#define PDSC_KV_RSRC(pair) \
+    __builtin_amdgcn_make_buffer_rsrc((void*)(a.kv + (size_t)(pair) * a.num_tiles * SPL_TILE_BYTES), 0, a.num_tiles * SPL_TILE_BYTES, 0x00020000)
+    // compat: the descriptor covers only this workgroup's query rows, so every offset fits 32 bits whatever N is
+#define PDSC_C_RSRC(pair, qblock)                                                                                                          \
+    __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.compat + ((size_t)(pair) * N + (qblock) * (NW * 32)) * a.ld * CEL), 0, \
+                                      (int)((unsigned)min(NW * 32, N - (qblock) * (NW * 32)) * (unsigned)a.ld * CEL), 0x00020000)
+    __amdgpu_buffer_rsrc_t kv_rsrc = PDSC_KV_RSRC(b);
+    const int q_first = qb * (NW * 32);
+    int q_rows = min(NW * 32, N - q_first);
+    __amdgpu_buffer_rsrc_t c_rsrc = PDSC_C_RSRC(b, qb);
+    // PS: kv_rsrc / c_rsrc address the K and compat tiles kt + dK, kv_v the V tile kt + dV of the run-ahead loads -- this
+    // item's streams (dK = 2, dV = 1) until its last two iterations, then the next item's (few scalar registers: with one
+    // descriptor set per item in flight the kernel spilled 49 of them into vector lanes, read back inside the tile loop)
+    __amdgpu_buffer_rsrc_t kv_v = kv_rsrc;
+    int dK = 2, dV = 1, kt0n = kt1, q_rows_n = q_rows, b_n = b, sp_n = sp, qb_n = qb, u0 = 0;
+    bool more = false;
     const unsigned lane16 = lane * 16;
     // (sized 4, not NCS: with a template-dependent bound hipcc 7.2's host pass silently drops the kernel's launch stub)
     unsigned coff[4] = {0u, 0u, 0u, 0u};         // byte offset of this lane's 16-B compat chunk per DMA piece, tile 0
@@ -127,19 +153,22 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         for (int g = 0; g < 4; ++g)
             dst[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rsrc, creg_off + 32u * g, kt * (SPL_BK * 4), 0));
     };
+    auto set_coff = [&](int rows) {
 #pragma unroll
-    for (int u = 0; u < NCS; ++u) {
-        if (C16) {
-            // a wave instruction = 16 rows x 64 B; LDS row = 4 chunks of 16 B, logical chunk c stored at c ^ ((row >> 2) & 3)
-            const int row = wave * 32 + 16 * u + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
-            coff[u] = (unsigned)min(row, q_rows - 1) * (unsigned)a.ld * 2u + 16u * c;
-        } else {
-            const int row = wave * 32 + 8 * u + (lane >> 3);             // row inside the workgroup's query block
-            const int c = (lane & 7) ^ ((row >> 1) & 7);                 // logical 16-B chunk (4 keys) this lane fetches
-            coff[u] = (unsigned)min(row, q_rows - 1) * (unsigned)a.ld * 4u + 16u * c;
+        for (int u = 0; u < NCS; ++u) {
+            if (C16) {
+                // a wave instruction = 16 rows x 64 B; LDS row = 4 chunks of 16 B, logical chunk c stored at c ^ ((row >> 2) & 3)
+                const int row = wave * 32 + 16 * u + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                coff[u] = (unsigned)min(row, rows - 1) * (unsigned)a.ld * 2u + 16u * c;
+            } else {
+                const int row = wave * 32 + 8 * u + (lane >> 3);             // row inside the workgroup's query block
+                const int c = (lane & 7) ^ ((row >> 1) & 7);                 // logical 16-B chunk (4 keys) this lane fetches
+                coff[u] = (unsigned)min(row, rows - 1) * (unsigned)a.ld * 4u + 16u * c;
+            }
         }
-    }
+    };
+    set_coff(q_rows);
     // DMA work of one wave for one loop iteration kt, as 9 slots that are issued BETWEEN the MFMA groups (an LDS-DMA
     // instruction costs its wave ~100 cycles of issue; bunched after the barrier that is ~1000 cycles per tile during
     // which neither wave of a SIMD feeds the matrix pipe):
@@ -153,13 +182,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             // the L2 to the K/V tiles the other workgroups of the XCD re-read: +1.6 % pairs/s; the unorm16 stream measured
             // faster without (tools/ab_forward.py, profiles/r02_c_ab_forward_compat_format_b32.txt)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lptr_t)(Cs + st * CSTAGE + (wave * NCS + slot) * 1024), 16, coff[slot],
-                                                     (kt + 2) * (SPL_BK * (int)CEL), 0, C16 ? 0 : 2);
+                                                     (PS ? kt + dK : kt + 2) * (SPL_BK * (int)CEL), 0, C16 ? 0 : 2);
         } else {
             const int i = min(wave + NW * (slot - NCS), PIECES - 1);    // surplus slots repeat the last piece
             const bool isk = i < KPIECES;                                // wave-uniform
             unsigned char* dst = isk ? Ks + st * SPL_K_BYTES + i * 1024 : Vs + (st ^ 1) * SPL_V_BYTES + (i - KPIECES) * 1024;
-            const int src = ((isk ? kt + 2 : kt + 1) * PIECES + i) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (lptr_t)dst, 16, lane16, src, 0, 0);
+            const int src = ((isk ? (PS ? kt + dK : kt + 2) : (PS ? kt + dV : kt + 1)) * PIECES + i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(PS ? (isk ? kv_rsrc : kv_v) : kv_rsrc, (lptr_t)dst, 16, lane16, src, 0, 0);
         }
     };
     constexpr int DMA_SLOTS = NCS + KV_SLOTS;    // fp32 compat: 9 (NW = 8) or 14 (NW = 4): 8 go after the QK steps, the rest after PV steps
@@ -180,16 +209,28 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     if (kt0 + 1 < kt1) { dma_k(kt0 + 1); dma_c(kt0 + 1); }
     if (CREG) creg_load(kt0 + 1, cnext);
     dma_v(kt0);
-    const int qrow = min(qb * (NW * 32) + wave * 32 + l31, N - 1);
     bf16x8 qh[8], ql[8];
-    {
-        const __bf16* qsrc = a.qs + ((size_t)b * N + qrow) * SPL_Q_LD + 8 * h;
+    auto load_q = [&](int pair, int qblock) {
+        const int qrow = min(qblock * (NW * 32) + wave * 32 + l31, N - 1);
+        const __bf16* qsrc = a.qs + ((size_t)pair * N + qrow) * SPL_Q_LD + 8 * h;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             qh[j] = *reinterpret_cast<const bf16x8*>(qsrc + 16 * j);
             ql[j] = *reinterpret_cast<const bf16x8*>(qsrc + PDSC_CHANNELS + 16 * j);
         }
-    }
+    };
+    load_q(b, qb);
+    // PS: look one item ahead (descriptors and first tile of the item the run-ahead loads of the last two tiles address)
+    auto look_ahead = [&]() {
+        more = item + item_step < item_end;
+        if (more) {
+            const int nx = item + item_step, g2 = nx / a.nq;
+            qb_n = nx % a.nq; sp_n = g2 % a.nsplit; b_n = g2 / a.nsplit;
+            kt0n = sp_n * per + min(sp_n, rem);
+            q_rows_n = min(NW * 32, N - qb_n * (NW * 32));
+        }             // (nothing follows: the run-ahead loads keep walking this item's streams -- bounds-checked, never read)
+    };
+    if constexpr (PS) look_ahead();
 
     f32x16 o[4];
 #pragma unroll
@@ -197,6 +238,27 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     float m_run = 0.f, l_run = 0.f;              // m_run: reference exponent of this query's p values (set by the first tile)
+    // PS: the finished item's partials leave in the next item's first loop iteration
+    float m_prev = 0.f, l_prev = 0.f;
+    size_t slot_prev = 0;
+    bool pend = false;
+    auto store_pending = [&]() {
+        // point-fragment order (see the one-item epilogue below): the accumulator registers are the layer kernel's operands
+        float* base = a.part_o + slot_prev * PDSC_CHANNELS + lane * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(base + pf_offset_floats(4 * c + g)) = f32x4{o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]};
+        if (h == 0) {
+            a.part_ml[(slot_prev + l31) * 2 + 0] = m_prev;
+            a.part_ml[(slot_prev + l31) * 2 + 1] = l_prev;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    };
 
     const int koff = l31 * SPL_K_STRIDE + 16 * h;   // K image: row of key l31, chunk 2j+h -> + 32 j   (immediates)
     const int voff = l31 * SPL_V_STRIDE + 16 * h;   // V^T image: row of channel 32c + l31, chunk 2j+h -> + 32 j + 32 c stride
@@ -244,11 +306,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     float mx_next = -INFINITY;
     f32x16 sacc;
     PDSC_TRACE_STAMP(0)                          // 0: prologue issue + Q loads
+  for (;;) {                                     // (PS: one pass per item; else exactly one pass)
     // ---- tile kt0: S^T = K Q^T, logits, reference = row maximum ---------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
-        const unsigned char* K = Ks;
+        const unsigned char* K = PS ? Ks + (u0 & 1) * SPL_K_BYTES : Ks;
+        const unsigned char* C0 = PS ? Cs + (u0 & 1) * CSTAGE : Cs;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 32 * j);
@@ -259,8 +323,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         }
         if (C16) {
             unsigned w[8];
-            c16_load(Cs + crow_off, 0, w);
-            c16_load(Cs + crow_off, 1, w);
+            c16_load(C0 + crow_off, 0, w);
+            c16_load(C0 + crow_off, 1, w);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float cc[4];
@@ -278,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 cc = *reinterpret_cast<const f32x4*>(Cs + crow_off + (((2 * g + h) ^ csw) << 4));
+                const f32x4 cc = *reinterpret_cast<const f32x4*>(C0 + crow_off + (((2 * g + h) ^ csw) << 4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tl[4 * g + e] = cc[e] * sacc[4 * g + e];
             }
@@ -293,13 +357,31 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     if (a.prio_mode == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);       // static priority, no per-segment flips
     if (a.prio_mode == 2 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int st = (kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
+        const int st = (PS ? u0 + kt - kt0 : kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
         const bool has_next = kt + 1 < kt1;
+        if constexpr (PS) {
+            // what this iteration's run-ahead loads address: this item's tiles kt + 2 (K, compat) / kt + 1 (V), or, past its
+            // end, the next item's first tiles.  The compat offsets of the lanes follow the next item's row count from the
+            // iteration that issues its first compat tile on (this item's last compat tile went out an iteration ago).
+            if (more && kt + 2 == kt1) {
+                kv_rsrc = PDSC_KV_RSRC(b_n);
+                c_rsrc = PDSC_C_RSRC(b_n, qb_n);
+                dK = kt0n - kt1 + 2;
+                if (q_rows_n != q_rows) set_coff(q_rows_n);
+            }
+            if (more && kt + 1 == kt1) {
+                kv_v = kv_rsrc;
+                dV = kt0n - kt1 + 1;
+            }
+        }
         // K_{kt+1}, compat_{kt+1}, V_kt landed (own LDS-DMA pieces) + everyone finished the previous iteration
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PDSC_TRACE_STAMP(2)                      // 2: wait for own DMA
         __syncthreads();
         PDSC_TRACE_STAMP(3)                      // 3: barrier
+        if constexpr (PS) {
+            if (pend) { store_pending(); pend = false; }      // (phase A does not touch the accumulators)
+        }
         if (CREG) {
             if (kt != kt0) {                     // (the loads issued one iteration ago have landed: vmcnt(0) above)
 #pragma unroll
@@ -407,7 +489,31 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         PDSC_TRACE_STAMP(7)
     }
 
+    if constexpr (!PS) break;
+    else {
+        // ---- item done: partials straight from the accumulators (point-fragment order, see below), no LDS, no wait for
+        //      the loads in flight -- they carry the next item's first tiles
+        // The stores themselves wait until the next item's first loop iteration (store_pending): issued here, the next
+        // s_waitcnt vmcnt(0) -- the first tile's -- would sit out their whole round trip.
+        l_prev = l_run + __shfl_xor(l_run, 32, 64);
+        m_prev = m_run;
+        slot_prev = ((size_t)b * a.nsplit + sp) * a.Npad + qb * (NW * 32) + wave * 32;
+        if (!more) { store_pending(); break; }
+        pend = true;
+        u0 += kt1 - kt0;                         // stage parity carries over: the next item's tile 0 sits where tile kt1 would
+        item += item_step;
+        b = b_n; sp = sp_n; qb = qb_n;
+        kt0 = kt0n;
+        kt1 = kt0 + per + (sp < rem ? 1 : 0);
+        q_rows = q_rows_n;
+        dK = 2; dV = 1;                          // (the descriptors switched with the run-ahead loads)
+        load_q(b, qb);
+        l_run = 0.f;
+        look_ahead();
+    }
+  }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead DMA of the last iterations targets this workgroup's LDS
+    if constexpr (PS) return;
     // ---- epilogue: o[c][4g+e] = O^T[channel 32c + 8g + 4h + e][query l31] ---------------------------------
     // In this layout a lane owns 16 bytes of 32 different output rows: a direct store would touch 64 cache lines per
     // instruction.  The K/V stages are dead now, so every wave transposes its 32 x 128 tile through its own 16.5 KiB of
@@ -659,6 +765,27 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
             rc = launch_attention_combine(c, bs, st);
         }
         return rc;
+    }
+    // A/B knob PDSC_ATT_PERSIST = 1: one workgroup per CU walking its items (point-fragment partials, 8-wave plan, whole
+    // multiples of 8 items, at least two per workgroup)
+    a.items = (int)grid;
+    const bool persist = nw == 8 && !creg && !trace && a.part_frag && (grid & 7) == 0 && grid >= 512 && env_int("PDSC_ATT_PERSIST", 0) != 0;
+    if (persist) {
+        unsigned pgrid = (unsigned)env_int("PDSC_ATT_PERSIST_GRID", 256) & ~7u;      // A/B knob: workgroups (multiple of 8)
+        if (pgrid < 8 || pgrid > grid) pgrid = 256;
+        if (c16) {
+            rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<8, 1, false, true>), lds_bytes, "pdsc_sc_attention_split(dynamic LDS)");
+            if (rc != PDSC_OK) return rc;
+            profile_mark_begin(PDSC_PROF_ATTENTION, st);
+            hipLaunchKernelGGL((sc_attention_split_kernel<8, 1, false, true>), dim3(pgrid), dim3(512), lds_bytes, st, a);
+        } else {
+            rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<8, 0, false, true>), lds_bytes, "pdsc_sc_attention_split(dynamic LDS)");
+            if (rc != PDSC_OK) return rc;
+            profile_mark_begin(PDSC_PROF_ATTENTION, st);
+            hipLaunchKernelGGL((sc_attention_split_kernel<8, 0, false, true>), dim3(pgrid), dim3(512), lds_bytes, st, a);
+        }
+        profile_mark_end(PDSC_PROF_ATTENTION, st);
+        return check_launch("pdsc_sc_attention_split(persistent)");
     }
 #define PDSC_ATT_LAUNCH(NWV, CMV, TRV)                                                                                    \
     do {                                                                                                                    \

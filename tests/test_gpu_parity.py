@@ -628,6 +628,32 @@ def test_point_fragment_hand_offs_reproduce_the_row_order_chain(n, bs, nsplit):
     assert torch.equal(ops.pf_to_rows(fb_h, bs, ops.pf_rows(n))[:, :n].reshape(m, 128), fb_hr) and torch.equal(qs_h, qs_hr) and torch.equal(kv_h, kv_hr)
 
 
+@pytest.mark.parametrize("fmt", ["f32", "u16"])
+@pytest.mark.parametrize("n,bs,nsplit", [(5000, 13, 2), (4100, 16, 2), (2053, 32, 2)])
+def test_persistent_attention_writes_the_same_partials(n, bs, nsplit, fmt, monkeypatch):
+    """PDSC_ATT_PERSIST=1: one workgroup per CU walks its (pair, key split, query block) items, the run-ahead loads of an
+    item's last tiles fetching the next item's first tiles.  Same arithmetic per item: the point-fragment partials (O and
+    (m, l)) must be the one-item-per-workgroup kernel's bit for bit -- uneven item counts per workgroup, ragged last query
+    blocks (other compat row clamp from one item to the next), both compat formats."""
+    gen = torch.Generator().manual_seed(600 + n)
+    batch = synthetic.make_batch(bs, n, seed=11 + n)
+    sig = g(torch.tensor([0.1]))
+    compat = (ops.spatial_compat_u16 if fmt == "u16" else ops.spatial_compat)(g(batch["src_keypts"]), g(batch["tgt_keypts"]), sig)
+    qkv = torch.cat([torch.randn(bs * n, 128, generator=gen) * 0.3 * QSCALE, torch.randn(bs * n, 128, generator=gen) * 0.3,
+                     torch.randn(bs * n, 128, generator=gen)], dim=-1)
+    qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+    monkeypatch.setenv("PDSC_ATT_PERSIST", "0")
+    want = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit, merge=False, layout="pf")[0].clone()
+    monkeypatch.setenv("PDSC_ATT_PERSIST", "1")
+    got = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit, merge=False, layout="pf")[0]
+    npad = (n + 255) // 256 * 256
+    cut = bs * nsplit * npad * 128
+    a_o, b_o = (t.view(torch.float32)[:cut].reshape(bs * nsplit, npad, 128)[:, : (n + 31) // 32 * 32] for t in (want, got))
+    assert torch.equal(a_o, b_o)
+    a_ml, b_ml = (t.view(torch.float32)[cut:cut + bs * nsplit * npad * 2].reshape(bs * nsplit, npad, 2)[:, :n] for t in (want, got))
+    assert torch.equal(a_ml, b_ml)
+
+
 def test_layer_fused_frag_h3_small_and_large_magnitudes():
     """The fp16 halves of H3 at the edges of their range: activations of order 1e-5 (hi parts are fp16 subnormals: they
     must not be flushed by the conversions or the MFMA) and of order 1e3, zero biases so nothing masks them."""
