@@ -259,10 +259,10 @@ def main():
     lay_ghz = lay_pipe_cycles / lay_avg / 1e9 if lay_n else None
     # with the H3 GEMMs (model.layer_gemm = "h3", wavefront-resident kernel) the launch needs 16 k matrix-pipe cycles per tile
     # and is bound by HBM: per point it reads the key-split partials (ns x (512 + 8) B) and the residual row (512 B) and
-    # writes featB (512 B), the Q rows (512 B) and its share of the K/V tile image (37 KiB / 32)
+    # writes featB (512 B), the Q rows (512 B) and its share of the K/V tile image (32 KiB / 32)
     lay_h3 = (not fp32_att(args)) and model.layer_gemm == "h3" and not lib.pdsc_layer_prefers_block(B, N)
     lay_ns = int(lib.pdsc_attention_split_default_split(B, N))
-    lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 37888 / 32.0) * N * B
+    lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 32768 / 32.0) * N * B
     lay_gbs = lay_bytes / lay_avg / 1e9 if lay_n else None
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
     att_avg = att_ms / max(att_n, 1) * 1e-3

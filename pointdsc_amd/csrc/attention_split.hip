@@ -27,8 +27,8 @@ namespace pdsc {
 
 
 // LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, descriptor + scalar offset + one 32-bit lane
-// offset -- no 64-bit address registers) of one part of a tile.  The K part (17 KiB) and the V^T part (20 KiB) of a
-// 37 KiB tile image are linear copies, pieces dealt round-robin to the waves.
+// offset -- no 64-bit address registers) of one part of a tile.  The K part (16 KiB) and the V^T part (16 KiB) of a
+// 32 KiB tile image (split_layout.h) are linear copies, pieces dealt round-robin to the waves.
 template <int NW, int BYTES>
 __device__ __forceinline__ void issue_linear(__amdgpu_buffer_rsrc_t rsrc, int src_off, unsigned char* dst, int wave, unsigned lane16) {
     constexpr int PIECES = BYTES / 1024;
@@ -53,14 +53,14 @@ __device__ __forceinline__ f32x16 scale_acc(f32x16 o, float alpha) {
 }
 
 constexpr float ATT_RESCALE_THR = 8.0f;   // running max is only moved when a logit exceeds it by 2^8 (log2 domain)
-constexpr int SPL_K_BYTES = 2 * 32 * SPL_K_STRIDE;    // Kh | Kl   17 KiB
-constexpr int SPL_V_BYTES = 2 * 128 * SPL_V_STRIDE;   // Vh | Vl   20 KiB
+constexpr int SPL_K_BYTES = 2 * SPL_K_PLANE;    // Kh | Kl   16 KiB
+constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
 
 // Software pipeline (per wave, per key tile t):  phase A = QK^T of tile t+1 on the matrix pipe WHILE the VALU turns
 // tile t's logits into P (exp2, hi/lo split);  phase B = P V of tile t WHILE the VALU forms tile t+1's logits.  Both
 // waves of a SIMD therefore always have matrix and vector work to interleave (with the plain QK -> softmax -> PV order
 // the two waves, released by the same barrier, do their softmax at the same time and the matrix pipe idles).
-// K and compat consequently run one tile ahead of V: per array two LDS stages, 138 KiB in all.
+// K and compat consequently run one tile ahead of V: per array two LDS stages, 128 KiB in all.
 #define PDSC_TRACE_STAMP(k)                                                      \
     if (TRACE) {                                                                 \
         const long long now__ = __builtin_readcyclecounter();                    \
@@ -72,7 +72,7 @@ constexpr int SPL_V_BYTES = 2 * 128 * SPL_V_STRIDE;   // Vh | Vl   20 KiB
 // every 32-key group the 16 keys a lane half holds are contiguous: position 16 h + 4 g + e for key 8 g + 4 h + e), i.e.
 // 64 B per query row per tile instead of 128: half the HBM stream, half the compat LDS stage and DMA instructions.
 // CM (compat mode): 0 = fp32 matrix, slices staged in LDS by LDS-DMA (default);  1 = unorm16 matrix, staged in LDS (C16);
-// 2 = fp32 matrix, every lane loads the 16 values of its query straight into registers (CREG: no compat LDS stage -- 74 KiB
+// 2 = fp32 matrix, every lane loads the 16 values of its query straight into registers (CREG: no compat LDS stage -- 64 KiB
 // per workgroup, so two 4-wave workgroups fit a CU and one's prologue / epilogue overlaps the other's main loop).
 // PS (persistent): one workgroup per CU walks several (pair, key split, query block) items.  The loads that run ahead of an
 // item's last tiles fetch the NEXT item's first K / compat / V tiles (today they fetch tiles nobody reads), so the
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = TRACE ? (long long)__builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* const Ks = lds;                                  // 2 x 17 KiB
-    unsigned char* const Vs = lds + 2 * SPL_K_BYTES;                // 2 x 20 KiB
+    unsigned char* const Ks = lds;                                  // 2 x 16 KiB
+    unsigned char* const Vs = lds + 2 * SPL_K_BYTES;                // 2 x 16 KiB
     unsigned char* const Cs = Vs + 2 * SPL_V_BYTES;                 // 2 x NW*4 KiB
     constexpr int CROW = C16 ? 64 : 128;         // bytes of compat per query row per tile
     constexpr int CSTAGE = CREG ? 0 : NW * 32 * CROW;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // (macros, not lambdas: with a lambda that returns a buffer resource hipcc 7.2's host pass silently drops every launch stub
     //  of this template)
 #define PDSC_KV_RSRC(pair) \
-    __builtin_amdgcn_make_buffer_rsrc((void*)(a.kv + (size_t)(pair) * a.num_tiles * SPL_TILE_BYTES), 0, a.num_tiles * SPL_TILE_BYTES, 0x00020000)
+    __builtin_amdgcn_make_buffer_rsrc((void*)(a.kv + (size_t)(pair) * a.num_tiles * SPL_TILE_STRIDE), 0, a.num_tiles * SPL_TILE_STRIDE, 0x00020000)
     // compat: the descriptor covers only this workgroup's query rows, so every offset fits 32 bits whatever N is
 #define PDSC_C_RSRC(pair, qblock)                                                                                                          \
     __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.compat + ((size_t)(pair) * N + (qblock) * (NW * 32)) * a.ld * CEL), 0, \
@@ -187,14 +187,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             const int i = min(wave + NW * (slot - NCS), PIECES - 1);    // surplus slots repeat the last piece
             const bool isk = i < KPIECES;                                // wave-uniform
             unsigned char* dst = isk ? Ks + st * SPL_K_BYTES + i * 1024 : Vs + (st ^ 1) * SPL_V_BYTES + (i - KPIECES) * 1024;
-            const int src = ((isk ? (PS ? kt + dK : kt + 2) : (PS ? kt + dV : kt + 1)) * PIECES + i) * 1024;
+            const int src = (isk ? (PS ? kt + dK : kt + 2) : (PS ? kt + dV : kt + 1)) * SPL_TILE_STRIDE + i * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(PS ? (isk ? kv_rsrc : kv_v) : kv_rsrc, (lptr_t)dst, 16, lane16, src, 0, 0);
         }
     };
     constexpr int DMA_SLOTS = NCS + KV_SLOTS;    // fp32 compat: 9 (NW = 8) or 14 (NW = 4): 8 go after the QK steps, the rest after PV steps
     static_assert(DMA_SLOTS <= 16, "16 places per iteration");
-    auto dma_k = [&](int kt) { issue_linear<NW, SPL_K_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_KH, Ks + ((kt - kt0) & 1) * SPL_K_BYTES, wave, lane16); };
-    auto dma_v = [&](int kt) { issue_linear<NW, SPL_V_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_VH, Vs + ((kt - kt0) & 1) * SPL_V_BYTES, wave, lane16); };
+    auto dma_k = [&](int kt) { issue_linear<NW, SPL_K_BYTES>(kv_rsrc, kt * SPL_TILE_STRIDE + SPL_KH, Ks + ((kt - kt0) & 1) * SPL_K_BYTES, wave, lane16); };
+    auto dma_v = [&](int kt) { issue_linear<NW, SPL_V_BYTES>(kv_rsrc, kt * SPL_TILE_STRIDE + SPL_VH, Vs + ((kt - kt0) & 1) * SPL_V_BYTES, wave, lane16); };
     auto dma_c = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < NCS; ++u)
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     };
 
-    const int koff = l31 * SPL_K_STRIDE + 16 * h;   // K image: row of key l31, chunk 2j+h -> + 32 j   (immediates)
-    const int voff = l31 * SPL_V_STRIDE + 16 * h;   // V^T image: row of channel 32c + l31, chunk 2j+h -> + 32 j + 32 c stride
+    const int koff = l31 * 16 + 512 * h;            // K image (chunk-major): chunk 2j+h of key l31 -> + 1024 j   (immediates)
+    const int voff = l31 * 16 + 2048 * h;           // V^T image: chunk 2j+h of channel 32c + l31 -> + 4096 j + 512 c
     const int crow_off = (wave * 32 + l31) * CROW;  // compat row of this lane's query in a compat stage
     const int csw = C16 ? (l31 >> 2) & 3 : ((wave * 32 + l31) >> 1) & 7;
     constexpr float C16_INV = 1.0f / 65535.0f;      // 65535 * fl(1/65535) == 1.0f exactly (and 0 stays 0)
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         const unsigned char* C0 = PS ? Cs + (u0 & 1) * CSTAGE : Cs;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 32 * j);
-            const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 32 * j);
+            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * j);
+            const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * j);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
@@ -400,10 +400,18 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         bf16x8 ph[2], pl[2];
         {
             const unsigned char* K = Ks + (st ^ 1) * SPL_K_BYTES;
+            // fragments one step ahead of their MFMAs, and the steps pinned in source order: with the chunk-major image every
+            // read is `base + immediate`, and left to itself the scheduler hoists all sixteen to the top of the iteration and
+            // clusters the MFMAs behind them (measured: +7 % per launch)
+            bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff);
+            bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 32 * j);
-                const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 32 * j);
+                bf16x8 nh = fh, nl = fl;
+                if (j + 1 < 8) {
+                    nh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * (j + 1));
+                    nl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * (j + 1));
+                }
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
@@ -417,6 +425,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                     ph[r >> 3][r & 7] = hi;
                     pl[r >> 3][r & 7] = lo;
                 }
+                fh = nh; fl = nl;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         l_run += psum;
@@ -428,12 +438,17 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             const unsigned char* Cn = Cs + (st ^ 1) * CSTAGE + crow_off;
             unsigned cw[8];
             mx_next = -INFINITY;                 // row maximum of tile kt+1's logits, gathered as they are formed
+            bf16x8 vh = *reinterpret_cast<const bf16x8*>(V + voff);
+            bf16x8 vl = *reinterpret_cast<const bf16x8*>(V + SPL_V_PLANE + voff);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = u >> 1, j = u & 1;
-                const int vo = c * 32 * SPL_V_STRIDE + voff + 32 * j;
-                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(V + vo);
-                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(V + 128 * SPL_V_STRIDE + vo);
+                bf16x8 nvh = vh, nvl = vl;
+                if (u + 1 < 8) {
+                    const int vo = ((u + 1) >> 1) * 512 + voff + 4096 * ((u + 1) & 1);
+                    nvh = *reinterpret_cast<const bf16x8*>(V + vo);
+                    nvl = *reinterpret_cast<const bf16x8*>(V + SPL_V_PLANE + vo);
+                }
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[j], o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[j], o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[j], o[c], 0, 0, 0);
@@ -463,6 +478,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                     for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
                     mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                 }
+                vh = nvh; vl = nvl;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -598,7 +615,7 @@ __global__ __launch_bounds__(256) void pack_qkv_split_kernel(const float* __rest
                                                              unsigned char* __restrict__ kv, int N, int num_tiles) {
     const int tile = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const float* rows = qkv + (size_t)b * N * 3 * PDSC_CHANNELS;
-    unsigned char* img = kv + ((size_t)b * num_tiles + tile) * SPL_TILE_BYTES;
+    unsigned char* img = kv + ((size_t)b * num_tiles + tile) * SPL_TILE_STRIDE;
     const int k0 = tile * SPL_BK;
     // Q: thread -> (row, 4 channels)
 #pragma unroll
@@ -641,7 +658,6 @@ __global__ __launch_bounds__(256) void pack_qkv_split_kernel(const float* __rest
         *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
         *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
     }
-    spl_zero_pads(img, t);
 }
 
 // waves per workgroup and key split for (bs, N): fill the 256 CUs (one 8-wave or two 4-wave workgroups each)
@@ -677,7 +693,7 @@ extern "C" size_t pdsc_split_q_bytes(int bs, int N) {
 }
 extern "C" size_t pdsc_split_kv_bytes(int bs, int N) {
     if (bs <= 0 || N <= 0) return 0;
-    return (size_t)bs * spl_num_tiles(N) * SPL_TILE_BYTES;
+    return (size_t)bs * spl_num_tiles(N) * SPL_TILE_STRIDE;
 }
 
 extern "C" int pdsc_attention_split_default_split(int bs, int N) {
@@ -743,7 +759,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     PDSC_REQUIRE(partial_layout == PDSC_PARTIALS_ROWS || (!msg && nsplit > 1), "pdsc_sc_attention_split: point-fragment partials are not merged here (msg must be NULL, key split > 1)");
     a.part_frag = partial_layout == PDSC_PARTIALS_PF;
     hipStream_t st = (hipStream_t)stream;
-    // 2 stages x (K 17 KiB + V 20 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
+    // 2 stages x (K 16 KiB + V 16 KiB + compat of the workgroup's nw*32 queries: 128 B (fp32) or 64 B (unorm16) per row)
     // ... and at least the epilogue's transposition patches (one 32 x 132-float patch per wave)
     // A/B knob PDSC_ATT_CREG = 1: fp32 compat values straight into registers (no LDS stage)
     const bool creg = !c16 && env_int("PDSC_ATT_CREG", 0) != 0;

@@ -17,8 +17,8 @@ namespace pdsc {
 
 constexpr int WD_NW = 4, WD_G = 2;                       // waves per workgroup, 32-query groups per wave
 constexpr int WD_QROWS = WD_NW * WD_G * 32;              // 256 queries per workgroup
-constexpr int WD_K_BYTES = 2 * 32 * SPL_K_STRIDE;        // Kh | Kl   17 KiB
-constexpr int WD_V_BYTES = 2 * 128 * SPL_V_STRIDE;       // Vh | Vl   20 KiB
+constexpr int WD_K_BYTES = 2 * SPL_K_PLANE;        // Kh | Kl   16 KiB
+constexpr int WD_V_BYTES = 2 * SPL_V_PLANE;        // Vh | Vl   16 KiB
 constexpr int WD_CSTAGE = WD_QROWS * 128;                // compat slice of the 256 queries for one tile: 32 KiB
 constexpr float WD_RESCALE_THR = 8.0f;
 
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WD_NW * 64, 1) void sc_attention_wide_kernel(AttSpl
     const int kt1 = kt0 + per + (sp < rem ? 1 : 0);
 
     const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.kv + (size_t)b * a.num_tiles * SPL_TILE_BYTES), 0, a.num_tiles * SPL_TILE_BYTES, 0x00020000);
+        (void*)(a.kv + (size_t)b * a.num_tiles * SPL_TILE_STRIDE), 0, a.num_tiles * SPL_TILE_STRIDE, 0x00020000);
     const int q_first = qb * WD_QROWS;
     const int q_rows = min(WD_QROWS, N - q_first);
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(WD_NW * 64, 1) void sc_attention_wide_kernel(AttSpl
             const int i = min(wave + WD_NW * (slot - 8), PIECES - 1);
             const bool isk = i < KPIECES;
             unsigned char* dst = isk ? Ks + st * WD_K_BYTES + i * 1024 : Vs + (st ^ 1) * WD_V_BYTES + (i - KPIECES) * 1024;
-            const int src = ((isk ? kt + 2 : kt + 1) * PIECES + i) * 1024;
+            const int src = (isk ? kt + 2 : kt + 1) * SPL_TILE_STRIDE + i * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (lptr_t)dst, 16, lane16, src, 0, 0);
         }
     };
-    auto dma_k = [&](int kt) { wd_issue_linear<WD_K_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_KH, Ks + ((kt - kt0) & 1) * WD_K_BYTES, wave, lane16); };
-    auto dma_v = [&](int kt) { wd_issue_linear<WD_V_BYTES>(kv_rsrc, kt * SPL_TILE_BYTES + SPL_VH, Vs + ((kt - kt0) & 1) * WD_V_BYTES, wave, lane16); };
+    auto dma_k = [&](int kt) { wd_issue_linear<WD_K_BYTES>(kv_rsrc, kt * SPL_TILE_STRIDE + SPL_KH, Ks + ((kt - kt0) & 1) * WD_K_BYTES, wave, lane16); };
+    auto dma_v = [&](int kt) { wd_issue_linear<WD_V_BYTES>(kv_rsrc, kt * SPL_TILE_STRIDE + SPL_VH, Vs + ((kt - kt0) & 1) * WD_V_BYTES, wave, lane16); };
     auto dma_c = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(WD_NW * 64, 1) void sc_attention_wide_kernel(AttSpl
             for (int r = 0; r < 16; ++r) o[g][c][r] = 0.f;
     float m_run[WD_G] = {0.f, 0.f}, l_run[WD_G] = {0.f, 0.f};
 
-    const int koff = l31 * SPL_K_STRIDE + 16 * h;
-    const int voff = l31 * SPL_V_STRIDE + 16 * h;
+    const int koff = l31 * 16 + 512 * h;             // chunk-major images (split_layout.h)
+    const int voff = l31 * 16 + 2048 * h;
     const int csw = (l31 >> 1) & 7;                       // (row >> 1) & 7 with row = 32-aligned base + l31
     int crow_off[WD_G];
 #pragma unroll
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(WD_NW * 64, 1) void sc_attention_wide_kernel(AttSpl
     {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(Ks + SPL_KH + koff + 32 * j);
-            const bf16x8 fl = *reinterpret_cast<const bf16x8*>(Ks + SPL_KL + koff + 32 * j);
+            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(Ks + SPL_KH + koff + 1024 * j);
+            const bf16x8 fl = *reinterpret_cast<const bf16x8*>(Ks + SPL_KL + koff + 1024 * j);
 #pragma unroll
             for (int g = 0; g < WD_G; ++g) {
                 sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[g][j], j == 0 ? zero16 : sacc[g], 0, 0, 0);
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(WD_NW * 64, 1) void sc_attention_wide_kernel(AttSpl
             const unsigned char* K = Ks + (st ^ 1) * WD_K_BYTES;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 32 * j);
-                const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 32 * j);
+                const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * j);
+                const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * j);
 #pragma unroll
                 for (int g = 0; g < WD_G; ++g) {
                     sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[g][j], j == 0 ? zero16 : sacc[g], 0, 0, 0);
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(WD_NW * 64, 1) void sc_attention_wide_kernel(AttSpl
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = u >> 1, j = u & 1;
-                const int vo = c * 32 * SPL_V_STRIDE + voff + 32 * j;
+                const int vo = c * 512 + voff + 4096 * j;
                 const bf16x8 vh = *reinterpret_cast<const bf16x8*>(V + vo);
-                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(V + 128 * SPL_V_STRIDE + vo);
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(V + SPL_V_PLANE + vo);
 #pragma unroll
                 for (int g = 0; g < WD_G; ++g) {
                     o[g][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[g][j], o[g][c], 0, 0, 0);

@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
             __syncthreads();
             if (a.qkv_out) tile_to_global(Xb, a.qkv_out + 128 * c, 3 * PDSC_CHANNELS, m0, M, t);
             if (a.qs) {
-                unsigned char* img = a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_BYTES;
+                unsigned char* img = a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_STRIDE;
                 const int valid = min(LF_ROWS, M - m0);
                 if (c == 0) tile_to_split<0>(Xb, a.qs + (size_t)m0 * SPL_Q_LD, img, valid, t);
                 else if (c == 1) tile_to_split<1>(Xb, nullptr, img, valid, t);
-                else { tile_to_split<2>(Xb, nullptr, img, valid, t); spl_zero_pads(img, t); }
+                else tile_to_split<2>(Xb, nullptr, img, valid, t);
             }
             if (c < 2) __syncthreads();
         }
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
         tile_to_global(Xa, a.featB_out, PDSC_CHANNELS, m0, M, t);
         LF_STAMP(9)
         // ---- q|k|v: 128 -> 384, three 128-column chunks, hi*hi + hi*lo + lo*hi on the bf16 matrix cores, staged via Xa ----
-        unsigned char* img = a.kv ? a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_BYTES : nullptr;
+        unsigned char* img = a.kv ? a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_STRIDE : nullptr;
         const int valid = min(LF_ROWS, M - m0);
         const int xo = l31 * LF_XLD16 + 8 * h;
 #pragma unroll
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
             if (a.qs) {
                 if (c == 0) tile_to_split<0>(Xa, a.qs + (size_t)m0 * SPL_Q_LD, img, valid, t);
                 else if (c == 1) tile_to_split<1>(Xa, nullptr, img, valid, t);
-                else { tile_to_split<2>(Xa, nullptr, img, valid, t); spl_zero_pads(img, t); }
+                else tile_to_split<2>(Xa, nullptr, img, valid, t);
             }
             if (c == 0) { LF_STAMP(12) }
         }

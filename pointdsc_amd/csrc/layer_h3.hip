@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
     }
     LH_STAMP(1)
 
-    unsigned char* img = H ? a.kv + (size_t)gw * SPL_TILE_BYTES : nullptr;
+    unsigned char* img = H ? a.kv + (size_t)gw * SPL_TILE_STRIDE : nullptr;
     f32x16 acc, cross;
     f32x4 vp[4];                 // values of the output tile whose epilogue is pending
     u32x4 ev = {0u, 0u, 0u, 0u}; // patch -> global staging register of the epilogue pipeline
@@ -207,29 +207,32 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
         } else {
             // q | k | v, output tile d.tile of 12: tiles 0..3 = q, 4..7 = k, 8..11 = v
             {
-                if constexpr (d.tile < 8) {
-                    // patch row = (hi 64 B | lo 64 B) of this tile's 32 channels: lower lane-half holds hi chunks, upper lo
+                if constexpr (d.tile >= 4 && d.tile < 8) {
+                    // K image, chunk-major (split_layout.h): after the half swap lane (key l31, half h) holds chunk 4(t-4)+s of its
+                    // key for the hi (h = 0) / lo (h = 1) plane -- the 32 lanes of a half store 512 consecutive, aligned bytes
                     if constexpr (s < 4) {
                         f32x4 z = v[s];
-                        if constexpr (d.tile >= 4) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) z[e] = live ? z[e] : 0.f;                // keys beyond N are zero
-                        }
+                        for (int e = 0; e < 4; ++e) z[e] = live ? z[e] : 0.f;                    // keys beyond N are zero
                         unsigned hi[2], lo[2];
                         split4(z, hi, lo);
+                        const u32x4 ck = chunk_for_store(hi, lo);
+                        if constexpr (!(EXP & (2 | 16))) *reinterpret_cast<u32x4*>(img + (h ? SPL_KL : SPL_KH) + spl_k_offset(l31, 4 * (d.tile - 4) + s)) = ck;
+                        else asm volatile("" :: "v"(ck));
+                    }
+                } else if constexpr (d.tile < 4) {
+                    // Q rows (hi[128] | lo[128]) bf16 through the patch: row = (hi 64 B | lo 64 B) of this tile's 32 channels
+                    if constexpr (s < 4) {
+                        unsigned hi[2], lo[2];
+                        split4(v[s], hi, lo);
                         *reinterpret_cast<u32x4*>(patch + l31 * LW_PROW + 64 * h + 16 * s) = chunk_for_store(hi, lo);
                     }
                     if constexpr (s == 3) wave_lds_sync();
                     if constexpr (s >= 4) {
                         const int pt = 8 * (s - 4) + (lane >> 3), piece = lane & 7;
-                        if constexpr (d.tile < 4) {      // Q rows: (hi[128] | lo[128]) bf16
-                            __bf16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
-                            if constexpr (!(EXP & (2 | 8))) *reinterpret_cast<u32x4*>(dst) = ev;
-                            else asm volatile("" :: "v"(ev), "v"(dst));
-                        } else {                         // K image: 64-byte runs, chunks 4t..4t+3 of a key, hi plane then lo plane
-                            if constexpr (!(EXP & (2 | 16))) *reinterpret_cast<u32x4*>(img + ((piece >> 2) ? SPL_KL : SPL_KH) + spl_k_offset(pt, 4 * (d.tile - 4) + (piece & 3))) = ev;
-                            else asm volatile("" :: "v"(ev));
-                        }
+                        __bf16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
+                        if constexpr (!(EXP & (2 | 8))) *reinterpret_cast<u32x4*>(dst) = ev;
+                        else asm volatile("" :: "v"(ev), "v"(dst));
                     }
                     if constexpr (s >= 3 && s < 7) {
                         const int pt = 8 * (s - 3) + (lane >> 3), piece = lane & 7;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) vt[e] = Vs[spl_v_key(jh, e) * LW_VLD + cl];
                     }
-                    if constexpr (s == 5 || s == 7) {     // 64-byte runs
+                    if constexpr (s == 5 || s == 7) {     // 256-byte runs: 16 channels of one key chunk
                         const int cl = 16 * ((s - 5) >> 1) + (lane >> 2), jh = lane & 3;
                         unsigned chi[4], clo[4];
 #pragma unroll
@@ -337,18 +340,6 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
         __builtin_amdgcn_sched_barrier(0);      // chunks are the unit of the software pipeline: no code motion across them
     });
 
-    if (H) {                // pad chunks of the tile image (never read; zeroed so the stream is deterministic)
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (lane < 32) {
-            *reinterpret_cast<f32x4*>(img + SPL_KH + spl_k_offset(lane, 16)) = z;
-            *reinterpret_cast<f32x4*>(img + SPL_KL + spl_k_offset(lane, 16)) = z;
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            *reinterpret_cast<f32x4*>(img + SPL_VH + spl_v_offset(lane + 64 * it, 4)) = z;
-            *reinterpret_cast<f32x4*>(img + SPL_VL + spl_v_offset(lane + 64 * it, 4)) = z;
-        }
-    }
     LH_STAMP(63)
 }
 

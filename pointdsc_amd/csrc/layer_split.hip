@@ -182,7 +182,6 @@ __device__ __forceinline__ void stage_to_split(const float* F, __bf16* __restric
             *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
             *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
         }
-        spl_zero_pads(img, t);
     }
 }
 
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(256, 3) void layer_x3_kernel(LayerX3Args a) {
         __syncthreads();
         tile_to_global(F, a.featB_out, C, m0, M, t);
         // ---- q|k|v: 128 -> 384 in three 128-column chunks staged through F ----
-        unsigned char* img = a.kv ? a.kv + ((size_t)b * gridDim.x + blockIdx.x) * SPL_TILE_BYTES : nullptr;
+        unsigned char* img = a.kv ? a.kv + ((size_t)b * gridDim.x + blockIdx.x) * SPL_TILE_STRIDE : nullptr;
         const int valid = min(LX_ROWS, M - m0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

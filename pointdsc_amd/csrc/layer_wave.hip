@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
     }
     LW_STAMP(1)
 
-    unsigned char* img = (H && a.kv) ? a.kv + (size_t)gw * SPL_TILE_BYTES : nullptr;
+    unsigned char* img = (H && a.kv) ? a.kv + (size_t)gw * SPL_TILE_STRIDE : nullptr;
     f32x16 acc, cross;
 
     static_for<0, NCH>([&](auto ic) {
@@ -321,18 +321,6 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
         __builtin_amdgcn_sched_barrier(0);      // chunks are the unit of the software pipeline: no code motion across them
     });
 
-    if (H && a.qs) {        // pad chunks of the tile image (never read; zeroed so the stream is deterministic)
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (lane < 32) {
-            *reinterpret_cast<f32x4*>(img + SPL_KH + spl_k_offset(lane, 16)) = z;
-            *reinterpret_cast<f32x4*>(img + SPL_KL + spl_k_offset(lane, 16)) = z;
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            *reinterpret_cast<f32x4*>(img + SPL_VH + spl_v_offset(lane + 64 * it, 4)) = z;
-            *reinterpret_cast<f32x4*>(img + SPL_VL + spl_v_offset(lane + 64 * it, 4)) = z;
-        }
-    }
     LW_STAMP(63)
 }
 

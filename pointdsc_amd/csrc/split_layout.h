@@ -7,16 +7,20 @@
 // three v_mfma_f32_32x32x16_bf16 per operand pair = 3/16 of the cost of the exact fp32 MFMA.
 //
 //   Q stream : [bs*N][256] bf16   row = (hi[0..127] | lo[0..127]), natural channel order
-//   KV stream: [bs][ntiles][SPL_TILE_BYTES]  one 37 KiB block per tile of 32 keys, laid out as the exact LDS image
-//              the attention kernel wants, so that the LDS-DMA copy is linear and fully coalesced:
-//       +SPL_KH / +SPL_KL : K hi / lo   [32 keys][SPL_K_STRIDE = 272 B]: 16 chunks of 8 channels (16 B) + one pad chunk.
-//                           The odd number of chunks per row rotates consecutive keys by one 16-B bank slot, so the
-//                           column-slice ds_read_b128 (16 different keys, same chunk) is conflict-free AND every read of
-//                           a lane is `lane base + immediate` (an XOR swizzle would need one address register per chunk).
-//       +SPL_VH / +SPL_VL : V^T hi / lo [128 channels][SPL_V_STRIDE = 80 B]: 4 chunks of 8 keys (16 B) + one pad chunk;
-//                           chunk jh = 2j+h holds, in order e = 0..7, keys 16j + 8(e>>2) + 4h + (e&3) -- the keys
-//                           lane-half h holds in accumulator registers 8j..8j+7 of S^T = K Q^T.
-//   keys >= N of the last tile and all pad chunks are zero.
+//   KV stream: [bs][ntiles][SPL_TILE_STRIDE]  one 32 KiB block (SPL_TILE_BYTES) per tile of 32 keys, laid out as the exact LDS image
+//              the attention kernel wants, so that the LDS-DMA copy is linear and fully coalesced.  Both operands are
+//              CHUNK-MAJOR (r02; r01 had key / channel rows with a pad chunk, 37 KiB):
+//       +SPL_KH / +SPL_KL : K hi / lo   [16 chunks of 8 channels][32 keys][16 B]  (8 KiB per plane).  The MFMA A fragment
+//                           of lane (key l31, half h) in k-step j is chunk 2j+h of key l31: the 32 lanes of a half read 512
+//                           consecutive bytes -- the access the ds_read_b128 lane groups are built for, conflict-free with no
+//                           padding -- and every read of a lane is `lane base + immediate` (+1 KiB per j).
+//       +SPL_VH / +SPL_VL : V^T hi / lo [4 chunks of 8 keys][128 channels][16 B]  (8 KiB per plane); chunk jh = 2j+h
+//                           holds, in order e = 0..7, keys 16j + 8(e>>2) + 4h + (e&3) -- the keys lane-half h holds in
+//                           accumulator registers 8j..8j+7 of S^T = K Q^T.  Lane (channel 32c + l31, half h), step j reads
+//                           chunk 2j+h of its channel: again 512 consecutive bytes per lane half.
+//              On the producer side a chunk of one key / channel range is a run of whole, aligned cache lines: the layer
+//              kernel's lane (key l31, half h) stores its K chunk straight from registers (2 x 512 B per instruction).
+//   keys >= N of the last tile are zero.  No pad bytes.
 #pragma once
 #include "pdsc_common.h"
 
@@ -26,31 +30,23 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SPL_BK = 32;                       // keys per tile
-constexpr int SPL_K_STRIDE = 272, SPL_V_STRIDE = 80;      // bytes per K row (key) / V^T row (channel), pad chunk included
-constexpr int SPL_KH = 0, SPL_KL = 32 * SPL_K_STRIDE, SPL_VH = 2 * SPL_KL, SPL_VL = SPL_VH + 128 * SPL_V_STRIDE;
-constexpr int SPL_TILE_BYTES = SPL_VL + 128 * SPL_V_STRIDE;     // 37888 = 37 KiB
+constexpr int SPL_K_PLANE = 16 * 32 * 16, SPL_V_PLANE = 4 * 128 * 16;      // bytes per K / V^T plane (hi or lo): 8 KiB each
+constexpr int SPL_KH = 0, SPL_KL = SPL_K_PLANE, SPL_VH = 2 * SPL_K_PLANE, SPL_VL = SPL_VH + SPL_V_PLANE;
+constexpr int SPL_TILE_BYTES = SPL_VL + SPL_V_PLANE;     // 32768 = 32 KiB
+// Images sit SPL_TILE_STRIDE apart in HBM, not back to back: with a 32 KiB stride the eight XCDs, which walk their tile
+// ranges in step, ask the memory side for addresses that differ by multiples of 32 KiB at the same moment -- the attention
+// launch measured 7 % slower (profiles/r02_n_*).  37 KiB (an odd number of KiB; r01's image size) spreads them; the 5 KiB
+// between images are never read or written.
+constexpr int SPL_TILE_STRIDE = 37 * 1024;
 constexpr int SPL_Q_LD = 2 * PDSC_CHANNELS;     // bf16 elements per row of the Q stream
 
-__host__ __device__ __forceinline__ int spl_k_offset(int key, int chunk) { return key * SPL_K_STRIDE + (chunk << 4); }   // chunk 16 = pad
-__host__ __device__ __forceinline__ int spl_v_offset(int ch, int jh) { return ch * SPL_V_STRIDE + (jh << 4); }          // jh 4 = pad
+__host__ __device__ __forceinline__ int spl_k_offset(int key, int chunk) { return (chunk << 9) + (key << 4); }    // chunk 0..15
+__host__ __device__ __forceinline__ int spl_v_offset(int ch, int jh) { return (jh << 11) + (ch << 4); }            // jh 0..3
 __host__ __device__ __forceinline__ int spl_v_key(int jh, int e) { return 16 * (jh >> 1) + 8 * (e >> 2) + 4 * (jh & 1) + (e & 3); }
 
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
     hi = (__bf16)x;
     lo = (__bf16)(x - (float)hi);
-}
-
-// pad chunks of one tile image (never read by the attention kernel; zeroed so the stream is deterministic)
-__device__ __forceinline__ void spl_zero_pads(unsigned char* __restrict__ img, int t) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (t < 32) {
-        *reinterpret_cast<f32x4*>(img + SPL_KH + spl_k_offset(t, 16)) = z;
-        *reinterpret_cast<f32x4*>(img + SPL_KL + spl_k_offset(t, 16)) = z;
-    }
-    if (t < 128) {
-        *reinterpret_cast<f32x4*>(img + SPL_VH + spl_v_offset(t, 4)) = z;
-        *reinterpret_cast<f32x4*>(img + SPL_VL + spl_v_offset(t, 4)) = z;
-    }
 }
 
 static inline int spl_num_tiles(int N) { return ceil_div(N, SPL_BK); }

@@ -158,7 +158,7 @@ def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
     lib = _lib.load()
     qkv = _chk(qkv, "qkv")
     qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=qkv.device, dtype=torch.uint8)
-    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=qkv.device, dtype=torch.uint8)
+    kv = torch.zeros(int(lib.pdsc_split_kv_bytes(bs, n)), device=qkv.device, dtype=torch.uint8)
     _lib.check(lib.pdsc_pack_qkv_split(_p(qkv), _p(qs), _p(kv), bs, n, _stream()), "pdsc_pack_qkv_split")
     return qs, kv
 
@@ -237,7 +237,7 @@ def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_q
     featB = torch.empty(m, 128, device=dev, dtype=torch.float32) if has_head else None
     qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if want_qkv and has_head else None
     qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
-    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    kv = torch.zeros(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
     part_o = part_ml = None
     nsplit = npad = 0
     if partials is not None:
@@ -299,7 +299,7 @@ def layer_fused_io(res, feat_in, tail_w, head_w, bs: int, n: int, io_flags: int,
     fb_rows = bs * pf_rows(n) if io_flags & PF_FEATB else m
     featB = torch.empty(fb_rows * 128, device=dev, dtype=torch.float32) if has_head else None
     qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
-    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    kv = torch.zeros(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
     part_o = part_ml = None
     nsplit = npad = 0
     if partials is not None:
@@ -352,7 +352,7 @@ def layer_fused_x3(msg, res, feat_in, tail_w, head_w, bs: int, n: int, partials=
     featB = torch.empty(m, 128, device=dev, dtype=torch.float32) if has_head else None
     qkv = torch.empty(m, 384, device=dev, dtype=torch.float32) if (has_head and want_qkv) else None
     qs = torch.empty(int(lib.pdsc_split_q_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
-    kv = torch.empty(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
+    kv = torch.zeros(int(lib.pdsc_split_kv_bytes(bs, n)), device=dev, dtype=torch.uint8) if has_head else None
     part_o = part_ml = None
     nsplit = npad = 0
     if partials is not None:

@@ -251,20 +251,21 @@ def _pack_reference(qkv, bs, n):
     pad[:, :n] = qkv[..., 128:]
     k = pad[..., :128].reshape(bs, tiles, 32, 128)
     v = pad[..., 128:].reshape(bs, tiles, 32, 128)
-    # K image: [32 keys][16 chunks of 8 channels + 1 zero pad chunk]  (row stride 272 B)
-    kimg = torch.zeros(bs, tiles, 32, 17, 8)
-    kimg[:, :, :, :16] = k.reshape(bs, tiles, 32, 16, 8)
-    # V^T image: [128 channels][4 chunks of 8 keys + 1 zero pad chunk] (row stride 80 B);
+    # K image, chunk-major: [16 chunks of 8 channels][32 keys][8]  (8 KiB per plane, no padding)
+    kimg = k.reshape(bs, tiles, 32, 16, 8).permute(0, 1, 3, 2, 4).contiguous()
+    # V^T image, chunk-major: [4 chunks of 8 keys][128 channels][8];
     # chunk jh = 2j+h, element e = V[16j + 8(e>>2) + 4h + (e&3)][channel]
-    vimg = torch.zeros(bs, tiles, 128, 5, 8)
+    vimg = torch.zeros(bs, tiles, 4, 128, 8)
     for jh in range(4):
         for e in range(8):
             kk = 16 * (jh >> 1) + 8 * (e >> 2) + 4 * (jh & 1) + (e & 3)
-            vimg[:, :, :, jh, e] = v[:, :, kk, :]
+            vimg[:, :, jh, :, e] = v[:, :, kk, :]
     kh, kl = _split(kimg.reshape(bs, tiles, -1))
     vh, vl = _split(vimg.reshape(bs, tiles, -1))
     kv = torch.cat([kh, kl, vh, vl], dim=-1)
-    assert kv.shape[-1] * 2 == 37888
+    assert kv.shape[-1] * 2 == 32768
+    # images sit 37 KiB apart (SPL_TILE_STRIDE); the 5 KiB in between are never touched (ops allocates the stream zeroed)
+    kv = torch.cat([kv, torch.zeros(bs, tiles, (37 * 1024 - 32768) // 2, dtype=kv.dtype)], dim=-1)
     return qs.view(torch.uint8).reshape(-1), kv.contiguous().view(torch.uint8).reshape(-1)
 
 
