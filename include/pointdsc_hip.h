@@ -193,7 +193,7 @@ int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, f
 /* Same chain, with the head additionally (or instead of qkv_out, which may then be NULL) emitting the bf16 hi/lo
  * operand streams of the split-precision attention (layout: pointdsc_amd/csrc/split_layout.h):
  *   q_split  [bs*N][256] bf16 (hi | lo), pdsc_split_q_bytes(bs, N) bytes;
- *   kv_tiles [bs][ceil(N/32)][32 KiB],   pdsc_split_kv_bytes(bs, N) bytes.
+ *   kv_tiles [bs][ceil(N/32)][37 KiB] (a 32 KiB image per tile of 32 keys, images 37 KiB apart), pdsc_split_kv_bytes(bs, N) bytes.
  * Rows are bs pairs of N points (a 32-point tile never straddles two pairs).
  * The tail input is either `msg` (merged rows) or the un-merged key-split partials (`part_o`, `part_ml`, nsplit, Npad)
  * exactly as pdsc_sc_attention_split leaves them in its scratch when called with msg == NULL: the merge then happens

@@ -33,10 +33,9 @@ constexpr int SPL_BK = 32;                       // keys per tile
 constexpr int SPL_K_PLANE = 16 * 32 * 16, SPL_V_PLANE = 4 * 128 * 16;      // bytes per K / V^T plane (hi or lo): 8 KiB each
 constexpr int SPL_KH = 0, SPL_KL = SPL_K_PLANE, SPL_VH = 2 * SPL_K_PLANE, SPL_VL = SPL_VH + SPL_V_PLANE;
 constexpr int SPL_TILE_BYTES = SPL_VL + SPL_V_PLANE;     // 32768 = 32 KiB
-// Images sit SPL_TILE_STRIDE apart in HBM, not back to back: with a 32 KiB stride the eight XCDs, which walk their tile
-// ranges in step, ask the memory side for addresses that differ by multiples of 32 KiB at the same moment -- the attention
-// launch measured 7 % slower (profiles/r02_n_*).  37 KiB (an odd number of KiB; r01's image size) spreads them; the 5 KiB
-// between images are never read or written.
+// Images sit SPL_TILE_STRIDE apart in HBM, not back to back: an odd number of KiB keeps the eight XCDs, which walk their tile
+// ranges in step, off a power-of-two address stride (precaution: with the un-pinned attention loop 32 and 37 KiB measured the
+// same; r01's image size kept).  The 5 KiB between images are never read or written.
 constexpr int SPL_TILE_STRIDE = 37 * 1024;
 constexpr int SPL_Q_LD = 2 * PDSC_CHANNELS;     // bf16 elements per row of the Q stream
 
