@@ -267,7 +267,10 @@ def main():
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
     att_avg = att_ms / max(att_n, 1) * 1e-3
     att_tflops = att_flops / att_avg / 1e12 if att_n else None
-    cmp_bytes = (4.0 * N * N + 24.0 * N) * B                  # compat write + keypoint reads
+    # compat write + keypoint reads; the matrix is stored as unorm16 (2 B per entry) unless
+    # model.compat_format = "f32" 
+    c16 = (not fp32_att(args)) and model.compat_format == "u16"
+    cmp_bytes = ((2.0 if c16 else 4.0) * N * N + 24.0 * N) * B
     cmp_avg = cmp_ms / max(cmp_n, 1) * 1e-3
     cmp_gbs = cmp_bytes / cmp_avg / 1e9 if cmp_n else None
     fp32 = args.attention_precision == "fp32"
@@ -294,6 +297,7 @@ def main():
                                "seeded random weights" % (w["label"], N, total_pairs, world, B),
                    "name": args.config, "num_corr": N, "pairs_per_gpu": B, "global_batch": total_pairs,
                    "sigma_d": kw["sigma_d"], "inlier_threshold": kw["inlier_threshold"],
+                   "compat_format": "f32" if fp32 else model.compat_format, "layer_gemm": model.layer_gemm,
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s)"
                                   % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU")},
         "roofline": roof,
@@ -310,7 +314,7 @@ def main():
                             "frac": None if lay_ghz is None else round(lay_ghz / MAX_CLOCK_GHZ, 4),
                             "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
                             "flops_per_launch": lay_flops}),
-        "roofline_compat": {"kernel": "compat_sym_kernel", "bound": "hbm",
+        "roofline_compat": {"kernel": "compat_sym_u16_kernel" if c16 else "compat_sym_kernel", "bound": "hbm",
                             "achieved": None if cmp_gbs is None else round(cmp_gbs, 1), "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": None if cmp_gbs is None else round(cmp_gbs / PEAK_HBM_GBS, 4),
                             "traffic": None, "launches": cmp_n, "avg_launch_ms": round(cmp_avg * 1e3, 4),
@@ -322,10 +326,10 @@ def main():
     if traffic_file.exists():
         try:
             tj = json.loads(traffic_file.read_text())
-            key = f"{args.config}_B{B}"
+            key = f"{args.config}_B{B}" + ("_u16" if c16 else "")
             if key in tj:
                 line["roofline"]["traffic"] = tj[key].get(line["roofline"]["kernel"])
-                line["roofline_compat"]["traffic"] = tj[key].get("compat_sym_kernel")
+                line["roofline_compat"]["traffic"] = tj[key].get(line["roofline_compat"]["kernel"])
                 line["roofline_layer"]["traffic"] = tj[key].get(line["roofline_layer"]["kernel"])
         except Exception:
             pass

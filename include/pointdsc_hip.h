@@ -83,8 +83,9 @@ enum pdsc_layer_io { PDSC_IO_PARTIALS_PF = 1, PDSC_IO_RES_PF = 2, PDSC_IO_FEATB_
  * (the split-precision modes only; PDSC_ATT_FP32 always uses fp32 storage):
  *   U16: unorm16, value = round(compat * 65535) / 65535 -- 0 and 1 exact, |error| <= 2^-17 = 7.6e-6, the size of the
  *        2^-16 product error of the bf16x3 arithmetic it feeds; half the HBM stream (2 N^2 instead of 4 N^2 bytes per
- *        layer per pair), half the workspace; +5 % pairs/s at N=5000 (tools/ab_forward.py).            [opt-in]
- *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's.                     [default] */
+ *        layer per pair), half the workspace; +4.6 % pairs/s at N=5000 (tools/ab_forward.py).
+ *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's.
+ * The Python module defaults to U16 (parity census equal to F32's); the C struct has no default. */
 enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
 
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.

@@ -733,7 +733,7 @@ def test_split_and_fp32_attention_agree_through_the_encoder(n):
         out[prec if fmt == "u16" or prec == "fp32" else prec + "_f32compat"] = (
             model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
             model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
-    model.attention_precision, model.compat_format = "bf16x3", "f32"
+    model.attention_precision, model.compat_format = "bf16x3", COMPAT_FORMAT_DEFAULT
     scale = max(1.0, float(out["fp32"][0].abs().max()))
     print("feature error vs fp32:", {k: float((out["fp32"][0] - v[0]).abs().max()) / scale for k, v in out.items()})
     for prec, tol in (("bf16x3", 8e-6), ("bf16x3_f32compat", 8e-6), ("bf16x3_all", 3e-5)):
@@ -1065,6 +1065,7 @@ _BENCH_MODELS = {}
 
 
 LAYER_GEMM_DEFAULT = PointDSC().layer_gemm
+COMPAT_FORMAT_DEFAULT = PointDSC().compat_format
 
 
 def _bench_model(name):
@@ -1157,7 +1158,7 @@ def test_forward_is_bit_identical_with_row_order_and_point_fragment_hand_offs(na
             for k in env:
                 monkeypatch.delenv(k)
     finally:
-        model.compat_format, model.layer_gemm = "f32", LAYER_GEMM_DEFAULT
+        model.compat_format, model.layer_gemm = COMPAT_FORMAT_DEFAULT, LAYER_GEMM_DEFAULT
     for T, L in out[1:]:
         assert torch.equal(T, out[0][0]) and torch.equal(L, out[0][1])
     for i in range(bs):
@@ -1219,7 +1220,7 @@ def test_forward_is_bitwise_repeatable():
             for r in runs[1:]:
                 assert all(torch.equal(x, y) for x, y in zip(runs[0], r)), fmt
     finally:
-        model.compat_format = "f32"
+        model.compat_format = COMPAT_FORMAT_DEFAULT
 
 
 def test_batched_forward_equals_per_pair_calls():
