@@ -291,7 +291,9 @@ def main():
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
-        "dtype": "f32" if fp32 else "f32 (attention products as bf16x3 split, f32 accumulate)",
+        "dtype": "f32" if fp32 else ("f32 (attention products as bf16x3 split, f32 accumulate" +
+                                      ("; fc_message / PointCN products as fp16 hi+lo split" if lay_h3 else "") +
+                                      ("; spatial-consistency matrix stored as unorm16" if c16 else "") + ")"),
         "data": "synthetic",
         "config": {"workload": "%s: N=%d corr, %d pairs per step sharded over %d GPU(s) = %d per GPU, 12-layer PointDSC, "
                                "seeded random weights" % (w["label"], N, total_pairs, world, B),
