@@ -119,7 +119,7 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0, help="override the configuration's pairs per step over ALL GPUs")
     ap.add_argument("--pairs-per-gpu", type=int, default=0,
                     help="override: fixed batch per GPU per step (weak scaling); 0 = global-batch / gpus")
-    ap.add_argument("--attention-precision", choices=["bf16x3", "fp32", "bf16x3_all"], default="bf16x3",
+    ap.add_argument("--attention-precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank; gloo = rehearsal of the N>1 path with CPU-tensor collectives")
@@ -251,8 +251,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    # fused layer launch (tail of layer i + head of layer i+1): matrix-pipe cycles per 32-point tile = 600 fp32 MFMAs x 64
-    # + 288 bf16 MFMAs x 32 (q|k|v as bf16x3); 2 flop/MAC x (128*64 + 64*64 + 64*128 + 128*128 + 128*384) MACs per point
+    # fused layer launch (tail of layer i + head of layer i+1).  With layer_gemm = "h3" on the wavefront-resident kernel (the
+    # shipped default wherever pdsc_layer_prefers_block is 0) it is reported against HBM (`lay_bytes` below); the matrix-pipe
+    # figure (600 fp32 MFMAs x 64 + 288 bf16 MFMAs x 32 cycles per 32-point tile) is only reported for layer_gemm = "f32" /
+    # the workgroup-per-tile kernel.  2 flop/MAC x (128*64 + 64*64 + 64*128 + 128*128 + 128*384) MACs per point
     lay_flops = 2.0 * 86016 * N * B
     lay_avg = lay_ms / max(lay_n, 1) * 1e-3
     lay_pipe_cycles = (600 * 64 + 288 * 32) * math.ceil(N / 32) * B / 1024.0      # per SIMD (256 CUs x 4)
@@ -303,8 +305,8 @@ def main():
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s)"
                                   % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU")},
         "roofline": roof,
-        # matrix-pipe issue cycles the launch needs per SIMD / its duration, against a pipe that is busy every cycle at
-        # the maximum clock (the chip runs this kernel at 1.6-2.0 GHz: PMC summaries under profiles/)
+        # H3 kernel: algorithmic HBM bytes per launch / its duration against 8 TB/s; otherwise matrix-pipe issue cycles the
+        # launch needs per SIMD / its duration, against a pipe that is busy every cycle at the maximum clock
         "roofline_layer": ({"kernel": "layer_h3_kernel", "bound": "hbm",
                             "achieved": None if lay_gbs is None else round(lay_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": None if lay_gbs is None else round(lay_gbs / PEAK_HBM_GBS, 4),
@@ -336,25 +338,34 @@ def main():
         except Exception:
             pass
 
-    # ---- parity of this run's outputs, part 1: against the unmodified reference's outputs on the same pairs ----
+    # ---- parity of this run's outputs, part 1: EVERY pair of rank 0's shard against the unmodified reference's outputs on
+    #      the same pairs (tests/golden/census_<config>.npz: its fp32 and its fp64 run, oracle/make_census_goldens.py).  The
+    #      contract of BASELINE.json, no looser tolerance for any pair: labels bit-exact and R/t within 1e-4 of the fp32
+    #      output, or -- pairs on which the reference's own two precisions land on different hypotheses -- of the fp64 output.
     res = last["res"]
     check = None
     if not args.no_check:
         check = {}
-        gold = ROOT / "tests" / "golden" / f"bench_{args.config}.npz"
+        gold = ROOT / "tests" / "golden" / f"census_{args.config}.npz"
         if gold.exists():
             import numpy as np
             fx = np.load(gold, allow_pickle=False)
-            g = min(B, fx["ref_final_trans"].shape[0])
-            want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:g, :N].astype(np.float32))
-            got_T, got_lab = res["final_trans"][:g].cpu(), res["final_labels"][:g].cpu()
-            stable = torch.from_numpy(fx["stable"][:g])       # reference fp32 vs fp64 agree on the pair (make_bench_goldens.py)
-            dTs = (got_T - torch.from_numpy(fx["ref_final_trans"][:g])).abs().amax(dim=(1, 2))
-            check.update(pairs_vs_reference=g, max_abs_dT_vs_reference=float(dTs.max()),
-                         pairs_unstable_in_reference=int((~stable).sum()),
-                         max_abs_dT_vs_reference_stable_pairs=float(dTs[stable].max()) if bool(stable.any()) else None,
-                         label_flips_vs_reference=int((got_lab != want_lab).sum()),
-                         reference_outputs="tests/golden/bench_%s.npz (unmodified reference, oracle/make_bench_goldens.py)" % args.config)
+            g = min(B, fx["ref32_final_trans"].shape[0])
+            got_T, got_lab = res["final_trans"][:g].cpu().double(), res["final_labels"][:g].cpu()
+            per = {}
+            for tag in ("ref32", "ref64"):
+                lab = torch.from_numpy(np.unpackbits(fx[tag + "_final_labels_bits"][:g], axis=1)[:, :N].astype(np.float32))
+                per[tag] = ((got_T - torch.from_numpy(fx[tag + "_final_trans"][:g]).double()).abs().amax(dim=(1, 2)), (got_lab != lab).sum(dim=1))
+            ok32 = (per["ref32"][0] < 1e-4) & (per["ref32"][1] == 0)
+            ok64 = (per["ref64"][0] < 1e-4) & (per["ref64"][1] == 0)
+            best = torch.where(ok32, per["ref32"][0], torch.minimum(per["ref32"][0], per["ref64"][0]))
+            check.update(pairs_vs_reference=g, max_abs_dT_vs_reference=float(best.max()),
+                         max_abs_dT_vs_reference_fp32=float(per["ref32"][0].max()),
+                         pairs_matched_on_reference_fp64_only=int((~ok32 & ok64).sum()),
+                         pairs_failing_vs_reference=[int(i) for i in torch.nonzero(~(ok32 | ok64)).flatten()],
+                         label_flips_vs_reference=int(torch.where(ok32 | ~ok64, per["ref32"][1], per["ref64"][1]).sum()),
+                         reference_outputs="tests/golden/census_%s.npz (unmodified reference, fp32 and fp64 runs, "
+                                           "oracle/make_census_goldens.py)" % args.config)
 
     # ---- CPU baseline: the reference's CPU path on this host's cores, bounded sample (rank 0, N=1 only), in a child
     #      process with a wall-clock cap so the bench always finishes; the same child runs the exact oracle on the
@@ -393,13 +404,17 @@ def main():
                                     "sample": sample + " -- failed: %r" % (e,)}
         log("CPU baseline done")
     if check is not None:
-        dts = [check[k] for k in ("max_abs_dT_vs_reference_stable_pairs", "max_abs_dT_vs_oracle") if check.get(k) is not None]
+        dts = [check[k] for k in ("max_abs_dT_vs_reference", "max_abs_dT_vs_oracle") if check.get(k) is not None]
         fl = [check[k] for k in ("label_flips_vs_reference", "label_flips_vs_oracle") if k in check]
-        check["ok"] = bool(dts) and max(dts) < 1e-4 and sum(fl) == 0       # north_star: masks bit-exact, R/t within 1e-4
+        check["ok"] = bool(dts) and max(dts) < 1e-4 and sum(fl) == 0 and not check.get("pairs_failing_vs_reference")   # north_star: masks bit-exact, R/t within 1e-4
         line["check"] = check
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if check is not None and not check["ok"]:
+        # a throughput figure next to outputs that miss the parity contract is not a result: fail the run
+        print("[bench] PARITY CHECK FAILED: %s" % json.dumps(check), file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

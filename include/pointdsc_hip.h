@@ -14,8 +14,9 @@
  *     state is limited to: the per-(kernel, device) dynamic-LDS opt-in table (mutex-protected), the error string
  *     (thread-local), and the opt-in DIAGNOSTIC hooks -- pdsc_profile_* event timing, pdsc_attention_trace,
  *     pdsc_layer_trace -- which are process-wide switches and not thread-safe: use them from one thread.
- *     Tuning / A-B knobs are PDSC_* environment variables read on every call (nothing is cached; DESIGN.md lists
- *     them); the shipped behaviour is the default;
+ *     The product library reads NO environment variable: everything that selects a kernel or changes arithmetic is a field
+ *     of pdsc_config or an argument.  The PDSC_* tuning / A-B knobs DESIGN.md lists exist in experiments builds only
+ *     (-DPDSC_EXPERIMENTS, `python -m pointdsc_amd.build --experiments` -> libpointdsc_hip_exp.so; pdsc_experiments_enabled());
  *   - tensors are dense row-major; `bs` = number of correspondence sets (pairs), `N` = correspondences
  *     per pair, `C` = 128 channels, `S` = number of seeds, `k` = neighbours per seed;
  *   - bs > 1 means bs independent pairs, i.e. the reference called once per pair (the reference's
@@ -46,7 +47,7 @@ enum pdsc_status {
 
 /* Constructor arguments of reference PointDSC.__init__ (models/PointDSC.py:81-91) that the path uses. */
 typedef struct pdsc_config {
-    int in_dim;              /* 6                                              */
+    int in_dim;              /* 6 (1..16: datasets/ThreeDMatch.py:299-312 builds 6 / 9 / 12) */
     int num_layers;          /* 12 in the released snapshots                   */
     int num_channels;        /* must be PDSC_CHANNELS                          */
     int num_iterations;      /* power-iteration cap, 10                        */
@@ -81,9 +82,11 @@ enum pdsc_layer_io { PDSC_IO_PARTIALS_PF = 1, PDSC_IO_RES_PF = 2, PDSC_IO_FEATB_
 
 /* Storage of the spatial-consistency matrix between its build and the 12 attention launches that stream it
  * (the split-precision modes only; PDSC_ATT_FP32 always uses fp32 storage):
- *   U16: unorm16, value = round(compat * 65535) / 65535 -- 0 and 1 exact, |error| <= 2^-17 = 7.6e-6, the size of the
- *        2^-16 product error of the bf16x3 arithmetic it feeds; half the HBM stream (2 N^2 instead of 4 N^2 bytes per
- *        layer per pair), half the workspace; +4.6 % pairs/s at N=5000 (tools/ab_forward.py).
+ *   U16: unorm16, value = round(c * 65535) / 65535 with c evaluated on the hardware's 1-ulp square root (r03: the exact
+ *        sqrt / divide of the fp32 matrix made the build instruction-bound) -- within 2 units (3e-5) of the fp32 matrix,
+ *        the diagonal exactly 1, symmetric bit for bit; the size of the 2^-16 product error of the bf16x3 arithmetic it
+ *        feeds; half the HBM stream (2 N^2 instead of 4 N^2 bytes per layer per pair), half the workspace; +4.6 % pairs/s
+ *        at N=5000 (tools/ab_forward.py).
  *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's.
  * The Python module defaults to U16 (parity census equal to F32's); the C struct has no default. */
 enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
@@ -91,11 +94,11 @@ enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
  *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
  *           ~2^-16 relative error per product; 12-layer features within 5e-6, R/t within 1e-5 of the fp32 path.
- *           Also used for the q|k|v projection (its results only feed the attention); every GEMM whose result
- *           lands on the residual stream (PointCN, fc_message) stays exact fp32.                       [default]
+ *           Also used for the q|k|v projection (its results only feed the attention); the GEMMs whose results
+ *           land on the residual stream (PointCN, fc_message) follow pdsc_config.layer_gemm.           [default]
  *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time.
- *   BF16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): ~10 us less per layer, but their error lands on the
- *           residual stream un-averaged: 12-layer features within 2e-5 of the fp32 path (opt-in). */
+ *   BF16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): their error lands on the residual stream un-averaged,
+ *           12-layer features within 2e-5 of the fp32 path.  A/B record: accepted by experiments builds only. */
 enum pdsc_attention_precision { PDSC_ATT_BF16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_BF16X3_ALL = 2 };
 
 /* ---- packed weights --------------------------------------------------------------------------
@@ -104,7 +107,7 @@ enum pdsc_attention_precision { PDSC_ATT_BF16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT
  * that the host packer (pointdsc_amd/model.py) and the kernels cannot disagree.
  * All matrices are [out][in] row-major exactly like Conv1d.weight[:, :, 0]. */
 enum pdsc_wsection {
-    PDSC_W_LAYER0_W = 0,  /* [C][8]   in_dim zero-padded to 8   (encoder.layer0)            */
+    PDSC_W_LAYER0_W = 0,  /* [C][16]  in_dim (<= 16) zero-padded to 16 (encoder.layer0)       */
     PDSC_W_LAYER0_B,      /* [C]                                                             */
     PDSC_W_PCN_W,         /* per layer [C][C]     PointCN conv + BN folded                   */
     PDSC_W_PCN_B,         /* per layer [C]                                                   */
@@ -129,6 +132,8 @@ enum pdsc_wsection {
 
 int         pdsc_version(void);
 const char* pdsc_last_error(void);
+/* 1 in experiments builds (A/B knobs and the opt-in record kernels compiled in), 0 in the product library */
+int         pdsc_experiments_enabled(void);
 
 /* total floats of the packed buffer / offset of a section (layer ignored for per-model sections);
  * returns -1 on bad arguments */

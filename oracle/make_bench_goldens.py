@@ -48,9 +48,7 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, str(REF))
     from models.PointDSC import PointDSC as RefPointDSC  # the unmodified reference
-    # --all: every pair of every workload (census fixtures bench_<name>_all.npz for tools/parity_census.py), not just the
-    # first GOLDEN_PAIRS that the tests and bench.py --check use
-    all_pairs = "--all" in sys.argv
+    all_pairs = False      # (the every-pair census moved to oracle/make_census_goldens.py: 256 pairs per family, fp32 + fp64 outputs)
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     report = json.loads((GOLDEN / "BENCH_PINNING.json").read_text()) if (GOLDEN / "BENCH_PINNING.json").exists() else {}
     ok = True

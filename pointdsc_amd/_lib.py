@@ -42,6 +42,7 @@ _cfgp = C.POINTER(PdscConfig)
 SIGNATURES = {
     "pdsc_version": (_i, []),
     "pdsc_last_error": (C.c_char_p, []),
+    "pdsc_experiments_enabled": (_i, []),
     "pdsc_wpack_floats": (_ll, [_cfgp]),
     "pdsc_wpack_offset": (_ll, [_cfgp, _i, _i]),
     "pdsc_compat_ld": (_ll, [_i]),

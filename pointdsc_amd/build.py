@@ -3,6 +3,12 @@
 ``python -m pointdsc_amd.build`` or ``__graft_entry__.build()``.  The library is pure HIP runtime
 (no torch, no pybind): ``hipcc --offload-arch=gfx950 -shared -fPIC`` over ``csrc/*.hip``.
 hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the tree.
+
+``python -m pointdsc_amd.build --experiments`` builds ``libpointdsc_hip_exp.so`` from the same sources with
+``-DPDSC_EXPERIMENTS``: the PDSC_* environment knobs are live and the opt-in record kernels (64-query attention,
+persistent / compat-in-registers attention, all-split layer kernel, r02 exact-rounded unorm16 compat build) are compiled
+in.  Tools select it with ``POINTDSC_HIP_LIB=pointdsc_amd/libpointdsc_hip_exp.so`` (tools/ab_forward.py --exp); the product
+library reads no environment variable.
 """
 from __future__ import annotations
 
@@ -18,6 +24,8 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libpointdsc_hip.so"
 OBJ_DIR = PKG / "csrc" / "_obj"
 STAMP = OBJ_DIR / "sources.sha256"
+EXP_LIB = PKG / "libpointdsc_hip_exp.so"
+EXP_OBJ_DIR = PKG / "csrc" / "_obj_exp"
 
 ARCH = "gfx950"
 # -ffp-contract=off: the kernels spell out every fused multiply-add (fmaf) themselves, so the arithmetic
@@ -37,40 +45,50 @@ def _sources():
     return sorted(CSRC.glob("*.hip"))
 
 
-def _digest() -> str:
+def _digest(flags=None) -> str:
+    flags = FLAGS if flags is None else flags
     h = hashlib.sha256()
     for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "pointdsc_hip.h"]):
         h.update(p.name.encode())
         h.update(p.read_bytes())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags).encode())
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    digest = _digest()
-    if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == digest:
-        return LIB
-    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> Path:
+    flags = FLAGS + (["-DPDSC_EXPERIMENTS"] if experiments else [])
+    lib, obj_dir = (EXP_LIB, EXP_OBJ_DIR) if experiments else (LIB, OBJ_DIR)
+    stamp = obj_dir / "sources.sha256"
+    digest = _digest(flags)
+    if not force and lib.exists() and stamp.exists() and stamp.read_text().strip() == digest:
+        return lib
+    obj_dir.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
 
     def compile_one(src: Path) -> Path:
-        obj = OBJ_DIR / (src.stem + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        obj = obj_dir / (src.stem + ".o")
+        # per-file digest: only sources whose text (or any header) changed are recompiled
+        fd = hashlib.sha256(src.read_bytes() + b"".join(p.read_bytes() for p in sorted(CSRC.glob("*.h"))) +
+                            (PKG.parent / "include" / "pointdsc_hip.h").read_bytes() + " ".join(flags).encode()).hexdigest()
+        fstamp = obj_dir / (src.stem + ".sha256")
+        if not force and obj.exists() and fstamp.exists() and fstamp.read_text().strip() == fd:
+            return obj
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[pointdsc_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        fstamp.write_text(fd)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, _sources()))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(lib)]
     if verbose:
         print("[pointdsc_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    STAMP.write_text(digest)
-    return LIB
+    stamp.write_text(digest)
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

@@ -30,7 +30,8 @@ int check_launch(const char* what) {
 
 // ---- dynamic-LDS opt-in, once per (kernel, device) ----------------------------------------------
 int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
-    struct Entry { const void* fn; unsigned long long devices; size_t bytes; };
+    // granted size per (kernel, device): a larger request on one device must not mark the others as served
+    struct Entry { const void* fn; size_t granted[64]; };
     static Entry table[64];
     static int used = 0;
     static std::mutex mu;
@@ -40,13 +41,10 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
     Entry* e = nullptr;
     for (int i = 0; i < used; ++i)
         if (table[i].fn == fn) { e = &table[i]; break; }
-    if (e && dev < 64 && (e->devices >> dev & 1ull) && e->bytes >= bytes) return PDSC_OK;
+    if (e && dev < 64 && e->granted[dev] >= bytes) return PDSC_OK;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return check_launch(what);
-    if (!e && used < 64) { e = &table[used++]; e->fn = fn; e->devices = 0; e->bytes = 0; }
-    if (e && dev < 64) {
-        if (bytes > e->bytes) { e->bytes = bytes; e->devices = 0; }      // a larger request must be repeated on every device
-        e->devices |= 1ull << dev;
-    }
+    if (!e && used < 64) { e = &table[used++]; e->fn = fn; memset(e->granted, 0, sizeof(e->granted)); }
+    if (e && dev < 64) e->granted[dev] = bytes;
     return PDSC_OK;
 }
 
@@ -71,7 +69,7 @@ void profile_mark_end(int kind, hipStream_t st) {
 static bool config_ok(const pdsc_config* c) {
     if (!c) { set_error("pdsc_config is null"); return false; }
     if (c->num_channels != PDSC_CHANNELS) { set_error("num_channels=%d (only %d supported)", c->num_channels, PDSC_CHANNELS); return false; }
-    if (c->in_dim < 1 || c->in_dim > 8) { set_error("in_dim=%d must be in [1,8]", c->in_dim); return false; }
+    if (c->in_dim < 1 || c->in_dim > 16) { set_error("in_dim=%d must be in [1,16]", c->in_dim); return false; }
     if (c->num_layers < 0 || c->num_layers > 64) { set_error("num_layers=%d", c->num_layers); return false; }
     if (c->num_iterations < 0 || c->num_iterations > PDSC_MAX_POWER_ITERS) { set_error("num_iterations=%d", c->num_iterations); return false; }
     if (c->k < 1 || c->k > PDSC_MAX_K) { set_error("k=%d must be in [1,%d]", c->k, PDSC_MAX_K); return false; }
@@ -79,6 +77,12 @@ static bool config_ok(const pdsc_config* c) {
     if (c->attention_precision < PDSC_ATT_BF16X3 || c->attention_precision > PDSC_ATT_BF16X3_ALL) {
         set_error("attention_precision=%d", c->attention_precision); return false;
     }
+#ifndef PDSC_EXPERIMENTS
+    if (c->attention_precision == PDSC_ATT_BF16X3_ALL) {
+        set_error("attention_precision=PDSC_ATT_BF16X3_ALL (all-split layer GEMMs) exists in experiments builds only");
+        return false;
+    }
+#endif
     if (c->compat_format != PDSC_COMPAT_U16 && c->compat_format != PDSC_COMPAT_F32) { set_error("compat_format=%d", c->compat_format); return false; }
     if (c->layer_gemm != PDSC_LAYER_GEMM_F32 && c->layer_gemm != PDSC_LAYER_GEMM_H3) { set_error("layer_gemm=%d", c->layer_gemm); return false; }
     return true;
@@ -87,7 +91,7 @@ static bool config_ok(const pdsc_config* c) {
 static long long section_floats(int section) {
     const long long C = PDSC_CHANNELS, H = C / 2;
     switch (section) {
-        case PDSC_W_LAYER0_W: return C * 8;
+        case PDSC_W_LAYER0_W: return C * 16;
         case PDSC_W_LAYER0_B: return C;
         case PDSC_W_PCN_W: return C * C;
         case PDSC_W_PCN_B: return C;
@@ -201,6 +205,13 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
 using namespace pdsc;
 
 extern "C" int pdsc_version(void) { return PDSC_VERSION; }
+extern "C" int pdsc_experiments_enabled(void) {
+#ifdef PDSC_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char* pdsc_last_error(void) { return g_err; }
 
 extern "C" long long pdsc_wpack_floats(const pdsc_config* cfg) {
@@ -326,7 +337,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const int fuse_env = env_int("PDSC_FUSE_MERGE", 1);      // tuning/A-B knob
         // the layer kernels merge the key-split partials while loading (merge_partials.h): up to 4 splits, 8 in the
         // workgroup-per-tile kernel that small problems take
-        const char* var = getenv("PDSC_LAYER_VARIANT");          // same rule as pdsc_layer_fused_split
+        const char* var = env_str("PDSC_LAYER_VARIANT");          // same rule as pdsc_layer_fused_split
         const bool block_layer = !x3_gemm && ((var && var[0] == 'b') || (!(var && var[0] == 'w') && pdsc_layer_prefers_block(bs, N)));
         const bool fuse_merge = fuse_env && ns > 1 && ns <= (block_layer ? 8 : 4);
         const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;

@@ -313,7 +313,7 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
             rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<1>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
         if (rc_lds != PDSC_OK) return rc_lds;
     }
-    const char* env_variant = getenv("PDSC_ATT_VARIANT");       // tuning/A-B knob, read per call; default = shipped variant
+    const char* env_variant = pdsc::env_str("PDSC_ATT_VARIANT");       // tuning/A-B knob, read per call; default = shipped variant
     const int variant = env_variant ? atoi(env_variant) : PDSC_ATT_DEFAULT_VARIANT;
     dim3 grid(pdsc::ceil_div(N, pdsc::ATT_BQ), nsplit, bs);
     pdsc::profile_mark_begin(PDSC_PROF_ATTENTION, st);

@@ -769,6 +769,8 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
     int rc = PDSC_OK;
     const bool trace = nw == 8 && a.trace;
+    (void)trace;
+#ifdef PDSC_EXPERIMENTS
     // A/B knob PDSC_ATT_WIDE = 1: the one-wave-per-SIMD, 64-queries-per-wave variant (attention_wide.hip) where the plan
     // picks the 8-wave kernel
     if (nw == 8 && !c16 && !creg && !trace && !a.part_frag && env_int("PDSC_ATT_WIDE", 0)) {
@@ -782,9 +784,11 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
         }
         return rc;
     }
+#endif
+    a.items = (int)grid;
+#ifdef PDSC_EXPERIMENTS
     // A/B knob PDSC_ATT_PERSIST = 1: one workgroup per CU walking its items (point-fragment partials, 8-wave plan, whole
     // multiples of 8 items, at least two per workgroup)
-    a.items = (int)grid;
     const bool persist = nw == 8 && !creg && !trace && a.part_frag && (grid & 7) == 0 && grid >= 512 && env_int("PDSC_ATT_PERSIST", 0) != 0;
     if (persist) {
         unsigned pgrid = (unsigned)env_int("PDSC_ATT_PERSIST_GRID", 256) & ~7u;      // A/B knob: workgroups (multiple of 8)
@@ -803,6 +807,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
         profile_mark_end(PDSC_PROF_ATTENTION, st);
         return check_launch("pdsc_sc_attention_split(persistent)");
     }
+#endif
 #define PDSC_ATT_LAUNCH(NWV, CMV, TRV)                                                                                    \
     do {                                                                                                                    \
         rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, CMV, TRV>), lds_bytes,        \
@@ -812,13 +817,18 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
         hipLaunchKernelGGL((sc_attention_split_kernel<NWV, CMV, TRV>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);       \
         profile_mark_end(PDSC_PROF_ATTENTION, st);                                                                          \
     } while (0)
+#ifdef PDSC_EXPERIMENTS
     if (trace && c16) PDSC_ATT_LAUNCH(8, 1, true);
     else if (trace) PDSC_ATT_LAUNCH(8, 0, true);
-    else if (nw == 8 && c16) PDSC_ATT_LAUNCH(8, 1, false);
+    else
+#endif
+    if (nw == 8 && c16) PDSC_ATT_LAUNCH(8, 1, false);
+#ifdef PDSC_EXPERIMENTS
     else if (nw == 8 && creg) PDSC_ATT_LAUNCH(8, 2, false);
+    else if (nw != 8 && !c16 && creg) PDSC_ATT_LAUNCH(4, 2, false);
+#endif
     else if (nw == 8) PDSC_ATT_LAUNCH(8, 0, false);
     else if (c16) PDSC_ATT_LAUNCH(4, 1, false);
-    else if (creg) PDSC_ATT_LAUNCH(4, 2, false);
     else PDSC_ATT_LAUNCH(4, 0, false);
 #undef PDSC_ATT_LAUNCH
     rc = check_launch("pdsc_sc_attention_split");

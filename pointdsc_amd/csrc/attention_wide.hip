@@ -9,6 +9,7 @@
 //   * 4 waves instead of 8 meet at the per-tile barrier.
 // Registers: O^T 2 x 64, Q hi/lo 2 x 64, S^T 2 x 16, logits 2 x 16, P hi/lo 2 x 16 ... ~400 of the 512-entry unified
 // VGPR/AGPR file (one wave per SIMD).
+#ifdef PDSC_EXPERIMENTS      // opt-in record (13 % slower than the shipped kernel): experiments builds only
 #include <stdlib.h>
 #include "attention_common.h"
 #include "split_layout.h"
@@ -309,3 +310,4 @@ int launch_attention_wide(const AttSplitArgs& a, unsigned grid, hipStream_t st) 
 }
 
 }  // namespace pdsc
+#endif  // PDSC_EXPERIMENTS

@@ -200,16 +200,144 @@ __global__ __launch_bounds__(256) void compat_sym_kernel(const float* __restrict
 }
 
 // ---- unorm16 variant for the split-precision attention (the only consumer of the matrix in the forward) -----------
-// value = round(compat * 65535) (v_cvt_pknorm_u16_f32: 0 and 1 exact, |error| <= 2^-17), stored in the attention kernel's
-// tile order: inside every group of 32 keys, key 8g + 4h + e sits at position 16h + 4g + e -- the 16 keys a lane half of
-// the S^T accumulator holds are contiguous (attention_split.hip).  Same symmetric scheme as above; half the bytes.
+// value u = round(c * 65535) (v_cvt_pknorm_u16_f32), stored in the attention kernel's tile order: inside every group of 32
+// keys, key 8g + 4h + e sits at position 16h + 4g + e -- the 16 keys a lane half of the S^T accumulator holds are contiguous
+// (attention_split.hip).  A 16-byte chunk q of a group (positions 8q .. 8q+7) therefore holds the keys
+// 16(q&1) + 4(q>>1) + {0,1,2,3,8,9,10,11}.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ int c16_pos(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }   // r in [0, 32)
-constexpr int C16_PITCH = 2 * CS_T + 8;      // bytes per LDS strip row (128 u16 + pad)
+__host__ __device__ __forceinline__ int c16_chunk_base(int q) { return 16 * (q & 1) + 4 * (q >> 1); }            // first key of chunk q
 
+// r03: the shipped kernel.  The r02 kernel (below, experiments builds) paid the correctly rounded sqrt / divide of the fp32
+// matrix (~50 VALU instructions per element: instruction-bound at 0.38 of the HBM rate, PMC r02_c) for a result that is then
+// rounded to 16 bits.  Here c is evaluated with the hardware's 1-ulp v_sqrt_f32 and a multiplication by 1/sigma^2 on packed
+// fp32 math (v_pk_*_f32: two elements per instruction): ~16 issue slots per element.  |c - c_fp32| <= 2 (ulp(d_src) +
+// ulp(d_tgt)) |d_src - d_tgt| / sigma^2 < 2e-5 at the clamp (|d_src - d_tgt| -> sigma), -> 0 towards c = 1: the stored value
+// is within 2 units of round(c_fp32 * 65535), equal to it for ~99 % of the non-zero entries (tests); the diagonal is
+// exactly 65535, the matrix is symmetric bit for bit (each unordered pair is evaluated once).
+// Work decomposition: one workgroup = one 128 x 128 tile on / above the diagonal, one wavefront = a 64 x 64 quarter, one
+// lane = an 8 x 8 micro-block whose rows AND columns are the key sets of a 16-byte chunk -- so the lane holds, in
+// registers, whole chunks of 8 rows (direct tile) and of 8 columns (the mirrored tile): no LDS transposition, and every
+// store instruction of a wave writes 8 x 128 whole, aligned bytes in both orientations.
+constexpr int CF_T = 128;
+__device__ __forceinline__ int cf_point_slot(int r) { return (r + (r >> 4)) * 8; }      // floats; one pad point per 16: conflict-free b128 reads
+
+template <bool EDGE, bool CLAMP>
+__device__ __forceinline__ void compat_fast_tile(const float* __restrict__ pts, unsigned short* __restrict__ outb, long long ld,
+                                                 int N, int i0, int j0, bool offdiag, float ninv) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int ri = (w >> 1) * 8 + (lane >> 3), cj = (w & 1) * 8 + (lane & 7);       // chunk index of the rows / columns (0..15)
+    const int rbase = 32 * (ri >> 2) + c16_chunk_base(ri & 3);                      // first of this lane's 8 tile rows
+    const int cbase = 32 * (cj >> 2) + c16_chunk_base(cj & 3);
+    // columns in registers, as pairs (m, m+1)
+    f32x2 sx[4], sy[4], sz[4], tx[4], ty[4], tz[4];
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+        const int m0 = 2 * cp, c0 = cbase + (m0 & 3) + 8 * (m0 >> 2);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(CF_T + c0));
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(CF_T + c0) + 4);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(CF_T + c0 + 1));
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(CF_T + c0 + 1) + 4);
+        sx[cp] = f32x2{a0[0], a1[0]}; sy[cp] = f32x2{a0[1], a1[1]}; sz[cp] = f32x2{a0[2], a1[2]};
+        tx[cp] = f32x2{b0[0], b1[0]}; ty[cp] = f32x2{b0[1], b1[1]}; tz[cp] = f32x2{b0[2], b1[2]};
+    }
+    unsigned tr[8][4];                            // mirrored tile: chunk of column m = rows (2rp, 2rp+1) packed in word rp
+    const f32x2 one2 = {1.0f, 1.0f}, ninv2 = {ninv, ninv}, zero2 = {0.f, 0.f};
+    const int colpos = j0 + 32 * (cj >> 2) + 8 * (cj & 3);                           // tile-order position of this lane's column chunk
+    const int rowpos = i0 + 32 * (ri >> 2) + 8 * (ri & 3);
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) {
+        const int m0 = 2 * rp, r0 = rbase + (m0 & 3) + 8 * (m0 >> 2);
+        const f32x4 ps0 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(r0));
+        const f32x4 pt0 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(r0) + 4);
+        const f32x4 ps1 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(r0 + 1));
+        const f32x4 pt1 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(r0 + 1) + 4);
+        unsigned d0[4], d1[4];
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+            f32x2 o[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const f32x4 ps = rr ? ps1 : ps0, pt = rr ? pt1 : pt0;
+                const f32x2 dx = f32x2{ps[0], ps[0]} - sx[cp], dy = f32x2{ps[1], ps[1]} - sy[cp], dz = f32x2{ps[2], ps[2]} - sz[cp];
+                const f32x2 ex = f32x2{pt[0], pt[0]} - tx[cp], ey = f32x2{pt[1], pt[1]} - ty[cp], ez = f32x2{pt[2], pt[2]} - tz[cp];
+                const f32x2 a = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                const f32x2 b = __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
+                const f32x2 ds = {__builtin_amdgcn_sqrtf(a[0]), __builtin_amdgcn_sqrtf(a[1])};
+                const f32x2 dt = {__builtin_amdgcn_sqrtf(b[0]), __builtin_amdgcn_sqrtf(b[1])};
+                const f32x2 df = ds - dt;
+                f32x2 v = __builtin_elementwise_fma(df * df, ninv2, one2);           // 1 - df^2 / sigma^2
+                if (CLAMP) v = __builtin_elementwise_max(v, zero2);
+                o[rr] = v;
+            }
+            if (EDGE) {
+                const int mc = 2 * cp, jc = j0 + cbase + (mc & 3) + 8 * (mc >> 2);
+                const int ir = i0 + r0;
+                const bool vj0 = jc < N, vj1 = jc + 1 < N, vi0 = ir < N, vi1 = ir + 1 < N;
+                o[0][0] = (vi0 && vj0) ? o[0][0] : 0.f; o[0][1] = (vi0 && vj1) ? o[0][1] : 0.f;
+                o[1][0] = (vi1 && vj0) ? o[1][0] : 0.f; o[1][1] = (vi1 && vj1) ? o[1][1] : 0.f;
+            }
+            d0[cp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(o[0][0], o[0][1]));
+            d1[cp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(o[1][0], o[1][1]));
+            tr[2 * cp][rp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(o[0][0], o[1][0]));
+            tr[2 * cp + 1][rp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(o[0][1], o[1][1]));
+        }
+        const int i = i0 + r0;
+        if (!EDGE || (i < N && colpos < ld)) *reinterpret_cast<u32x4*>(outb + (size_t)i * ld + colpos) = u32x4{d0[0], d0[1], d0[2], d0[3]};
+        if (!EDGE || (i + 1 < N && colpos < ld)) *reinterpret_cast<u32x4*>(outb + (size_t)(i + 1) * ld + colpos) = u32x4{d1[0], d1[1], d1[2], d1[3]};
+    }
+    if (offdiag) {                                // block-uniform
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int j = j0 + cbase + (m & 3) + 8 * (m >> 2);
+            if (!EDGE || (j < N && rowpos < ld)) *reinterpret_cast<u32x4*>(outb + (size_t)j * ld + rowpos) = u32x4{tr[m][0], tr[m][1], tr[m][2], tr[m][3]};
+        }
+    }
+}
+
+template <bool CLAMP>
 __global__ __launch_bounds__(256) void compat_sym_u16_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
                                                              const float* __restrict__ sigma_spat,
-                                                             unsigned short* __restrict__ compat, long long ld, int N) {
+                                                             unsigned short* __restrict__ compat, long long ld, int N, int nt) {
+    // workgroup -> tile (I <= J) of the upper triangle, rows of tiles back to back: start(I) = I nt - I (I - 1) / 2
+    const int idx = blockIdx.x, b = blockIdx.y;
+    int I = (int)(((float)(2 * nt + 1) - __builtin_sqrtf((float)((2 * nt + 1) * (2 * nt + 1) - 8 * idx))) * 0.5f);
+    I = max(0, min(I, nt - 1));
+    while (I > 0 && I * nt - I * (I - 1) / 2 > idx) --I;
+    while ((I + 1) * nt - (I + 1) * I / 2 <= idx) ++I;
+    const int J = I + idx - (I * nt - I * (I - 1) / 2);
+    __shared__ __attribute__((aligned(16))) float pts[(2 * CF_T + 2 * CF_T / 16) * 8];      // tile rows, then tile columns: sx sy sz - tx ty tz -
+    const int i0 = I * CF_T, j0 = J * CF_T;
+    const float* srcb = src + (size_t)b * N * 3;
+    const float* tgtb = tgt + (size_t)b * N * 3;
+    const int t = threadIdx.x;
+    {
+        const int p = min((t < CF_T ? i0 : j0 - CF_T) + t, N - 1);
+        float* d = pts + cf_point_slot(t);
+        *reinterpret_cast<f32x4*>(d) = f32x4{srcb[p * 3 + 0], srcb[p * 3 + 1], srcb[p * 3 + 2], 0.f};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{tgtb[p * 3 + 0], tgtb[p * 3 + 1], tgtb[p * 3 + 2], 0.f};
+    }
+    const float sg = sigma_spat[0];
+    const float s2 = sg * sg;                        // `self.sigma_spat ** 2` in fp32
+    const float y0 = __builtin_amdgcn_rcpf(s2);
+    const float ninv = -fmaf(fmaf(-s2, y0, 1.0f), y0, y0);      // -(1 / sigma^2), one Newton step on the 1-ulp reciprocal
+    unsigned short* outb = compat + (size_t)b * N * ld;
+    __syncthreads();
+    if (i0 + CF_T > N || j0 + CF_T > N)              // block-uniform: only the last row / column of tiles masks and bounds-checks
+        compat_fast_tile<true, CLAMP>(pts, outb, ld, N, i0, j0, I != J, ninv);
+    else
+        compat_fast_tile<false, CLAMP>(pts, outb, ld, N, i0, j0, I != J, ninv);
+}
+
+#ifdef PDSC_EXPERIMENTS
+// r02 kernel (A/B record): u = round(c_fp32 * 65535) of the bit-exact fp32 matrix -- the exact sqrt / divide above, mirrored
+// tile transposed through a 32-row LDS strip.  0.38 of the HBM rate (instruction-bound).
+constexpr int C16_PITCH = 2 * CS_T + 8;      // bytes per LDS strip row (128 u16 + pad)
+
+__global__ __launch_bounds__(256) void compat_sym_u16_exact_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                                   const float* __restrict__ sigma_spat,
+                                                                   unsigned short* __restrict__ compat, long long ld, int N) {
     const int I = blockIdx.y, J = blockIdx.x, b = blockIdx.z;
     if (I > J) return;
     __shared__ __attribute__((aligned(16))) unsigned char Ts[CS_STRIP * C16_PITCH];   // one 32 x 128 strip of u16, row-major
@@ -282,6 +410,7 @@ __global__ __launch_bounds__(256) void compat_sym_u16_kernel(const float* __rest
         }
     }
 }
+#endif  // PDSC_EXPERIMENTS
 
 // self-test hook: the two hand-rolled exact primitives on arbitrary inputs (tests compare with IEEE results)
 __global__ void exact_math_selftest_kernel(const float* __restrict__ x, float b, float* __restrict__ sq, float* __restrict__ dv,
@@ -338,9 +467,21 @@ extern "C" int pdsc_spatial_compat_u16(const float* src, const float* tgt, const
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_spatial_compat_u16: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= pdsc::round_up(N, 32) && ld % 32 == 0, "pdsc_spatial_compat_u16: ld=%lld must be a multiple of 32 and >= N", ld);
     hipStream_t st = (hipStream_t)stream;
-    const int nt = pdsc::ceil_div(N, pdsc::CS_T);
+    const int nt = pdsc::ceil_div(N, pdsc::CF_T);
+    PDSC_REQUIRE(nt <= 1024, "pdsc_spatial_compat_u16: N=%d too large", N);
+    const dim3 grid((unsigned)(nt * (nt + 1) / 2), bs);
     pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
-    hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel, dim3(nt, nt, bs), dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N);
+#ifdef PDSC_EXPERIMENTS
+    // A/B knob (experiments builds only): 0 = r02 kernel (rounded exact fp32 matrix), 2 = fast kernel relying on the
+    // conversion instruction's own clamp
+    const int variant = pdsc::env_int("PDSC_COMPAT16_VARIANT", 1);
+    if (variant == 0)
+        hipLaunchKernelGGL(pdsc::compat_sym_u16_exact_kernel, dim3(nt, nt, bs), dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N);
+    else if (variant == 2)
+        hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel<false>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N, nt);
+    else
+#endif
+    hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N, nt);
     pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
     return pdsc::check_launch("pdsc_spatial_compat_u16");
 }

@@ -424,7 +424,7 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     // tiles its serial 46k matrix-pipe cycles per tile are the launch time, and this file's kernel, which spreads a tile
     // over the four SIMDs of a CU, is faster (N = 1000, one pair: 0.68 vs 1.10 ms per forward).
     // PDSC_LAYER_VARIANT = block | wave overrides the size rule.
-    const char* ev = getenv("PDSC_LAYER_VARIANT");          // read per call
+    const char* ev = pdsc::env_str("PDSC_LAYER_VARIANT");          // experiments builds only
     const int variant = !ev ? 0 : ev[0] == 'b' ? 1 : ev[0] == 'w' ? 2 : 0;
     const bool block_variant = variant == 1 || (variant == 0 && pdsc_layer_prefers_block(bs, N));
     if (!block_variant) {

@@ -23,6 +23,8 @@
 
 namespace pdsc {
 
+constexpr int PDSC_H3_SMALL_TILES = 1536;     // launches with at most this many 32-point tiles take the small-launch shape
+
 #define LH_STAMP(k) \
     if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
 
@@ -37,14 +39,20 @@ constexpr int stage_tiles(int stage) { return stage == ST_FC1 || stage == ST_FC2
 // launch -- 1: weights loaded once, 2: no global stores (8 / 16 / 32 / 64: no Q / K / V / featB stores), 4: no partial /
 // residual loads.  profiles/r02_j_layer_knockout*.txt: all three off = 30 us of 181; loads 69, stores 54, weights 21.
 // FB_PF: featB leaves in point-fragment order (split_layout.h) instead of rows
-template <bool T, bool H, bool TRACE = false, int PIPE = 6, int EXP = 0, bool FB_PF = false>
-__global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a) {
-    __shared__ __attribute__((aligned(16))) float Vs_all[LW_WAVES][32 * LW_VLD];
+// NWV / NBUF (r03): wavefronts per workgroup and depth of the weight-chunk ring.  The default (4 waves, 2 buffers) is tuned
+// for launches with more tiles than the chip has SIMDs (several wavefronts per SIMD hide each other's L2 round trips).  With
+// fewer tiles (the per-GPU shares of the 8-GPU configurations: 4 pairs of N=5000 = 625 tiles on 1024 SIMDs) every wavefront
+// is alone on its SIMD and its chain is paced by the round trip of each 8 KiB chunk; 4-wave workgroups also leave 100 of the
+// 256 CUs idle while the busy ones pull 4 x 344 KiB through one L1.  The small-launch form: 1 or 2 waves per workgroup
+// (tiles spread over all CUs) and a ring of 3 or 4 chunks in flight (the register budget of a lone wavefront is 512).
+template <bool T, bool H, bool TRACE = false, int PIPE = 6, int EXP = 0, bool FB_PF = false, int NWV = LW_WAVES, int NBUF = 2>
+__global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(LayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float Vs_all[NWV][32 * LW_VLD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int tpp = ceil_div_dev(a.N, 32);                          // tiles per pair
-    const int gw = blockIdx.x * LW_WAVES + wave;                    // one wave = one tile
+    const int gw = blockIdx.x * NWV + wave;                         // one wave = one tile
     if (gw >= a.bs * tpp) return;                                    // (no workgroup barriers anywhere below)
     const int b = gw / tpp, tile = gw - b * tpp;
     const int m0 = b * a.N + tile * 32;
@@ -68,8 +76,11 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
     }
     LH_STAMP(0)
     constexpr int NCH = num_chunks<T, H>();
-    WChunk w[2];
-    load_chunk<T, true, true>(w[0], a, 0, lane);
+    WChunk w[NBUF];
+    static_for<0, NBUF - 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < NCH) load_chunk<T, true, true>(w[j], a, j, lane);
+    });
 
     // B operands (k-step kk: channels 16kk + 8h .. +7 of this lane's point) of fc1 | fc2 | fc3 | pcn (H3) and q|k|v (bf16)
     u32x4 a0h[8], a0l[8], a1h[4], a1l[4], a2h[4], a2l[4], ayh[8], ayl[8], xqh[8], xql[8];
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
     static_for<0, NCH>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr ChunkDesc d = chunk_desc<T>(i);
-        if constexpr (i + 1 < NCH && !((EXP & 1) && i >= 1)) load_chunk<T, true, true>(w[(i + 1) & 1], a, i + 1, lane);
+        if constexpr (i + NBUF - 1 < NCH && !((EXP & 1) && i >= 1)) load_chunk<T, true, true>(w[(i + NBUF - 1) % NBUF], a, i + NBUF - 1, lane);
         if constexpr (T && d.stage == ST_FC2 && d.tile == 0 && !(EXP & 4)) {
             // residual rows for fc3's epilogue (the fc1 operand is dead, its registers are free): they come from HBM
             const bool pf = a.io_flags & PDSC_IO_RES_PF;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_h3_kernel(LayerArgs a)
 #pragma unroll
             for (int q = 0; q < 16; ++q) y3[q] = *reinterpret_cast<const f32x4*>(r0 + eq * q);
         }
-        const WChunk& wc = w[i & 1];
+        const WChunk& wc = w[i % NBUF];
         if constexpr (d.chunk == 0) {
             // accumulator := bias, on the matrix pipe: one extra k-step whose A operand is the bias fragment (zero in the
             // second k slot) and whose B operand is 1 -- no VALU work, and C = 0 is an inline constant
@@ -351,12 +362,33 @@ bool launch_layer_h3_fits(const LayerArgs& a, bool tail, bool head) {
     return a.wf_tail || !tail;
 }
 
+// launch shape for `tiles` wavefront-tiles: (waves per workgroup, weight-ring depth), see the kernel's NWV / NBUF note
+static void h3_launch_shape(int tiles, int* nwv, int* nbuf) {
+    *nwv = LW_WAVES; *nbuf = 2;
+    if (tiles <= PDSC_H3_SMALL_TILES) { *nwv = tiles <= 512 ? 1 : 2; *nbuf = 3; }
+    const int force = env_int("PDSC_LAYER_H3_SHAPE", 0);          // A/B knob (experiments builds): 10 * waves + depth, e.g. 23
+    if (force == 42 || force == 23 || force == 13 || force == 24 || force == 14 || force == 22) { *nwv = force / 10; *nbuf = force % 10; }
+}
+
 int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     const int waves = a.bs * ceil_div(a.N, 32);
-    const dim3 grid(ceil_div(waves, LW_WAVES)), block(64 * LW_WAVES);
+    int nwv, nbuf;
+    h3_launch_shape(waves, &nwv, &nbuf);
+    const dim3 grid(ceil_div(waves, nwv)), block(64 * nwv);
     const bool fb_pf = a.io_flags & PDSC_IO_FEATB_PF;
+    const bool timed = tail && head;
+    if (timed) profile_mark_begin(PDSC_PROF_LAYER, st);
+    // every (tail, head, featB order) form in the default shape and in the small-launch shapes
+#define PDSC_H3_LAUNCH(TT, HH, PF)                                                                                                  \
+    do {                                                                                                                            \
+        if (nwv == 2 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 3>), grid, block, 0, st, a);      \
+        else if (nwv == 1 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 3>), grid, block, 0, st, a); \
+        else if (nwv == 2 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 4>), grid, block, 0, st, a); \
+        else if (nwv == 1 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 4>), grid, block, 0, st, a); \
+        else if (nwv == 2 && nbuf == 2) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 2>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF>), grid, block, 0, st, a);                                  \
+    } while (0)
     if (tail && head && fb_pf) {
-        profile_mark_begin(PDSC_PROF_LAYER, st);
 #ifdef PDSC_LAYER_DIAG      // knock-out build (PDSC_HIPCC_EXTRA=-DPDSC_LAYER_DIAG python -m pointdsc_amd.build --force; tools/layer_bench.py)
         const int ex = env_int("PDSC_LAYER_H3_EXP", 0);
         if (ex == 1) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 1, true>), grid, block, 0, st, a);
@@ -369,21 +401,19 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
         else if (ex == 64) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 64, true>), grid, block, 0, st, a);
         else
 #endif
-        hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 6, 0, true>), grid, block, 0, st, a);
-        profile_mark_end(PDSC_PROF_LAYER, st);
+        PDSC_H3_LAUNCH(true, true, true);
     } else if (head && !tail && fb_pf) {
-        hipLaunchKernelGGL((layer_h3_kernel<false, true, false, 6, 0, true>), grid, block, 0, st, a);
+        PDSC_H3_LAUNCH(false, true, true);
     } else if (tail && head) {
-        profile_mark_begin(PDSC_PROF_LAYER, st);
-        if (a.trace) hipLaunchKernelGGL((layer_h3_kernel<true, true, true>), grid, block, 0, st, a);
-        else if (env_int("PDSC_LAYER_H3_PIPE", 6) == 0) hipLaunchKernelGGL((layer_h3_kernel<true, true, false, 0>), grid, block, 0, st, a);   // A/B knob
-        else hipLaunchKernelGGL((layer_h3_kernel<true, true>), grid, block, 0, st, a);
-        profile_mark_end(PDSC_PROF_LAYER, st);
+        if (a.trace) hipLaunchKernelGGL((layer_h3_kernel<true, true, true>), dim3(ceil_div(waves, LW_WAVES)), dim3(64 * LW_WAVES), 0, st, a);
+        else PDSC_H3_LAUNCH(true, true, false);
     } else if (tail) {
-        hipLaunchKernelGGL((layer_h3_kernel<true, false>), grid, block, 0, st, a);
+        PDSC_H3_LAUNCH(true, false, false);
     } else {
-        hipLaunchKernelGGL((layer_h3_kernel<false, true>), grid, block, 0, st, a);
+        PDSC_H3_LAUNCH(false, true, false);
     }
+#undef PDSC_H3_LAUNCH
+    if (timed) profile_mark_end(PDSC_PROF_LAYER, st);
     return check_launch("pdsc_layer_fused_frag(h3)");
 }
 

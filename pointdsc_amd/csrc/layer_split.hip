@@ -19,6 +19,7 @@
 
 namespace pdsc {
 
+#ifdef PDSC_EXPERIMENTS      // the all-split layer kernel is an A/B record (r01: +3 % pairs/s at 3e-5 feature error): experiments builds only
 constexpr int LX_ROWS = 32;                         // points per workgroup
 constexpr int LX_XLD = PDSC_CHANNELS + 8;           // bf16 elements per activation row (272 B)
 constexpr int LX_FLD = PDSC_CHANNELS + 4;           // floats per staging row
@@ -275,6 +276,8 @@ static int launch_layer_x3(const LayerX3Args& a, hipStream_t st) {
     return check_launch("pdsc_layer_fused_x3");
 }
 
+#endif  // PDSC_EXPERIMENTS
+
 // fp32 weight matrix [n] -> bf16 hi [n] | bf16 lo [n]
 __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -358,6 +361,12 @@ extern "C" int pdsc_layer_fused_x3(const float* msg, const float* part_o, const 
                                    void* q_split, void* kv_tiles, const void* w1, const float* b1, const void* w2,
                                    const float* b2, const void* w3, const float* b3, const void* wp, const float* bp,
                                    const void* wq, const float* bq, int bs, int N, void* stream) {
+#ifndef PDSC_EXPERIMENTS
+    (void)msg; (void)part_o; (void)part_ml; (void)nsplit; (void)Npad; (void)res; (void)feat_in; (void)feat_out; (void)featB_out; (void)qkv_out;
+    (void)q_split; (void)kv_tiles; (void)w1; (void)b1; (void)w2; (void)b2; (void)w3; (void)b3; (void)wp; (void)bp; (void)wq; (void)bq; (void)bs; (void)N; (void)stream;
+    set_error("pdsc_layer_fused_x3: the all-split layer kernel exists in experiments builds only (python -m pointdsc_amd.build --experiments)");
+    return PDSC_ERR_ARG;
+#else
     const bool tail = msg != nullptr || part_o != nullptr, head = featB_out != nullptr;
     PDSC_REQUIRE(tail || head, "pdsc_layer_fused_x3: neither tail (msg / partials) nor head (featB_out) requested");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_layer_fused_x3: bs=%d N=%d", bs, N);
@@ -382,4 +391,5 @@ extern "C" int pdsc_layer_fused_x3(const float* msg, const float* part_o, const 
     if (tail && head) return launch_layer_x3<true, true>(a, st);
     if (tail) return launch_layer_x3<true, false>(a, st);
     return launch_layer_x3<false, true>(a, st);
+#endif
 }

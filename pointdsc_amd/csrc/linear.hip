@@ -111,32 +111,38 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
     }
 }
 
-// encoder.layer0: in_dim (<=8) inputs -> C channels, pure VALU (K=6 is too thin for MFMA); bound by the 512 B per point it
-// writes.  A thread keeps its 4 channels' weights (4 x 8 + bias) in registers and walks its share of the rows: per row
-// in_dim broadcast loads, 32 FMAs, one 16-byte store (a wave instruction stores 2 whole rows).
+// encoder.layer0: in_dim (<= 16: the reference's data loaders build 6-, 9- and 12-column inputs, datasets/ThreeDMatch.py:299-312)
+// inputs -> C channels, pure VALU (K = 6 is too thin for MFMA); bound by the 512 B per point it writes.  A thread keeps its 4
+// channels' weights (4 x KD + bias, rows of the packed matrix are 16 floats apart) in registers and walks its share of the
+// rows: per row in_dim broadcast loads, 4 KD FMAs, one 16-byte store (a wave instruction stores 2 whole rows).
 constexpr int L0_MAX_BLOCKS = 2048;
+constexpr int L0_LD = 16;            // floats per row of PDSC_W_LAYER0_W
+template <int KD>
 __global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ corr, int in_dim,
                                                      const float* __restrict__ W0, const float* __restrict__ b0,
                                                      float* __restrict__ feat, int M) {
     const int c4 = (threadIdx.x & 31) * 4, rl = threadIdx.x >> 5;        // 32 channel groups x 8 row lanes, grid-stride over rows
-    float w[4][8], bias[4];
+    float w[4][KD], bias[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(W0 + (c4 + c) * 8), hi = *reinterpret_cast<const f32x4*>(W0 + (c4 + c) * 8 + 4);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) { w[c][d] = lo[d]; w[c][4 + d] = hi[d]; }
+        for (int d4 = 0; d4 < KD; d4 += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(W0 + (c4 + c) * L0_LD + d4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w[c][d4 + d] = v[d];
+        }
         bias[c] = b0[c4 + c];
     }
     for (long long row = (long long)blockIdx.x * 8 + rl; row < M; row += (long long)gridDim.x * 8) {
-        float x[8];
+        float x[KD];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) x[d] = d < in_dim ? corr[row * in_dim + d] : 0.f;
+        for (int d = 0; d < KD; ++d) x[d] = d < in_dim ? corr[row * in_dim + d] : 0.f;
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) s = fmaf(x[d], w[c][d], s);      // same chain as before: bit-identical results
+            for (int d = 0; d < KD; ++d) s = fmaf(x[d], w[c][d], s);     // one chain in column order (KD = 8: the r02 results, bit for bit)
             o[c] = s + bias[c];
         }
         *reinterpret_cast<f32x4*>(feat + row * PDSC_CHANNELS + c4) = o;
@@ -314,9 +320,11 @@ extern "C" int pdsc_linear(const float* X, long long ldx, const float* W, const 
 extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat, int M,
                            void* stream) {
     PDSC_REQUIRE(corr_pos && W0 && b0 && feat, "pdsc_layer0: null pointer");
-    PDSC_REQUIRE(in_dim >= 1 && in_dim <= 8 && M > 0, "pdsc_layer0: in_dim=%d M=%d", in_dim, M);
+    PDSC_REQUIRE(in_dim >= 1 && in_dim <= 16 && M > 0, "pdsc_layer0: in_dim=%d (1..16) M=%d", in_dim, M);
     const int blocks = pdsc::ceil_div(M, 8) < pdsc::L0_MAX_BLOCKS ? pdsc::ceil_div(M, 8) : pdsc::L0_MAX_BLOCKS;
-    hipLaunchKernelGGL(pdsc::layer0_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       corr_pos, in_dim, W0, b0, feat, M);
+    if (in_dim <= 8)
+        hipLaunchKernelGGL(pdsc::layer0_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, corr_pos, in_dim, W0, b0, feat, M);
+    else
+        hipLaunchKernelGGL(pdsc::layer0_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, corr_pos, in_dim, W0, b0, feat, M);
     return pdsc::check_launch("pdsc_layer0");
 }

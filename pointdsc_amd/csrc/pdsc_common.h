@@ -31,12 +31,20 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 void profile_mark_begin(int kind, hipStream_t st);
 void profile_mark_end(int kind, hipStream_t st);
 
-// Tuning / A-B knobs are environment variables read on EVERY call (no value is cached in the library; the shipped
-// behaviour is the default): PDSC_* names are listed in DESIGN.md.
+// Tuning / A-B knobs (PDSC_* environment variables, listed in DESIGN.md) exist in EXPERIMENTS builds only
+// (-DPDSC_EXPERIMENTS: libpointdsc_hip_exp.so, built by `python -m pointdsc_amd.build --experiments` for tools/ab_*.py).  In
+// the product library env_int / env_str return the default without looking at the environment: nothing outside
+// pdsc_config can change what a drop-in module computes or which kernel it runs.
+#ifdef PDSC_EXPERIMENTS
 static inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+static inline const char* env_str(const char* name) { return getenv(name); }
+#else
+static inline int env_int(const char*, int dflt) { return dflt; }
+static inline const char* env_str(const char*) { return nullptr; }
+#endif
 
 // The smallest fp32 x with sqrtf(x) >= thr (host sqrtf is correctly rounded, like the device's): since the correctly
 // rounded square root is monotone, `sqrt(x) >= thr` <=> `x >= x*` and `sqrt(x) < thr` <=> `x < x*`, bit for bit -- lets

@@ -90,8 +90,8 @@ constexpr int GRID_MAX = 64;
 struct NmsGridHeader { float xmin, ymin, inv_unused0, inv_unused1, wx, wy; int nbx, nby; };
 static_assert(sizeof(NmsGridHeader) == 32, "header layout");
 __device__ __forceinline__ int grid_cell_1d(float v, float vmin, float w, int nb) {
-    const int c = (int)floorf((v - vmin) / w);
-    return c < 0 ? 0 : (c >= nb ? nb - 1 : c);
+    const float q = floorf((v - vmin) / w);
+    return q >= 0.f ? (q < (float)nb ? (int)q : nb - 1) : 0;      // NaN -> cell 0 (only converted when finite and in range)
 }
 static size_t nms_ws_pair_bytes(int N) {
     return (size_t)round_up((long long)N * 16 + (long long)N * 4 + (GRID_MAX * GRID_MAX + 1) * 4 + sizeof(NmsGridHeader), 256);
@@ -111,9 +111,11 @@ __global__ __launch_bounds__(1024) void nms_grid_kernel(const float* __restrict_
     int* cell_start = reinterpret_cast<int*>(w + (size_t)N * 20);
     NmsGridHeader* hout = reinterpret_cast<NmsGridHeader*>(w + (size_t)N * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
     float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
+    int bad = 0;          // a NaN / Inf coordinate: its distances are NaN / Inf for EVERY partner, the window argument does not hold
     for (int i = t; i < N; i += 1024) {
-        const float x = s[i * 3], y = s[i * 3 + 1];
+        const float x = s[i * 3], y = s[i * 3 + 1], z = s[i * 3 + 2];
         xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
+        bad |= !(fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(1024) void nms_grid_kernel(const float* __restrict_
     }
     if (lane == 0) { red[0][wave] = xmn; red[1][wave] = xmx; red[2][wave] = ymn; red[3][wave] = ymx; }
     for (int i = t; i <= GRID_MAX * GRID_MAX; i += 1024) cells[i] = 0;
-    __syncthreads();
+    const int any_bad = __syncthreads_or(bad);
     if (t == 0) {
         for (int k = 1; k < 16; ++k) {
             red[0][0] = fminf(red[0][0], red[0][k]); red[1][0] = fmaxf(red[1][0], red[1][k]);
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(1024) void nms_grid_kernel(const float* __restrict_
         const float rm = radius * 1.001f;
         const float rx = red[1][0] - red[0][0], ry = red[3][0] - red[2][0];
         int nbx = (int)fminf(floorf(rx / rm), (float)GRID_MAX), nby = (int)fminf(floorf(ry / rm), (float)GRID_MAX);
-        if (!(nbx >= 1)) nbx = 1;
-        if (!(nby >= 1)) nby = 1;
+        if (!(nbx >= 1) || any_bad) nbx = 1;                 // non-finite input: one cell = every pair evaluated, as the N^2 kernel does
+        if (!(nby >= 1) || any_bad) nby = 1;
         hdr.xmin = red[0][0]; hdr.ymin = red[2][0]; hdr.nbx = nbx; hdr.nby = nby;
         hdr.wx = nbx > 1 ? rx / (float)nbx : 1.0f;            // >= rm by construction (nbx <= rx / rm); one cell: any width
         hdr.wy = nby > 1 ? ry / (float)nby : 1.0f;

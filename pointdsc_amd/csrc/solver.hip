@@ -151,7 +151,6 @@ __global__ __launch_bounds__(64 * SV_WAVES) void seed_solve_kernel(const float* 
     for (int I = 0; I < NB; ++I) {
 #pragma unroll
         for (int J = I; J < NB; ++J) {
-            if (16 * J >= k) continue;                    // wave-uniform: tile entirely beyond k
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 8; ++q)

@@ -91,11 +91,19 @@ __global__ __launch_bounds__(256) void sm_matvec_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[r][e] = 0.f;
         }
-        for (int j = lane * 4; j < ld; j += 256) {
+        // columns >= N never enter the sums: a caller's padding columns [N, ld) may hold anything (0 * NaN would poison a row)
+        const int n4 = (N + 3) & ~3;                                // <= ld (ld is a multiple of 4)
+        for (int j = lane * 4; j < n4; j += 256) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(vs + j);
             f32x4 m[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) m[r] = *reinterpret_cast<const f32x4*>(row[r] + j);
+            if (j + 4 > N) {                                        // the one ragged group of the row
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[r][e] = j + e < N ? m[r][e] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll

@@ -84,10 +84,11 @@ class PointDSC(nn.Module):
         if num_channels != _NUM_CHANNELS:
             raise ValueError(f"pointdsc_amd supports num_channels={_NUM_CHANNELS} (the released models); got {num_channels}")
         # limits of the HIP path (include/pointdsc_hip.h), checked here so that they do not surface at the first forward:
-        # the first conv is packed with 8 input columns (the released models use in_dim = 6; the reference's in_dim 9 / 12
-        # variants, datasets/ThreeDMatch.py:299-312, are not supported), one wavefront lane per neighbour, at most 32 power iterates kept
-        if not 1 <= in_dim <= 8:
-            raise ValueError(f"pointdsc_amd supports 1 <= in_dim <= 8 (released models: 6); got {in_dim}")
+        # the first conv is packed with 16 input columns (the released models use in_dim = 6; the reference's data loaders
+        # also build 9- and 12-column inputs, datasets/ThreeDMatch.py:299-312), one wavefront lane per neighbour, at most 32
+        # power iterates kept
+        if not 1 <= in_dim <= 16:
+            raise ValueError(f"pointdsc_amd supports 1 <= in_dim <= 16 (released models: 6); got {in_dim}")
         if not 1 <= k <= 64:
             raise ValueError(f"pointdsc_amd supports 1 <= k <= 64 neighbours per seed (released models: 40); got {k}")
         if not 0 <= num_iterations <= 32:
@@ -114,19 +115,19 @@ class PointDSC(nn.Module):
         # Not a reference constructor argument (the signature stays the reference's): arithmetic of the two
         # attention contractions.  "bf16x3" = split-precision bf16 MFMA (default; features within 5e-6 of fp32),
         # "fp32" = exact fp32 MFMA, "bf16x3_all" = the point-wise GEMMs in split precision too (features within 2e-5).
-        # Set the attribute (or POINTDSC_ATTENTION_PRECISION) before calling forward.
-        self.attention_precision = os.environ.get("POINTDSC_ATTENTION_PRECISION", "bf16x3")
+        # Module attributes only -- neither the module nor the library reads the environment.  Set before calling forward.
+        self.attention_precision = "bf16x3"
         # storage of the N x N spatial-consistency matrix between its build and the attention launches (split-precision
         # modes): "u16" = unorm16 (|error| <= 7.6e-6; default): half the workspace and HBM stream, 4.6 % more pairs/s at
         # N=5000 (tools/ab_forward.py), features as close to the exact-fp32 path as with "f32" (2e-6), parity census
         # over every pair of the bench workloads equal to "f32"'s; "f32" = the reference's fp32
         # matrix, bit-exact
-        self.compat_format = os.environ.get("POINTDSC_COMPAT_FORMAT", "u16")
+        self.compat_format = "u16"
         # arithmetic of the fc_message / PointCN GEMMs in the fused layer kernel (enum pdsc_layer_gemm): "h3" = fp16 hi /
         # scaled-lo split on the f16 matrix cores (default: ~2^-21 per product, measured closer to the fp64 chain than the
         # fp32 MFMA's own round-off; with it the attention -> layer -> layer hand-offs go in point-fragment order);
         # "f32" = v_mfma_f32_32x32x2_f32
-        self.layer_gemm = os.environ.get("POINTDSC_LAYER_GEMM", "h3")
+        self.layer_gemm = "h3"
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
@@ -199,7 +200,7 @@ class PointDSC(nn.Module):
 
         c = self.num_channels
         w0, b0 = _fold_bn(self.encoder.layer0, None)
-        w0p = torch.zeros(c, 8, dtype=torch.float64, device=w0.device)
+        w0p = torch.zeros(c, 16, dtype=torch.float64, device=w0.device)
         w0p[:, :self.in_dim] = w0
         put("LAYER0_W", 0, w0p)
         put("LAYER0_B", 0, b0)

@@ -70,7 +70,8 @@ def spatial_compat(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spa
 
 
 @_on_device
-def spatial_compat_u16(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spat: torch.Tensor) -> torch.Tensor:
+def spatial_compat_u16(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma_spat: torch.Tensor,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[bs,N,3] x2 -> unorm16 compat [bs,N,ld] (int16 storage of uint16 bits) in the attention kernel's tile order
     (pdsc_spatial_compat_u16); decode with `decode_compat_u16`."""
     lib = _lib.load()
@@ -78,7 +79,8 @@ def spatial_compat_u16(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, sigma
     sig = _chk(sigma_spat.reshape(-1), "sigma_spat")
     bs, n = src.shape[0], src.shape[1]
     ld = compat_ld(n)
-    out = torch.empty(bs, n, ld, device=src.device, dtype=torch.int16)
+    if out is None:
+        out = torch.empty(bs, n, ld, device=src.device, dtype=torch.int16)
     _lib.check(lib.pdsc_spatial_compat_u16(_p(src), _p(tgt), _p(sig), _p(out), ld, bs, n, _stream()), "pdsc_spatial_compat_u16")
     return out
 

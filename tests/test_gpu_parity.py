@@ -24,6 +24,10 @@ KW = dict(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.
           sigma_d=0.10, k=40, nms_radius=0.10)
 ORACLE_KEYS = ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")
 QSCALE = float(np.log2(np.e) / np.sqrt(128.0))
+# A/B record kernels and PDSC_* environment knobs exist in experiments builds only (POINTDSC_HIP_LIB=.../libpointdsc_hip_exp.so)
+EXPERIMENTS = bool(_lib.load().pdsc_experiments_enabled())
+needs_experiments = pytest.mark.skipif(not EXPERIMENTS, reason="experiments builds only (python -m pointdsc_amd.build --experiments)")
+PRECISIONS = ["bf16x3", "fp32", pytest.param("bf16x3_all", marks=needs_experiments)]
 
 
 def g(t):
@@ -112,9 +116,12 @@ def test_spatial_compat_batched_and_kitti_scale():
 
 @pytest.mark.parametrize("n,bs,scale,sigma", [(33, 1, 3.0, 0.1), (257, 2, 3.0, 0.1), (1000, 3, 3.0, 0.1), (5000, 2, 3.0, 0.1),
                                                 (3000, 1, 60.0, 1.2), (10000, 1, 3.0, 0.1)])
-def test_spatial_compat_u16_is_the_rounded_fp32_matrix(n, bs, scale, sigma):
-    """pdsc_spatial_compat_u16 (the matrix the split-precision attention streams): u = round(compat * 65535) of the
-    bit-exact fp32 matrix, in the attention kernel's tile order; 0 and 1 exact; symmetric; padding columns zero."""
+def test_spatial_compat_u16_tracks_the_fp32_matrix(n, bs, scale, sigma):
+    """pdsc_spatial_compat_u16 (the matrix the split-precision attention streams), r03 contract: u = round(c * 65535) with c
+    evaluated on the hardware's 1-ulp sqrt (packed fp32 math), in the attention kernel's tile order.  Against the bit-exact
+    fp32 matrix c32 of pdsc_spatial_compat: |u - round(c32 * 65535)| <= 2 units (bound: 2 (ulp(d_src) + ulp(d_tgt)) |d_src -
+    d_tgt| / sigma^2 * 65535 + the rounding, DESIGN.md section 4), equal to it on the overwhelming majority of the entries;
+    diagonal exactly 65535; entries that are clamped to 0 with a margin are exactly 0; symmetric bit for bit; padding zero."""
     batch = synthetic.make_batch(bs, n, seed=40 + n, scale=scale, noise=scale / 300.0)
     src, tgt, sig = g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([sigma]))
     c32 = ops.spatial_compat(src, tgt, sig)[:, :, :n]
@@ -124,11 +131,20 @@ def test_spatial_compat_u16_is_the_rounded_fp32_matrix(n, bs, scale, sigma):
     dec = ops.decode_compat_u16(c16, n)
     want = torch.round(c32.double() * 65535.0)
     got = torch.round(dec.double() * 65535.0)
-    assert float((got - want).abs().max()) <= 1.0                       # rounding of x*65535 in fp32 inside the instruction
-    assert float(((got - want).abs() > 0).float().mean()) < 1e-3        # ... differs from the fp64 rounding on ties only
-    assert float((dec - c32).abs().max()) <= 0.5 / 65535 + 1e-7
-    assert torch.equal(dec == 0, c32 < 0.5 / 65535) or float(((dec == 0) != (c32 < 0.5 / 65535)).float().mean()) < 1e-5
-    assert bool((dec[c32 == 1.0] == 1.0).all()) and bool((dec[c32 == 0.0] == 0.0).all())
+    diff = (got - want).abs()
+    assert float(diff.max()) <= 2.0
+    nz = want > 0
+    if bool(nz.any()):
+        assert float((diff[nz] > 0).float().mean()) < 0.05      # expected: a few % of the non-zero entries, by one unit
+    assert float((diff > 1).float().mean()) < 1e-4
+    assert float((dec - c32).abs().max()) <= 2.5 / 65535
+    # unclamped value in fp64: entries below -4e-5 (two units and the fp32 round-off away from the clamp) are exactly zero
+    sd = (batch["src_keypts"].double()[:, :, None] - batch["src_keypts"].double()[:, None]).norm(dim=-1)
+    td = (batch["tgt_keypts"].double()[:, :, None] - batch["tgt_keypts"].double()[:, None]).norm(dim=-1)
+    c64 = (1.0 - (sd - td) ** 2 / float(torch.tensor(sigma, dtype=torch.float32) ** 2)).to(DEV)
+    assert int((dec[c64 < -4e-5] != 0).sum()) == 0
+    assert bool((torch.diagonal(got, dim1=1, dim2=2) == 65535).all())
+    assert bool((got[c32 == 1.0] == 65535).all())
     assert torch.equal(dec, dec.transpose(1, 2))
     # columns >= N of the padded rows (tile order keeps them inside their own 32-group): all zero
     j = torch.arange(ops.compat_ld(n), device=DEV)
@@ -161,11 +177,42 @@ def test_linear_matches_fp64(m, k, nout, relu, res):
 def test_layer0_matches_oracle():
     c = case(1000)
     sd = c["sd"]
-    w0 = torch.zeros(128, 8)
+    w0 = torch.zeros(128, 16)
     w0[:, :6] = sd["encoder.layer0.weight"][:, :, 0]
     y = ops.layer0(g(c["pair"]["corr_pos"]), g(w0), g(sd["encoder.layer0.bias"])).cpu()
     want = (sd["encoder.layer0.weight"][:, :, 0] @ c["pair"]["corr_pos"][0].T + sd["encoder.layer0.bias"][:, None]).T
     assert (y - want).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("in_dim", [1, 8, 9, 12, 16])
+def test_layer0_wide_inputs(in_dim):
+    """encoder.layer0 for the reference's other input widths (datasets/ThreeDMatch.py:299-312 builds 6, 9 and 12 columns)."""
+    gen = torch.Generator().manual_seed(in_dim)
+    x = torch.randn(777, in_dim, generator=gen)
+    w = torch.randn(128, in_dim, generator=gen) / in_dim ** 0.5
+    b = torch.randn(128, generator=gen)
+    w0 = torch.zeros(128, 16)
+    w0[:, :in_dim] = w
+    y = ops.layer0(g(x), g(w0), g(b)).cpu()
+    want = (x.double() @ w.double().T + b.double())
+    assert (y.double() - want).abs().max() < 2e-6
+
+
+def test_forward_with_twelve_input_columns():
+    """in_dim = 12 end to end (the reference's 'in_dim == 12' branch concatenates normals): same stages, wider first conv."""
+    kw = dict(KW, in_dim=12, num_layers=3)
+    model = PointDSC(**kw)
+    sd = synthetic.make_state_dict(model.state_dict(), seed=3)
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    pair = synthetic.make_pair(600, inlier_ratio=0.4, seed=5)
+    gen = torch.Generator().manual_seed(1)
+    corr12 = torch.cat([pair["corr_pos"], torch.randn(1, 600, 6, generator=gen) * 0.1], dim=-1)
+    res = model({"corr_pos": g(corr12), "src_keypts": g(pair["src_keypts"]), "tgt_keypts": g(pair["tgt_keypts"]), "testing": True})
+    ref = O.forward_testing(sd, corr12, pair["src_keypts"], pair["tgt_keypts"],
+                            **{k: kw[k] for k in ("num_layers", "num_channels", "num_iterations", "ratio", "inlier_threshold", "k", "nms_radius")})
+    assert int((res["final_labels"].cpu() != ref["final_labels"]).sum()) == 0
+    assert float((res["final_trans"].cpu() - ref["final_trans"]).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("m", [1, 31, 32, 33, 1000])
@@ -298,6 +345,7 @@ def test_layer_fused_split_emits_the_streams_of_its_own_qkv(n, bs):
     assert none_qkv is None and torch.equal(qs2, qs) and torch.equal(kv2, kv)
 
 
+@needs_experiments
 @pytest.mark.parametrize("n,bs", [(1, 1), (31, 1), (33, 2), (1000, 1)])
 def test_layer_fused_x3_matches_fp64_chain(n, bs):
     """Split-precision fused chain (tail+head, head only, tail only) vs the five GEMMs in fp64; its streams are exactly
@@ -381,6 +429,7 @@ def test_layer_fused_frag_streams_match_natural_weights(n, bs):
     assert (d(q1) - qkv).abs().max() < 4e-5 * max(1.0, float(qkv.abs().max()))
 
 
+@needs_experiments
 @pytest.mark.parametrize("n,bs,nsplit", [(257, 1, 2), (1000, 2, 3), (300, 3, 4)])
 def test_layer_fused_x3_merges_attention_partials(n, bs, nsplit):
     """Un-merged key-split partials fed to the layer kernel == merged msg fed to it (the merge arithmetic is the
@@ -632,10 +681,12 @@ def test_point_fragment_hand_offs_reproduce_the_row_order_chain(n, bs, nsplit):
 @pytest.mark.parametrize("fmt", ["f32", "u16"])
 @pytest.mark.parametrize("n,bs,nsplit", [(5000, 13, 2), (4100, 16, 2), (2053, 32, 2)])
 def test_persistent_attention_writes_the_same_partials(n, bs, nsplit, fmt, monkeypatch):
-    """PDSC_ATT_PERSIST=1: one workgroup per CU walks its (pair, key split, query block) items, the run-ahead loads of an
+    """(experiments builds only: POINTDSC_HIP_LIB=pointdsc_amd/libpointdsc_hip_exp.so)  PDSC_ATT_PERSIST=1: one workgroup per CU walks its (pair, key split, query block) items, the run-ahead loads of an
     item's last tiles fetching the next item's first tiles.  Same arithmetic per item: the point-fragment partials (O and
     (m, l)) must be the one-item-per-workgroup kernel's bit for bit -- uneven item counts per workgroup, ragged last query
     blocks (other compat row clamp from one item to the next), both compat formats."""
+    if not _lib.load().pdsc_experiments_enabled():
+        pytest.skip("the persistent form is an A/B record: experiments builds only")
     gen = torch.Generator().manual_seed(600 + n)
     batch = synthetic.make_batch(bs, n, seed=11 + n)
     sig = g(torch.tensor([0.1]))
@@ -695,27 +746,29 @@ def test_layer_fused_frag_h3_merges_attention_partials(n, bs, nsplit):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("n", [1000, 2053])
-def test_layer_gemm_h3_agrees_with_fp32_gemms_through_the_encoder(n, monkeypatch):
-    """model.layer_gemm = "h3" vs "f32" through the 12 layers on the wavefront-resident layer kernel (forced: single pairs
-    of this size default to the workgroup-per-tile kernel, which has no H3 form): features within 2e-6, same seeds,
-    labels, R/t within 1e-5."""
-    monkeypatch.setenv("PDSC_LAYER_VARIANT", "w")
+@pytest.mark.parametrize("n,bs", [(1000, 10), (2053, 5)])
+def test_layer_gemm_h3_agrees_with_fp32_gemms_through_the_encoder(n, bs):
+    """model.layer_gemm = "h3" vs "f32" through the 12 layers on the wavefront-resident layer kernels (batches large enough
+    that the size rule does not pick the workgroup-per-tile kernel, which has no H3 form): features within 2e-6, same seeds."""
+    assert _lib.load().pdsc_layer_prefers_block(bs, n) == 0
     c = case(n)
     model = c["model"]
+    batch = synthetic.make_batch(bs, n, seed=21, inlier_ratio=0.3)
+    s_per = int(n * 0.1)
     out = {}
     for gemm in ("f32", "h3"):
         model.layer_gemm = gemm
-        res = _forward(model, c["pair"])
-        out[gemm] = (model.workspace_view("featA", 1, n)[: n * 128].reshape(n, 128).cpu().clone(),
-                     model.workspace_view("seeds", 1, n, torch.int32)[: int(n * 0.1)].cpu().clone(), res)
+        res = _forward(model, batch)
+        out[gemm] = (model.workspace_view("featA", bs, n)[: bs * n * 128].reshape(bs * n, 128).cpu().clone(),
+                     model.workspace_view("seeds", bs, n, torch.int32)[: bs * s_per].cpu().clone(), res)
     model.layer_gemm = LAYER_GEMM_DEFAULT
     scale = max(1.0, float(out["f32"][0].abs().max()))
     err = float((out["f32"][0] - out["h3"][0]).abs().max()) / scale
     print(f"feature difference h3 vs f32 GEMMs: {err:.2e}")
     assert err < 2e-6
     assert not torch.equal(out["f32"][0], out["h3"][0]), "the H3 path did not run"
-    assert set(out["f32"][1].tolist()) == set(out["h3"][1].tolist())
+    for i in range(bs):
+        assert set(out["f32"][1][i * s_per:(i + 1) * s_per].tolist()) == set(out["h3"][1][i * s_per:(i + 1) * s_per].tolist())
     assert torch.equal(out["f32"][2]["final_labels"], out["h3"][2]["final_labels"])
     assert (out["f32"][2]["final_trans"] - out["h3"][2]["final_trans"]).abs().max() < 1e-5
 
@@ -727,7 +780,8 @@ def test_split_and_fp32_attention_agree_through_the_encoder(n):
     c = case(n)
     model = c["model"]
     out = {}
-    for prec, fmt in (("fp32", "f32"), ("bf16x3", "u16"), ("bf16x3", "f32"), ("bf16x3_all", "u16")):
+    modes = (("fp32", "f32"), ("bf16x3", "u16"), ("bf16x3", "f32")) + ((("bf16x3_all", "u16"),) if EXPERIMENTS else ())
+    for prec, fmt in modes:
         model.attention_precision, model.compat_format = prec, fmt
         res = _forward(model, c["pair"])
         out[prec if fmt == "u16" or prec == "fp32" else prec + "_f32compat"] = (
@@ -736,7 +790,7 @@ def test_split_and_fp32_attention_agree_through_the_encoder(n):
     model.attention_precision, model.compat_format = "bf16x3", COMPAT_FORMAT_DEFAULT
     scale = max(1.0, float(out["fp32"][0].abs().max()))
     print("feature error vs fp32:", {k: float((out["fp32"][0] - v[0]).abs().max()) / scale for k, v in out.items()})
-    for prec, tol in (("bf16x3", 8e-6), ("bf16x3_f32compat", 8e-6), ("bf16x3_all", 3e-5)):
+    for prec, tol in (("bf16x3", 8e-6), ("bf16x3_f32compat", 8e-6)) + ((("bf16x3_all", 3e-5),) if EXPERIMENTS else ()):
         assert (out["fp32"][0] - out[prec][0]).abs().max() < tol * scale, prec
         # same seed SET (two seeds whose confidence differs by less than the feature tolerance may swap ranks)
         assert set(out["fp32"][1].tolist()) == set(out[prec][1].tolist()), prec
@@ -747,7 +801,7 @@ def test_split_and_fp32_attention_agree_through_the_encoder(n):
 # ------------------------------------------------------------------------------------------------------
 # encoder end to end (a-2 + a-3 chained over 12 layers) and a-4
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_all"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("n", [257, 1000])
 def test_encoder_and_head_match_oracle(n, precision):
     c = case(n)
@@ -996,7 +1050,7 @@ def _forward(model, pair_or_batch):
     return res
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_all"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("n", [257, 1000, 2053])
 def test_forward_matches_oracle(n, precision):
     c = case(n)
@@ -1010,7 +1064,7 @@ def test_forward_matches_oracle(n, precision):
     assert re < 1.0 and te < 5.0
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_all"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["n257_s0", "n1000_s1", "n1000_s2_defaultbn", "n2053_s3", "kitti_n1500_s4", "n5000_s5",
                                   "kitti_n5000_s8", "lomatch_n10000_s7"])
 def test_forward_matches_reference_golden(name, precision):
@@ -1103,10 +1157,10 @@ def test_bench_workload_matches_reference_golden(name, bs):
     flips = int((res["final_labels"][:g_pairs].cpu() != want_lab[:g_pairs]).sum())
     dT = (res["final_trans"][:g_pairs].cpu() - want_T[:g_pairs]).abs().amax(dim=(1, 2))
     assert flips == 0, f"{flips} label flips vs the reference"
-    # pairs on which the reference's own fp32 and fp64 runs disagree (> 2e-5: a discrete near-tie decides the pose) are
-    # flagged by the fixture generator and held to 1e-3; every other pair to the 1e-4 of BASELINE.json
-    tol = torch.where(torch.from_numpy(fx["stable"][:g_pairs]), 1e-4, 1e-3)
-    assert bool((dT < tol).all()), (dT.tolist(), fx["stable"].tolist())
+    assert bool((dT < 1e-4).all()), dT.tolist()            # all golden pairs of the bench workloads are stable in the reference
+    # ... and EVERY pair of the batch against the census fixture (reference fp32 and fp64 outputs of the same pairs)
+    ok, d32, dbest, f32, which = _census_judge(res["final_trans"], res["final_labels"], _census_fixture(name), n)
+    assert bool(ok.all()), (np.flatnonzero(~ok.numpy()).tolist(), d32.tolist())
     # every pair of the batch, golden or not, must register (well-conditioned workload) and be a rigid motion
     T = res["final_trans"].cpu().double()
     assert (T[:, :3, :3] @ T[:, :3, :3].transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5
@@ -1115,28 +1169,56 @@ def test_bench_workload_matches_reference_golden(name, bs):
         assert re < 1.0 and te < (60.0 if "kitti" in name else 5.0), (i, re, te)
 
 
-@pytest.mark.parametrize("gemm", ["f32", "h3"])
-@pytest.mark.parametrize("name", ["n5000_b32", "kitti_n5000_b16", "lomatch_n10000_b8", "n1000_b1"])
-def test_bench_workload_census_every_pair_matches_the_reference(name, gemm):
-    """The WHOLE batch bench.py times, every pair against the unmodified reference (census fixtures
-    tests/golden/bench_<name>_all.npz = `oracle/make_bench_goldens.py --all`: 32 + 16 + 8 + 1 pairs): inlier masks bit-exact
-    on every pair, R/t within 1e-4 on every pair the reference itself reproduces between fp32 and fp64 (2 of the 57 pairs
-    sit at 7e-5 / 9e-5 in the reference's own comparison and are held to 1e-3)."""
+_CENSUS = {}
+
+
+def _census_fixture(name):
+    if name not in _CENSUS:
+        _CENSUS[name] = np.load(GOLDEN / f"census_{name}.npz", allow_pickle=False)
+    return _CENSUS[name]
+
+
+def _census_judge(trans, labels, fx, n, first=0):
+    """tools/parity_census.py:judge -- the contract of BASELINE.json with no looser tolerance for any pair: labels bit-exact
+    and R/t within 1e-4 of the reference's fp32 output, or (pairs on which the reference's own two precisions land on
+    different hypotheses) of its fp64 output."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("parity_census", ROOT / "tools" / "parity_census.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.judge(trans, labels, fx, n, first)
+
+
+@pytest.mark.parametrize("gemm", ["h3", "f32"])
+@pytest.mark.parametrize("name,step", [("n5000_b32", 32), ("n5000_b32", 4), ("kitti_n5000_b16", 16), ("kitti_n5000_b16", 2),
+                                       ("lomatch_n10000_b8", 8), ("lomatch_n10000_b8", 1), ("n1000_b1", 1), ("n1000_b1", 16)])
+def test_parity_census(name, step, gemm):
+    """Parity census (r03): 256 seeded pairs per workload family (64 at N = 10 000), pair i = the bench workload's pair i,
+    run in batches of the bench's global batch and of its 8-GPU share, with both layer-GEMM arithmetics: EVERY pair must
+    meet the contract against the unmodified reference (oracle/make_census_goldens.py: its fp32 output, or its fp64 output
+    where the reference itself lands on another hypothesis) -- no 1e-3 escape, no seed selection."""
     model, _ = _bench_model(name)
-    fx = np.load(GOLDEN / f"bench_{name}_all.npz", allow_pickle=False)
-    w = workloads.WORKLOADS[name]
-    n, bs = w["num_corr"], w["global_batch"]
-    assert fx["ref_final_trans"].shape[0] == bs
-    model.layer_gemm = gemm           # arithmetic of the fc_message / PointCN GEMMs (enum pdsc_layer_gemm), both held to the bar
+    fx = _census_fixture(name)
+    n = workloads.WORKLOADS[name]["num_corr"]
+    total = fx["ref32_final_trans"].shape[0]
+    model.layer_gemm = gemm
+    T, L = [], []
     try:
-        res = _forward(model, workloads.batch(name, 0, bs))
+        for first in range(0, total, step):
+            batch = workloads.batch(name, first, min(step, total - first))
+            if first == 0:
+                chk = sum(float(batch[k][0].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts"))
+                assert abs(chk - float(fx["input_checksum"][0])) < 1e-6, "synthetic inputs differ from the fixture's"
+            res = _forward(model, batch)
+            T.append(res["final_trans"].cpu())
+            L.append(res["final_labels"].cpu())
     finally:
         model.layer_gemm = LAYER_GEMM_DEFAULT
-    want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:, :n].astype(np.float32))
-    assert int((res["final_labels"].cpu() != want_lab).sum()) == 0
-    dT = (res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().amax(dim=(1, 2))
-    tol = torch.where(torch.from_numpy(fx["stable"]), 1e-4, 1e-3)
-    assert bool((dT < tol).all()), (dT.tolist(), fx["stable"].tolist())
+    ok, d32, dbest, f32, which = _census_judge(torch.cat(T), torch.cat(L), fx, n)
+    bad = np.flatnonzero(~ok.numpy()).tolist()
+    print(f"{name} x{step} {gemm}: median dT {float(dbest.median()):.1e} max {float(dbest.max()):.1e}, matched on fp64 ref: "
+          f"{np.flatnonzero(which.numpy() == 1).tolist()}, failing {bad}")
+    assert not bad, [(i, float(d32[i]), int(f32[i])) for i in bad]
 
 
 @pytest.mark.parametrize("fmt", ["f32", "u16"])
@@ -1150,7 +1232,8 @@ def test_forward_is_bit_identical_with_row_order_and_point_fragment_hand_offs(na
     model.compat_format, model.layer_gemm = fmt, "h3"
     out = []
     try:
-        for env in ({}, {"PDSC_LAYER_PF": "0"}, {"PDSC_LAYER_H3_VARIANT": "0"}):
+        envs = ({}, {"PDSC_LAYER_PF": "0"}, {"PDSC_LAYER_H3_VARIANT": "0"}) if _lib.load().pdsc_experiments_enabled() else ({}, {})
+        for env in envs:     # (the knobs exist in experiments builds; the product library runs the default twice: repeatability)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             res = _forward(model, batch)

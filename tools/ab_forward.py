@@ -5,7 +5,9 @@ processes and boxes, so variants are compared as A B C A B C ... rounds of the s
     python tools/ab_forward.py --config n5000_b32 --variants f32 u16 f32+PDSC_ATT_WIDE=1 [--rounds 7] [--steps 25]
 
 A variant is `<compat_format>[+<ENV>=<value>...][+@<attribute>=<value>...]`: model.compat_format, per-call environment knobs
-of the library, attributes of the module (attention_precision, layer_gemm).
+of the library, attributes of the module (attention_precision, layer_gemm).  Environment knobs exist in the EXPERIMENTS
+library only (python -m pointdsc_amd.build --experiments): variants that use one make this tool load
+pointdsc_amd/libpointdsc_hip_exp.so (or pass --exp to force it); the product library ignores the environment.
 """
 import argparse
 import os
@@ -17,7 +19,9 @@ import torch
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-from pointdsc_amd import PointDSC, workloads  # noqa: E402
+if "--exp" in sys.argv or any("+PDSC_" in x for x in sys.argv):
+    os.environ.setdefault("POINTDSC_HIP_LIB", str(ROOT / "pointdsc_amd" / "libpointdsc_hip_exp.so"))
+from pointdsc_amd import PointDSC, _lib, workloads  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="n5000_b32")
@@ -25,7 +29,10 @@ ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--variants", nargs="+", default=["f32", "u16"])
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=25)
+ap.add_argument("--exp", action="store_true", help="load the experiments library")
 a = ap.parse_args()
+if any("+PDSC_" in v for v in a.variants) and not _lib.load().pdsc_experiments_enabled():
+    raise SystemExit("environment knobs need the experiments library (python -m pointdsc_amd.build --experiments)")
 w = workloads.WORKLOADS[a.config]
 B = a.batch or w["global_batch"]
 model = PointDSC(**w["model"])

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""Parity census: EVERY pair of every bench workload against the unmodified reference's outputs.
+"""Parity census: many seeded pairs per workload family against the unmodified reference's outputs (fp32 AND fp64 runs).
 
-    python tools/parity_census.py [--compat-format f32|u16] [--json]
+    python tools/parity_census.py [--only NAME] [--batches 1,2,4,8,16,32] [--compat-format u16|f32] [--layer-gemm h3|f32] [--json]
 
-The tests and `bench.py --check` gate on the first 4 pairs of each workload (tests/golden/bench_<name>.npz).  This tool reads the
-census fixtures (tests/golden/bench_<name>_all.npz, written by `oracle/make_bench_goldens.py --all`: reference outputs and
-the reference's own fp32-vs-fp64 stability for all 32 + 16 + 8 + 1 pairs), runs each workload's whole batch through
-pdsc_forward_testing exactly as bench.py does and reports, per workload: label flips, the distribution of max|dT|, the
-pairs above 1e-4 and whether the reference itself is stable on them.
+Fixtures: tests/golden/census_<name>.npz (oracle/make_census_goldens.py: for every pair the reference's pose and label mask as
+shipped (fp32) and with the default dtype switched to fp64).  Every pair is run through pdsc_forward_testing with the module's
+shipped defaults (or the overrides), in consecutive batches of each requested size -- the batch size selects the attention's
+key-split plan and the layer kernel, i.e. the summation orders -- and held to BASELINE.json's contract:
+    labels bit-exact and max|dT| < 1e-4 against the reference's fp32 output,
+    or, where the reference's own two precisions disagree (a discrete near-tie among seed hypotheses decided by round-off,
+    models/PointDSC.py:325-335), against its fp64 output.
+There is no looser tolerance for any pair.  Prints one line per (workload, batch size) with the dT histogram and the list of
+failing pairs; --json prints the same as one JSON object.
 """
 import argparse
 import json
@@ -21,51 +25,85 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from pointdsc_amd import PointDSC, workloads  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--compat-format", default="f32")
-ap.add_argument("--json", action="store_true")
-ap.add_argument("--layer-gemm", default=None, help="f32 | h3 (default: the module's)")
-ap.add_argument("--batch", type=int, default=0, help="run the workload's pairs in consecutive batches of this size (0 = the global batch)")
-ap.add_argument("--only", default=None, help="one workload name")
-a = ap.parse_args()
-out = {}
-for name, w in workloads.WORKLOADS.items():
-    fxp = ROOT / "tests" / "golden" / f"bench_{name}_all.npz"
-    if not fxp.exists() or (a.only and name != a.only):
-        continue
-    fx = np.load(fxp, allow_pickle=False)
-    bs, n = w["global_batch"], w["num_corr"]
+EDGES = (1e-6, 1e-5, 2e-5, 5e-5, 1e-4)
+
+
+def judge(trans: torch.Tensor, labels: torch.Tensor, fx, n: int, first: int = 0):
+    """Per pair: (ok, dT vs fp32 reference, dT vs the closer of the two references, label flips vs fp32, which reference matched)."""
+    g = trans.shape[0]
+    t32 = torch.from_numpy(fx["ref32_final_trans"][first:first + g]).double()
+    t64 = torch.from_numpy(fx["ref64_final_trans"][first:first + g]).double()
+    l32 = torch.from_numpy(np.unpackbits(fx["ref32_final_labels_bits"][first:first + g], axis=1)[:, :n].astype(np.float32))
+    l64 = torch.from_numpy(np.unpackbits(fx["ref64_final_labels_bits"][first:first + g], axis=1)[:, :n].astype(np.float32))
+    T, L = trans.cpu().double(), labels.cpu()
+    d32 = (T - t32).abs().amax(dim=(1, 2))
+    d64 = (T - t64).abs().amax(dim=(1, 2))
+    f32 = (L != l32).sum(dim=1)
+    f64 = (L != l64).sum(dim=1)
+    ok32 = (d32 < 1e-4) & (f32 == 0)
+    ok64 = (d64 < 1e-4) & (f64 == 0)
+    return ok32 | ok64, d32, torch.where(ok32, d32, torch.minimum(d32, d64)), f32, torch.where(ok32, 0, torch.where(ok64, 1, -1))
+
+
+def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0):
+    fx = np.load(ROOT / "tests" / "golden" / f"census_{name}.npz", allow_pickle=False)
+    w = workloads.WORKLOADS[name]
+    n = w["num_corr"]
+    total = fx["ref32_final_trans"].shape[0] if pairs <= 0 else min(pairs, fx["ref32_final_trans"].shape[0])
     model = PointDSC(**w["model"])
     model.load_state_dict(workloads.state_dict(name, model.state_dict()))
     model = model.eval().cuda()
-    model.compat_format = a.compat_format
-    if a.layer_gemm:
-        model.layer_gemm = a.layer_gemm
-    step = a.batch if 0 < a.batch < bs else bs
-    parts = {"final_trans": [], "final_labels": []}
-    for first in range(0, bs, step):
-        batch = workloads.batch(name, first, min(step, bs - first))
-        data = {k: batch[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
-        data["testing"] = True
-        with torch.no_grad():
-            r = model(data)
-        for k in parts:
-            parts[k].append(r[k].cpu())
-    res = {k: torch.cat(v) for k, v in parts.items()}
-    want_lab = torch.from_numpy(np.unpackbits(fx["ref_final_labels_bits"], axis=1)[:, :n].astype(np.float32))
-    dT = (res["final_trans"].cpu() - torch.from_numpy(fx["ref_final_trans"])).abs().amax(dim=(1, 2)).numpy()
-    flips = (res["final_labels"].cpu() != want_lab).sum(dim=1).numpy()
-    stable = fx["stable"]
-    rep = {"pairs": int(bs), "label_flips_total": int(flips.sum()), "pairs_with_label_flips": int((flips > 0).sum()),
-           "max_dT": float(dT.max()), "median_dT": float(np.median(dT)),
-           "pairs_dT_above_1e-4": [int(i) for i in np.flatnonzero(dT >= 1e-4)],
-           "of_which_unstable_in_reference": [int(i) for i in np.flatnonzero((dT >= 1e-4) & ~stable)],
-           "pairs_unstable_in_reference": [int(i) for i in np.flatnonzero(~stable)],
-           "dT_sorted_top5": [float(x) for x in np.sort(dT)[::-1][:5]]}
-    out[name] = rep
-    if not a.json:
-        print(f"{name} (batches of {step}, layer_gemm {model.layer_gemm}): {bs} pairs, label flips {rep['label_flips_total']} (in {rep['pairs_with_label_flips']} pairs), "
-              f"max|dT| median {rep['median_dT']:.2e} max {rep['max_dT']:.2e}; >= 1e-4: {rep['pairs_dT_above_1e-4']} "
-              f"(reference itself unstable on {rep['pairs_unstable_in_reference']}); top5 {['%.1e' % x for x in rep['dT_sorted_top5']]}")
-if a.json:
-    print(json.dumps(out))
+    if compat_format:
+        model.compat_format = compat_format
+    if layer_gemm:
+        model.layer_gemm = layer_gemm
+    out = {}
+    for step in batches:
+        T, L = [], []
+        for first in range(0, total, step):
+            batch = workloads.batch(name, first, min(step, total - first))
+            data = {k: batch[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+            data["testing"] = True
+            with torch.no_grad():
+                r = model(data)
+            T.append(r["final_trans"].cpu())
+            L.append(r["final_labels"].cpu())
+        ok, d32, dbest, f32, which = judge(torch.cat(T), torch.cat(L), fx, n)
+        d = dbest.numpy()
+        hist = [int(((d >= lo) & (d < hi)).sum()) for lo, hi in zip((0.0,) + EDGES, EDGES + (np.inf,))]
+        out[step] = {"pairs": int(total), "failing_pairs": [int(i) for i in np.flatnonzero(~ok.numpy())],
+                     "label_flips_vs_fp32_reference": int(f32.sum()), "pairs_matched_on_fp64_reference": [int(i) for i in np.flatnonzero(which.numpy() == 1)],
+                     "median_dT": float(np.median(d)), "max_dT": float(d.max()), "max_dT_vs_fp32_reference": float(d32.max()),
+                     "dT_histogram": dict(zip(["<1e-6", "<1e-5", "<2e-5", "<5e-5", "<1e-4", ">=1e-4"], hist))}
+    return out, model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--batches", default="0", help="comma list of batch sizes; 0 = the workload's global batch")
+    ap.add_argument("--compat-format", default=None)
+    ap.add_argument("--layer-gemm", default=None)
+    ap.add_argument("--pairs", type=int, default=0, help="first K pairs of each family only")
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    report = {}
+    for name, w in workloads.WORKLOADS.items():
+        if (a.only and name != a.only) or not (ROOT / "tests" / "golden" / f"census_{name}.npz").exists():
+            continue
+        batches = [int(x) or w["global_batch"] for x in a.batches.split(",")]
+        rep, model = run_family(name, batches, a.compat_format, a.layer_gemm, a.pairs)
+        report[name] = rep
+        if not a.json:
+            for step, r in rep.items():
+                print(f"{name} (N={w['num_corr']}, compat {model.compat_format}, layer_gemm {model.layer_gemm}) batches of {step}: {r['pairs']} pairs, "
+                      f"FAIL {r['failing_pairs']}, label flips vs fp32 ref {r['label_flips_vs_fp32_reference']}, matched on the fp64 ref "
+                      f"{r['pairs_matched_on_fp64_reference']}, max|dT| median {r['median_dT']:.1e} max {r['max_dT']:.1e}, histogram {r['dT_histogram']}",
+                      flush=True)
+    if a.json:
+        print(json.dumps(report))
+    return 1 if any(r["failing_pairs"] for rep in report.values() for r in rep.values()) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
