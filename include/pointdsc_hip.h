@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 3
+#define PDSC_VERSION 4
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32
@@ -395,6 +395,24 @@ int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void*
                          int bs, int N, int num_seeds,
                          float* final_trans, float* final_labels,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- whole path, ragged batch ---------------------------------------------------------------------
+ * The reference's real evaluation feeds every pair with its own number of correspondences (evaluation/test_3DMatch.py:126
+ * `num_node='all'`, datasets/ThreeDMatch.py:271-276) and therefore one pair per call (models/PointDSC.py:210); its own
+ * batching crops every pair to the shortest (datasets/dataloader.py:6-31).  Here a batch may mix sizes: the inputs are
+ * padded to the longest pair, [bs][N][.] with N = max_b num_corr[b] (padding rows: any finite values, e.g. zeros), and
+ *   num_corr           [bs] int32, DEVICE: correspondences of pair b (2 <= num_corr[b] <= N)
+ *   num_seeds_per_pair [bs] int32, DEVICE: int(num_corr[b] * ratio) >= 1, computed by the caller in double precision (:174)
+ *   num_seeds          = max_b num_seeds_per_pair[b],   n_min = min_b num_corr[b] (host copies; n_min must leave every pair
+ *                        at least one 32-key tile per attention key split: ceil(n_min / 32) >= pdsc_attention_split_default_split(bs, N))
+ * Pair b's results are those of pdsc_forward_testing on its own num_corr[b] rows (same stages on the same data; only the
+ * launch plans, i.e. fp32 summation orders, are the batch's): final_trans [bs][16], final_labels [bs][N] with rows
+ * >= num_corr[b] zero.  Workspace: pdsc_workspace_bytes(cfg, bs, N, num_seeds).  Split-precision attention modes only. */
+int pdsc_forward_testing_ragged(const pdsc_config* cfg, const float* wpack, const void* wsplit,
+                                const float* corr_pos, const float* src_keypts, const float* tgt_keypts,
+                                int bs, int N, int num_seeds, const int* num_corr, const int* num_seeds_per_pair, int n_min,
+                                float* final_trans, float* final_labels,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- validation forward -------------------------------------------------
  * replaces PointDSC.forward(data) WITHOUT the 'testing' key on a module in eval() mode (libs/trainer.py:158-222

@@ -111,6 +111,7 @@ SIGNATURES = {
     "pdsc_feature_compat": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pdsc_conv_mask_all_pairs": (_i, [_vp, _i, _vp]),
     "pdsc_forward_testing": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pdsc_forward_testing_ragged": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -136,7 +137,7 @@ def load() -> C.CDLL:
             raise PointDSCLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.pdsc_version() != 3:
+    if lib.pdsc_version() != 4:
         raise PointDSCLibraryError(f"unexpected library version {lib.pdsc_version()}")
     _lib = lib
     return lib

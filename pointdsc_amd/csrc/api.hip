@@ -7,10 +7,16 @@
 #include <string.h>
 #include <mutex>
 #include "pdsc_common.h"
+#include "ragged.h"
 
 namespace pdsc {
 
 static thread_local char g_err[512] = "";
+
+const int*& layer_nvalid_slot() {
+    static thread_local const int* slot = nullptr;
+    return slot;
+}
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -277,11 +283,27 @@ extern "C" int pdsc_profile_read(int kind, double* total_ms, int* launches) {
 
 // mode 0 = testing forward; mode 1 = validation forward (no 'testing' key, module in eval mode): feature similarity
 // matrix M, seeds = top-S by confidence (no NMS), batch-wide power-iteration exit, no refinement, labels = logits
+// nvalid / svalid (device, [bs]) != NULL: ragged batch (ragged.h) -- N and num_seeds are then those of the longest pair,
+// n_min the shortest pair's count (host copy: the attention's key split must leave every pair at least one tile per split).
 static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
                        const float* src, const float* tgt, int bs, int N, int num_seeds,
                        float* final_trans, float* final_labels, float* Mout, long long ldM, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, void* stream, const int* nvalid = nullptr, const int* svalid = nullptr, int n_min = 0) {
     if (!config_ok(cfg)) return PDSC_ERR_ARG;
+    struct SlotGuard {       // the fused-layer entry points read the count array from the thread-local slot (ragged.h)
+        explicit SlotGuard(const int* p) { layer_nvalid_slot() = p; }
+        ~SlotGuard() { layer_nvalid_slot() = nullptr; }
+    } slot_guard(nvalid);
+    hipStream_t hst = (hipStream_t)stream;
+    if (nvalid) {
+        PDSC_REQUIRE(mode == 0 && svalid, "pdsc_forward_testing_ragged: testing forward only, both count arrays needed");
+        PDSC_REQUIRE(cfg->attention_precision != PDSC_ATT_FP32, "pdsc_forward_testing_ragged: needs a split-precision attention mode "
+                     "(the exact-fp32 attention kernel takes one N per launch)");
+        PDSC_REQUIRE(n_min >= 2 && n_min <= N, "pdsc_forward_testing_ragged: n_min=%d (N=%d)", n_min, N);
+        PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
+                     "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
+                     "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
+    }
     PDSC_REQUIRE(wpack && corr_pos && src && tgt && final_trans && final_labels && workspace,
                  "pdsc_forward_testing: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 1, "pdsc_forward_testing: bs=%d N=%d", bs, N);
@@ -323,9 +345,8 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     else
         PDSC_TRY(pdsc_spatial_compat(src, tgt, W(PDSC_W_SIGMA_SPAT, 0), compat, nullptr, ld, bs, N, stream));
     auto attention_split = [&](float* msg_out, int nsplit) {
-        return compat16 ? pdsc_sc_attention_split_u16(q_split, kv_tiles, (const unsigned short*)compat, ld, msg_out, att_scratch,
-                                                      att_bytes, bs, N, nsplit, stream)
-                        : pdsc_sc_attention_split(q_split, kv_tiles, compat, ld, msg_out, att_scratch, att_bytes, bs, N, nsplit, stream);
+        return launch_attention_split_ex(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, msg_out, att_scratch,
+                                         att_bytes, bs, N, nsplit, PDSC_PARTIALS_ROWS, nvalid, hst);
     };
     PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
     const int fused = env_int("PDSC_FUSED_LAYERS", 1);          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
@@ -371,8 +392,8 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
             if (pf)
-                PDSC_TRY(pdsc_sc_attention_split_partials(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld,
-                                                          att_scratch, att_bytes, bs, N, ns, PDSC_PARTIALS_PF, stream));
+                PDSC_TRY(launch_attention_split_ex(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, nullptr,
+                                                   att_scratch, att_bytes, bs, N, ns, PDSC_PARTIALS_PF, nvalid, hst));
             else
                 PDSC_TRY(attention_split(fuse_merge ? nullptr : msg, ns));
             const bool last = i + 1 == cfg->num_layers;
@@ -440,15 +461,15 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
     PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
     if (mode == 0) {
-        PDSC_TRY(pdsc_nms_keys_grid(src, conf, cfg->nms_radius, keys, ws + L.find("nms_ws"), pdsc_nms_workspace_bytes(bs, N), bs, N, stream));
-        PDSC_TRY(pdsc_rank_select(keys, seeds, bs, N, S, stream));
+        PDSC_TRY(launch_nms_keys_grid(src, conf, cfg->nms_radius, keys, ws + L.find("nms_ws"), pdsc_nms_workspace_bytes(bs, N), bs, N, nvalid, hst));
+        PDSC_TRY(launch_rank_select(keys, seeds, bs, N, S, nvalid, svalid, hst));
     } else {
         // models/PointDSC.py:158-163 and :176
         PDSC_TRY(pdsc_feature_compat(normed, W(PDSC_W_SIGMA, 0), Mout, ldM, bs, N, stream));
         PDSC_TRY(pdsc_rank_select(conf, seeds, bs, N, S, stream));
     }
     // Step 3 & 4 (:182 -> :234-336): per-seed hypotheses, scoring, best
-    PDSC_TRY(pdsc_knn_seeds(normed, seeds, knn_dist, knn_idx, bs, N, S, k, stream));
+    PDSC_TRY(launch_knn_seeds(normed, seeds, knn_dist, knn_idx, bs, N, S, k, nvalid, hst));
     if (mode == 1 && bs > 1) {
         // validation forward: the early exit is taken over the seeds of ALL pairs of the batch (one torch.allclose over
         // [bs*S, k]) -- the per-pair masks are AND-ed before the iterate is chosen, so the two steps stay apart
@@ -460,13 +481,11 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     } else
         PDSC_TRY(pdsc_seed_solve(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig, conv_mask, nullptr,
                                  seed_trans, seed_w, bs, N, S, k, cfg->num_iterations, stream));
-    PDSC_TRY(pdsc_score_hypotheses(seed_trans, src, tgt, cfg->inlier_threshold, counts, bs, N, S, stream));
+    PDSC_TRY(launch_score_hypotheses(seed_trans, src, tgt, cfg->inlier_threshold, counts, bs, N, S, nvalid, hst));
     if (mode == 0) {
-        PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S,
-                                  stream));
+        PDSC_TRY(launch_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S, nvalid, hst));
         // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
-        PDSC_TRY(pdsc_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N,
-                                      stream));
+        PDSC_TRY(launch_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N, nvalid, hst));
     } else {
         // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,
@@ -483,6 +502,15 @@ extern "C" int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, 
                                     void* stream) {
     return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, final_labels, nullptr, 0,
                        workspace, workspace_bytes, stream);
+}
+
+extern "C" int pdsc_forward_testing_ragged(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                                           const float* src, const float* tgt, int bs, int N, int num_seeds, const int* num_corr,
+                                           const int* num_seeds_per_pair, int n_min, float* final_trans, float* final_labels,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    PDSC_REQUIRE(num_corr && num_seeds_per_pair, "pdsc_forward_testing_ragged: the per-pair count arrays (device, [bs] int32) are required");
+    return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, final_labels, nullptr, 0,
+                       workspace, workspace_bytes, stream, num_corr, num_seeds_per_pair, n_min);
 }
 
 extern "C" int pdsc_forward_validation(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,

@@ -28,6 +28,7 @@ struct AttSplitArgs {
     int compat_nt;               // A/B knob PDSC_ATT_COMPAT_NT: stream the compat slices with the non-temporal policy
     int items;                   // persistent form: number of (pair, key split, query block) items (= the one-item form's grid)
     int part_frag;               // key-split partials in point-fragment order (split_layout.h: PF), straight from the accumulators
+    const int* nvalid;           // ragged batches: [bs] correspondences per pair (<= N), or NULL: every pair has N
     long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
 };
 

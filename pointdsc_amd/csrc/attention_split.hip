@@ -22,6 +22,7 @@
 #include <type_traits>
 #include "attention_common.h"
 #include "split_layout.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int N = a.N;
+    const int NS = a.N;              // rows per pair in every buffer (ragged batches: the longest pair)
 
     // block -> (query block, key split, pair).  Blocks i, i+8, i+16.. run on the same XCD (own L2): hand every XCD
     // a contiguous run of the (pair, split, query block) list, so that the workgroups streaming the same K/V tiles
@@ -118,8 +119,13 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         qb = rank % a.nq;
     }
     int sp = grp % a.nsplit, b = grp / a.nsplit;
+    // ragged batches (pdsc_forward_testing_ragged): this pair's own correspondence count -- its queries, its key tiles and the
+    // mask of its last tile; buffer strides stay those of the longest pair.  (Not in the persistent form: one N per launch.)
+    const int N = (!PS && a.nvalid) ? a.nvalid[b] : NS;
+    if (!PS && qb * (NW * 32) >= N) return;      // query block entirely past this pair's rows (workgroup-uniform)
+    const int ntiles = (!PS && a.nvalid) ? ceil_div_dev(N, SPL_BK) : a.num_tiles;
 
-    const int per = a.num_tiles / a.nsplit, rem = a.num_tiles % a.nsplit;
+    const int per = ntiles / a.nsplit, rem = ntiles % a.nsplit;
     int kt0 = sp * per + min(sp, rem);
     int kt1 = kt0 + per + (sp < rem ? 1 : 0);
 
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     __builtin_amdgcn_make_buffer_rsrc((void*)(a.kv + (size_t)(pair) * a.num_tiles * SPL_TILE_STRIDE), 0, a.num_tiles * SPL_TILE_STRIDE, 0x00020000)
     // compat: the descriptor covers only this workgroup's query rows, so every offset fits 32 bits whatever N is
 #define PDSC_C_RSRC(pair, qblock)                                                                                                          \
-    __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.compat + ((size_t)(pair) * N + (qblock) * (NW * 32)) * a.ld * CEL), 0, \
+    __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.compat + ((size_t)(pair) * NS + (qblock) * (NW * 32)) * a.ld * CEL), 0, \
                                       (int)((unsigned)min(NW * 32, N - (qblock) * (NW * 32)) * (unsigned)a.ld * CEL), 0x00020000)
     __amdgpu_buffer_rsrc_t kv_rsrc = PDSC_KV_RSRC(b);
     const int q_first = qb * (NW * 32);
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     bf16x8 qh[8], ql[8];
     auto load_q = [&](int pair, int qblock) {
         const int qrow = min(qblock * (NW * 32) + wave * 32 + l31, N - 1);
-        const __bf16* qsrc = a.qs + ((size_t)pair * N + qrow) * SPL_Q_LD + 8 * h;
+        const __bf16* qsrc = a.qs + ((size_t)pair * NS + qrow) * SPL_Q_LD + 8 * h;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             qh[j] = *reinterpret_cast<const bf16x8*>(qsrc + 16 * j);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-        float* const base = a.nsplit == 1 ? a.msg + (size_t)b * N * PDSC_CHANNELS
+        float* const base = a.nsplit == 1 ? a.msg + (size_t)b * NS * PDSC_CHANNELS
                                           : a.part_o + ((size_t)b * a.nsplit + sp) * a.Npad * PDSC_CHANNELS;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -730,7 +736,7 @@ extern "C" int pdsc_attention_trace(long long* device_buffer) {   // diagnostics
 
 static int launch_attention_split(const void* q_split, const void* kv_tiles, const void* compat, bool c16, long long ld,
                                   float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream,
-                                  int partial_layout = PDSC_PARTIALS_ROWS) {
+                                  int partial_layout = PDSC_PARTIALS_ROWS, const int* nvalid = nullptr) {
     PDSC_REQUIRE(q_split && kv_tiles && compat, "pdsc_sc_attention_split: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_split: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % (c16 ? 8 : 4) == 0,
@@ -753,6 +759,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * PDSC_CHANNELS : nullptr;
     a.trace = g_att_trace;
+    a.nvalid = nvalid;
     a.prio_mode = env_int("PDSC_ATT_PRIO", 0);
     a.compat_nt = c16 ? 0 : 1;                 // (the wide variant still takes it as an argument)
     PDSC_REQUIRE(partial_layout == PDSC_PARTIALS_ROWS || partial_layout == PDSC_PARTIALS_PF, "pdsc_sc_attention_split: partial_layout=%d", partial_layout);
@@ -773,7 +780,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
 #ifdef PDSC_EXPERIMENTS
     // A/B knob PDSC_ATT_WIDE = 1: the one-wave-per-SIMD, 64-queries-per-wave variant (attention_wide.hip) where the plan
     // picks the 8-wave kernel
-    if (nw == 8 && !c16 && !creg && !trace && !a.part_frag && env_int("PDSC_ATT_WIDE", 0)) {
+    if (nw == 8 && !c16 && !creg && !trace && !a.part_frag && !nvalid && env_int("PDSC_ATT_WIDE", 0)) {
         rc = launch_attention_wide(a, grid, st);
         if (rc != PDSC_OK) return rc;
         if (nsplit > 1 && msg) {
@@ -789,7 +796,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
 #ifdef PDSC_EXPERIMENTS
     // A/B knob PDSC_ATT_PERSIST = 1: one workgroup per CU walking its items (point-fragment partials, 8-wave plan, whole
     // multiples of 8 items, at least two per workgroup)
-    const bool persist = nw == 8 && !creg && !trace && a.part_frag && (grid & 7) == 0 && grid >= 512 && env_int("PDSC_ATT_PERSIST", 0) != 0;
+    const bool persist = nw == 8 && !creg && !trace && !nvalid && a.part_frag && (grid & 7) == 0 && grid >= 512 && env_int("PDSC_ATT_PERSIST", 0) != 0;
     if (persist) {
         unsigned pgrid = (unsigned)env_int("PDSC_ATT_PERSIST_GRID", 256) & ~7u;      // A/B knob: workgroups (multiple of 8)
         if (pgrid < 8 || pgrid > grid) pgrid = 256;
@@ -848,12 +855,19 @@ extern "C" int pdsc_sc_attention_split(const void* q_split, const void* kv_tiles
     return launch_attention_split(q_split, kv_tiles, compat, false, ld, msg, scratch, scratch_bytes, bs, N, nsplit, stream);
 }
 
+int pdsc::launch_attention_split_ex(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
+                                    float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, int partial_layout,
+                                    const int* nvalid, hipStream_t st) {
+    PDSC_REQUIRE(compat_format == PDSC_COMPAT_F32 || compat_format == PDSC_COMPAT_U16, "pdsc_sc_attention_split: compat_format=%d", compat_format);
+    return launch_attention_split(q_split, kv_tiles, compat, compat_format == PDSC_COMPAT_U16, ld, msg, scratch, scratch_bytes, bs, N,
+                                  nsplit, st, partial_layout, nvalid);
+}
+
 extern "C" int pdsc_sc_attention_split_partials(const void* q_split, const void* kv_tiles, const void* compat, int compat_format,
                                                 long long ld, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                                 int partial_layout, void* stream) {
-    PDSC_REQUIRE(compat_format == PDSC_COMPAT_F32 || compat_format == PDSC_COMPAT_U16, "pdsc_sc_attention_split_partials: compat_format=%d", compat_format);
-    return launch_attention_split(q_split, kv_tiles, compat, compat_format == PDSC_COMPAT_U16, ld, nullptr, scratch, scratch_bytes, bs, N,
-                                  nsplit, stream, partial_layout);
+    return pdsc::launch_attention_split_ex(q_split, kv_tiles, compat, compat_format, ld, nullptr, scratch, scratch_bytes, bs, N, nsplit,
+                                           partial_layout, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_sc_attention_split_u16(const void* q_split, const void* kv_tiles, const unsigned short* compat_u16,

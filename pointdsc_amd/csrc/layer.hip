@@ -15,6 +15,7 @@
 #include "split_layout.h"
 #include "merge_partials.h"
 #include "layer_args.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * a.N + blockIdx.x * LF_ROWS;     // first row of this tile
-    const int M = (blockIdx.y + 1) * a.N;                        // end of this pair's rows
+    const int M = blockIdx.y * a.N + (a.nvalid ? a.nvalid[blockIdx.y] : a.N);     // end of this pair's rows
+    if (m0 >= M) return;                                         // (ragged batches: tile past the pair's own rows; workgroup-uniform)
 
     LF_STAMP(0)
     f32x4 wpre[16];                                                  // PointCN weight tile of this wave (prefetched early)
@@ -419,6 +421,7 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
                       wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, PDSC_LAYER_GEMM_F32, 0, 0, 0, g_layer_trace};
+    a.nvalid = pdsc::layer_nvalid_slot();
     hipStream_t st = (hipStream_t)stream;
     // Two implementations.  layer_wave.hip (one wavefront per 32-point tile) wins once the tiles fill the chip; with few
     // tiles its serial 46k matrix-pipe cycles per tile are the launch time, and this file's kernel, which spreads a tile

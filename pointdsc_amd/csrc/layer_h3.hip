@@ -20,6 +20,7 @@
 #include "merge_partials.h"
 #include "layer_args.h"
 #include "layer_wave.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
     if (gw >= a.bs * tpp) return;                                    // (no workgroup barriers anywhere below)
     const int b = gw / tpp, tile = gw - b * tpp;
     const int m0 = b * a.N + tile * 32;
-    const int valid = min(32, a.N - tile * 32);
+    const int valid = min(32, (a.nvalid ? a.nvalid[b] : a.N) - tile * 32);
+    if (valid <= 0) return;                                          // (ragged batches: tile past the pair's own rows)
     const bool live = l31 < valid;
     const size_t row = (size_t)m0 + min(l31, valid - 1);
     float* Vs = Vs_all[wave];
@@ -457,6 +459,7 @@ extern "C" int pdsc_layer_fused_frag_io(const float* msg, const float* part_o, c
     a.stagger_cycles = env_int("PDSC_LAYER_STAGGER", 0);
     a.stagger_mode = env_int("PDSC_LAYER_STAGGER_MODE", 1);
     a.trace = nullptr;
+    a.nvalid = layer_nvalid_slot();
     PDSC_REQUIRE(launch_layer_h3_fits(a, tail, head), "pdsc_layer_fused_frag_io: output set not served by the point-fragment kernel "
                                                      "(tail + head: no feat_out; tail only: feat_out)");
     return launch_layer_h3(a, tail, head, (hipStream_t)stream);

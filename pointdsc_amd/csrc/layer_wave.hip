@@ -24,6 +24,7 @@
 #include "layer_args.h"
 
 #include "layer_wave.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
     if (gw >= a.bs * tpp) return;                                    // (no workgroup barriers anywhere below)
     const int b = gw / tpp, tile = gw - b * tpp;
     const int m0 = b * a.N + tile * 32;
-    const int valid = min(32, a.N - tile * 32);
+    const int valid = min(32, (a.nvalid ? a.nvalid[b] : a.N) - tile * 32);
+    if (valid <= 0) return;                                          // (ragged batches: tile past the pair's own rows)
     const bool live = l31 < valid;
     const size_t row = (size_t)m0 + min(l31, valid - 1);
     float* Vs = Vs_all[wave];
@@ -479,6 +481,7 @@ extern "C" int pdsc_layer_fused_frag_fmt(const float* msg, const float* part_o, 
     a.stagger_cycles = env_int("PDSC_LAYER_STAGGER", 0);
     a.stagger_mode = env_int("PDSC_LAYER_STAGGER_MODE", 1);
     a.trace = pdsc_layer_trace_buffer();
+    a.nvalid = layer_nvalid_slot();
     // H3: the pipelined kernel of layer_h3.hip; A/B knob PDSC_LAYER_H3_VARIANT = 0: this file's kernel with the H3 GEMMs
     if (gemm_format == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0 && launch_layer_h3_fits(a, tail, head))
         return launch_layer_h3(a, tail, head, (hipStream_t)stream);

@@ -1,0 +1,34 @@
+// Ragged batches (pdsc_forward_testing_ragged): every pair of a batch has its own correspondence count n_b <= N and its own
+// seed count s_b <= S, while every buffer keeps the strides of the longest pair (rows n_b .. N-1 of a pair are padding).
+// The stages whose result depends on the count -- attention (keys / queries), NMS, seed ranking, kNN columns, hypothesis
+// scoring, best-hypothesis labels, refinement -- take the device arrays `nvalid` / `svalid` ([bs] int32, NULL = uniform
+// batch) through these internal launchers; the public stage entry points are the same launchers with NULL.
+// Everything row-parallel (layer kernels, classifier, normalisation, Gram rows, per-seed solver) runs unchanged over the
+// padded layout: padding rows carry finite copies / unused values that no valid row ever reads.
+#pragma once
+#include "pdsc_common.h"
+
+namespace pdsc {
+
+int launch_nms_keys_grid(const float* src, const float* conf, float radius, float* keys, void* workspace, size_t workspace_bytes,
+                         int bs, int N, const int* nvalid, hipStream_t st);
+int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st);
+int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
+                     const int* nvalid, hipStream_t st);
+int launch_score_hypotheses(const float* seed_trans, const float* src, const float* tgt, float inlier_threshold, int* counts, int bs,
+                            int N, int S, const int* nvalid, hipStream_t st);
+int launch_select_best(const int* counts, const float* seed_trans, const float* src, const float* tgt, float inlier_threshold, int* best,
+                       float* best_trans, float* labels, int bs, int N, int S, const int* nvalid, hipStream_t st);
+int launch_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold, int max_iters,
+                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st);
+// msg != NULL: merged output rows (key split 1, or the combine launch); msg == NULL: the key-split partials stay in `scratch`
+int launch_attention_split_ex(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
+                              float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, int partial_layout,
+                              const int* nvalid, hipStream_t st);
+
+// The three fused-layer entry points (pdsc_layer_fused_split / _frag_fmt / _frag_io: 18-24 arguments each) read the count
+// array from this thread-local slot when they fill LayerArgs; run_forward sets it for the duration of a ragged call and
+// clears it before returning (host-side, per thread: concurrent callers on other threads are unaffected).
+const int*& layer_nvalid_slot();
+
+}  // namespace pdsc

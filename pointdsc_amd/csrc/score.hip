@@ -5,6 +5,7 @@
 // formed in registers and only S integer counts leave the chip.  Bound: VALU/latency (30*S*N flop, 24*N+64*S
 // bytes); reported as time only.
 #include "pdsc_common.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -35,18 +36,19 @@ __device__ __forceinline__ float residual_sq(const float* __restrict__ T, float 
 // counts are those of the reference's `L2 < thr` without S*N correctly rounded square roots (half of this kernel's VALU work)
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ seed_trans, const float* __restrict__ src,
                                                     const float* __restrict__ tgt, float thr2, int* __restrict__ counts,
-                                                    int N, int S) {
+                                                    int NS, int S, const int* __restrict__ nvalid) {
     __shared__ float Ts[SC_SEEDS][12];
     const int t = threadIdx.x, lane = t & 63;
     const int s0 = blockIdx.x * SC_SEEDS, p0 = blockIdx.y * SC_POINTS, b = blockIdx.z;
+    const int N = nvalid ? nvalid[b] : NS;        // ragged batches: only the pair's own correspondences vote (ragged.h)
     if (t < SC_SEEDS * 12) {
         const int sl = t / 12, e = t % 12;
         const int s = min(s0 + sl, S - 1);
         Ts[sl][e] = seed_trans[((size_t)b * S + s) * 16 + e];
     }
     __syncthreads();
-    const float* srcb = src + (size_t)b * N * 3;
-    const float* tgtb = tgt + (size_t)b * N * 3;
+    const float* srcb = src + (size_t)b * NS * 3;
+    const float* tgtb = tgt + (size_t)b * NS * 3;
     int cnt[SC_SEEDS];
 #pragma unroll
     for (int s = 0; s < SC_SEEDS; ++s) cnt[s] = 0;
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict
                                                            const float* __restrict__ src, const float* __restrict__ tgt,
                                                            float thr, int* __restrict__ best_out,
                                                            float* __restrict__ initial_trans, float* __restrict__ labels,
-                                                           int N, int S) {
+                                                           int NS, int S, const int* __restrict__ nvalid) {
+    const int N = nvalid ? nvalid[blockIdx.x] : NS;
     __shared__ unsigned long long wbest[16];
     __shared__ float Tb[16];
     __shared__ int best_s;
@@ -99,23 +102,26 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict
         initial_trans[(size_t)b * 16 + t] = v;
     }
     __syncthreads();
-    const float* srcb = src + (size_t)b * N * 3;
-    const float* tgtb = tgt + (size_t)b * N * 3;
+    const float* srcb = src + (size_t)b * NS * 3;
+    const float* tgtb = tgt + (size_t)b * NS * 3;
     for (int i = t; i < N; i += 1024) {
         const float r = residual(Tb, srcb[i * 3], srcb[i * 3 + 1], srcb[i * 3 + 2], tgtb[i * 3], tgtb[i * 3 + 1], tgtb[i * 3 + 2]);
-        labels[(size_t)b * N + i] = r < thr ? 1.0f : 0.0f;
+        labels[(size_t)b * NS + i] = r < thr ? 1.0f : 0.0f;
     }
+    for (int i = N + t; i < NS; i += 1024) labels[(size_t)b * NS + i] = 0.0f;       // padding rows of a ragged batch
 }
 
 // post_refinement: one persistent 512-thread workgroup per pair runs the whole <=max_iters loop.
 __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ initial_trans, const float* __restrict__ src,
                                                       const float* __restrict__ tgt, float thr, int max_iters,
-                                                      float* __restrict__ final_trans, int* __restrict__ solves, int N) {
+                                                      float* __restrict__ final_trans, int* __restrict__ solves, int NS,
+                                                      const int* __restrict__ nvalid) {
     __shared__ float red[8 * 9];
     __shared__ float Tc[16];
     const int t = threadIdx.x, b = blockIdx.x;
-    const float* srcb = src + (size_t)b * N * 3;
-    const float* tgtb = tgt + (size_t)b * N * 3;
+    const int N = nvalid ? nvalid[b] : NS;
+    const float* srcb = src + (size_t)b * NS * 3;
+    const float* tgtb = tgt + (size_t)b * NS * 3;
     if (t < 16) Tc[t] = initial_trans[(size_t)b * 16 + t];
     __syncthreads();
     int prev = 0, solved = 0;
@@ -169,31 +175,48 @@ __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ i
 
 }  // namespace pdsc
 
-extern "C" int pdsc_score_hypotheses(const float* seed_trans, const float* src, const float* tgt, float thr, int* counts,
-                                     int bs, int N, int S, void* stream) {
+namespace pdsc {
+
+int launch_score_hypotheses(const float* seed_trans, const float* src, const float* tgt, float thr, int* counts, int bs, int N, int S,
+                            const int* nvalid, hipStream_t st) {
     PDSC_REQUIRE(seed_trans && src && tgt && counts, "pdsc_score_hypotheses: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_score_hypotheses: bs=%d N=%d S=%d", bs, N, S);
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)bs * S, st) != hipSuccess) return pdsc::check_launch("memset");
-    dim3 grid(pdsc::ceil_div(S, pdsc::SC_SEEDS), pdsc::ceil_div(N, pdsc::SC_POINTS), bs);
-    hipLaunchKernelGGL(pdsc::score_kernel, grid, dim3(256), 0, st, seed_trans, src, tgt, pdsc::sqrt_threshold_radicand(thr), counts, N, S);
-    return pdsc::check_launch("pdsc_score_hypotheses");
+    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)bs * S, st) != hipSuccess) return check_launch("memset");
+    dim3 grid(ceil_div(S, SC_SEEDS), ceil_div(N, SC_POINTS), bs);
+    hipLaunchKernelGGL(score_kernel, grid, dim3(256), 0, st, seed_trans, src, tgt, sqrt_threshold_radicand(thr), counts, N, S, nvalid);
+    return check_launch("pdsc_score_hypotheses");
+}
+
+int launch_select_best(const int* counts, const float* seed_trans, const float* src, const float* tgt, float thr, int* best,
+                       float* initial_trans, float* labels, int bs, int N, int S, const int* nvalid, hipStream_t st) {
+    PDSC_REQUIRE(counts && seed_trans && src && tgt && initial_trans && labels, "pdsc_select_best: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_select_best: bs=%d N=%d S=%d", bs, N, S);
+    hipLaunchKernelGGL(select_best_kernel, dim3(bs), dim3(1024), 0, st, counts, seed_trans, src, tgt, thr, best, initial_trans, labels, N, S,
+                       nvalid);
+    return check_launch("pdsc_select_best");
+}
+
+int launch_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold, int max_iters,
+                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st) {
+    PDSC_REQUIRE(initial_trans && src && tgt && final_trans, "pdsc_post_refinement: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && max_iters >= 0, "pdsc_post_refinement: bs=%d N=%d iters=%d", bs, N, max_iters);
+    hipLaunchKernelGGL(refine_kernel, dim3(bs), dim3(512), 0, st, initial_trans, src, tgt, threshold, max_iters, final_trans, solves, N, nvalid);
+    return check_launch("pdsc_post_refinement");
+}
+
+}  // namespace pdsc
+
+extern "C" int pdsc_score_hypotheses(const float* seed_trans, const float* src, const float* tgt, float thr, int* counts,
+                                     int bs, int N, int S, void* stream) {
+    return pdsc::launch_score_hypotheses(seed_trans, src, tgt, thr, counts, bs, N, S, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_select_best(const int* counts, const float* seed_trans, const float* src, const float* tgt, float thr,
                                 int* best, float* initial_trans, float* labels, int bs, int N, int S, void* stream) {
-    PDSC_REQUIRE(counts && seed_trans && src && tgt && initial_trans && labels, "pdsc_select_best: null pointer");
-    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_select_best: bs=%d N=%d S=%d", bs, N, S);
-    hipLaunchKernelGGL(pdsc::select_best_kernel, dim3(bs), dim3(1024), 0, (hipStream_t)stream, counts, seed_trans, src, tgt,
-                       thr, best, initial_trans, labels, N, S);
-    return pdsc::check_launch("pdsc_select_best");
+    return pdsc::launch_select_best(counts, seed_trans, src, tgt, thr, best, initial_trans, labels, bs, N, S, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold,
                                     int max_iters, float* final_trans, int* solves, int bs, int N, void* stream) {
-    PDSC_REQUIRE(initial_trans && src && tgt && final_trans, "pdsc_post_refinement: null pointer");
-    PDSC_REQUIRE(bs > 0 && N > 0 && max_iters >= 0, "pdsc_post_refinement: bs=%d N=%d iters=%d", bs, N, max_iters);
-    hipLaunchKernelGGL(pdsc::refine_kernel, dim3(bs), dim3(512), 0, (hipStream_t)stream, initial_trans, src, tgt, threshold,
-                       max_iters, final_trans, solves, N);
-    return pdsc::check_launch("pdsc_post_refinement");
+    return pdsc::launch_post_refinement(initial_trans, src, tgt, threshold, max_iters, final_trans, solves, bs, N, nullptr, (hipStream_t)stream);
 }

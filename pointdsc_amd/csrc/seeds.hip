@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "pdsc_common.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -96,20 +97,24 @@ __device__ __forceinline__ int grid_cell_1d(float v, float vmin, float w, int nb
 static size_t nms_ws_pair_bytes(int N) {
     return (size_t)round_up((long long)N * 16 + (long long)N * 4 + (GRID_MAX * GRID_MAX + 1) * 4 + sizeof(NmsGridHeader), 256);
 }
+// Ragged batches (nvalid != NULL): NS = rows per pair in src / conf / keys and in the workspace layout (the longest pair), the
+// pair's own count N = nvalid[b] bounds every loop.
 __global__ __launch_bounds__(1024) void nms_grid_kernel(const float* __restrict__ src, const float* __restrict__ conf, float radius,
-                                                        unsigned char* __restrict__ ws, size_t ws_pair, int N) {
+                                                        unsigned char* __restrict__ ws, size_t ws_pair, int NS,
+                                                        const int* __restrict__ nvalid) {
+    const int N = nvalid ? nvalid[blockIdx.x] : NS;
     __shared__ int cells[GRID_MAX * GRID_MAX + 1];
     __shared__ float red[4][16];
     __shared__ int wtot[16];
     __shared__ NmsGridHeader hdr;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
-    const float* s = src + (size_t)b * N * 3;
-    const float* c = conf + (size_t)b * N;
+    const float* s = src + (size_t)b * NS * 3;
+    const float* c = conf + (size_t)b * NS;
     unsigned char* w = ws + (size_t)b * ws_pair;
     float4* rec = reinterpret_cast<float4*>(w);
-    int* oidx = reinterpret_cast<int*>(w + (size_t)N * 16);
-    int* cell_start = reinterpret_cast<int*>(w + (size_t)N * 20);
-    NmsGridHeader* hout = reinterpret_cast<NmsGridHeader*>(w + (size_t)N * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
+    int* oidx = reinterpret_cast<int*>(w + (size_t)NS * 16);
+    int* cell_start = reinterpret_cast<int*>(w + (size_t)NS * 20);
+    NmsGridHeader* hout = reinterpret_cast<NmsGridHeader*>(w + (size_t)NS * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
     float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
     int bad = 0;          // a NaN / Inf coordinate: its distances are NaN / Inf for EVERY partner, the window argument does not hold
     for (int i = t; i < N; i += 1024) {
@@ -186,13 +191,14 @@ __global__ __launch_bounds__(1024) void nms_grid_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void nms_window_kernel(const unsigned char* __restrict__ ws, size_t ws_pair, float radius2,
-                                                         float* __restrict__ keys, int N) {
+                                                         float* __restrict__ keys, int NS, const int* __restrict__ nvalid) {
     const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const int N = nvalid ? nvalid[b] : NS;
     const unsigned char* w = ws + (size_t)b * ws_pair;
     const float4* rec = reinterpret_cast<const float4*>(w);
-    const int* oidx = reinterpret_cast<const int*>(w + (size_t)N * 16);
-    const int* cell_start = reinterpret_cast<const int*>(w + (size_t)N * 20);
-    const NmsGridHeader h = *reinterpret_cast<const NmsGridHeader*>(w + (size_t)N * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
+    const int* oidx = reinterpret_cast<const int*>(w + (size_t)NS * 16);
+    const int* cell_start = reinterpret_cast<const int*>(w + (size_t)NS * 20);
+    const NmsGridHeader h = *reinterpret_cast<const NmsGridHeader*>(w + (size_t)NS * 20 + (GRID_MAX * GRID_MAX + 1) * 4);
     if (p >= N) return;
     const float4 me = rec[p];
     const int cx = grid_cell_1d(me.x, h.xmin, h.wx, h.nbx), cy = grid_cell_1d(me.y, h.ymin, h.wy, h.nby);
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void nms_window_kernel(const unsigned char* __
             ok = ok && ((me.w >= o.w) || (d2 >= radius2));
         }
     }
-    keys[(size_t)b * N + oidx[p]] = ok ? me.w : me.w * 0.0f;                        // -0.0 for suppressed negatives, like torch
+    keys[(size_t)b * NS + oidx[p]] = ok ? me.w : me.w * 0.0f;                       // -0.0 for suppressed negatives, like torch
 }
 
 // ---- top-S by descending key, equal keys by ascending index: one workgroup per pair ---------------------
@@ -223,15 +229,21 @@ __device__ __forceinline__ unsigned int desc_key_bits(float f) {
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                           // ascending float order == ascending unsigned
     return ~u;                                                                // ... descending
 }
-__global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds, int N,
-                                                                  int num_seeds) {
+// Ragged batches: NS / SS = rows per pair of keys / slots per pair of seeds (those of the longest pair); this pair ranks its own
+// N = nvalid[b] keys and picks num_seeds = svalid[b] of them.  The unused slots [num_seeds, SS) are filled with copies of the
+// pair's first seed: every later stage then works on valid indices, a duplicate hypothesis scores exactly like the original
+// and, sitting behind it, can never win the first-maximum argmax (models/PointDSC.py:331) -- nor change the AND of the
+// per-seed convergence flags.
+__global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds, int NS,
+                                                                  int SS, const int* __restrict__ nvalid, const int* __restrict__ svalid) {
+    const int N = nvalid ? nvalid[blockIdx.x] : NS, num_seeds = svalid ? svalid[blockIdx.x] : SS;
     extern __shared__ __attribute__((aligned(16))) unsigned long long surv[];     // [num_seeds]
     __shared__ int hist[256];
     __shared__ unsigned int sh_prefix;
     __shared__ int sh_remaining, sh_count, sh_eq_base;
     __shared__ int wave_cnt[SEL_THREADS / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
-    const float* k = keys + (size_t)b * N;
+    const float* k = keys + (size_t)b * NS;
     unsigned int prefix = 0, mask = 0;
     int remaining = num_seeds;                        // 1-based rank of the wanted value inside the current candidate set
     for (int pass = 0; pass < 4; ++pass) {
@@ -297,7 +309,9 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float* _
         const unsigned long long mine = surv[e];
         int rank = 0;
         for (int f = 0; f < num_seeds; ++f) rank += surv[f] < mine;          // LDS broadcast reads
-        seeds[(size_t)b * num_seeds + rank] = (int)(mine & 0xFFFFFFFFull);
+        seeds[(size_t)b * SS + rank] = (int)(mine & 0xFFFFFFFFull);
+        if (rank == 0)
+            for (int f = num_seeds; f < SS; ++f) seeds[(size_t)b * SS + f] = (int)(mine & 0xFFFFFFFFull);     // (ragged batches only)
     }
 }
 
@@ -313,8 +327,9 @@ constexpr int KNN_THREADS = 256;
 constexpr int KNN_FAST_CAP = 1024;
 
 __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(const float* __restrict__ dist, long long ldd,
-                                                                 int* __restrict__ knn_idx, int N, int S, int k,
-                                                                 int idx_bits) {
+                                                                 int* __restrict__ knn_idx, int NS, int S, int k,
+                                                                 int idx_bits, const int* __restrict__ nvalid) {
+    const int N = nvalid ? nvalid[blockIdx.y] : NS;      // ragged batches: only this pair's own columns are candidates
     extern __shared__ __attribute__((aligned(16))) unsigned int lds_u[];
     unsigned int* keys = lds_u;                     // [N] monotone distance bits
     __shared__ int hist[256];
@@ -512,59 +527,76 @@ extern "C" size_t pdsc_nms_workspace_bytes(int bs, int N) {
     return (size_t)bs * pdsc::nms_ws_pair_bytes(N);
 }
 
-extern "C" int pdsc_nms_keys_grid(const float* src, const float* conf, float radius, float* keys, void* workspace,
-                                  size_t workspace_bytes, int bs, int N, void* stream) {
+namespace pdsc {
+
+int launch_nms_keys_grid(const float* src, const float* conf, float radius, float* keys, void* workspace, size_t workspace_bytes,
+                         int bs, int N, const int* nvalid, hipStream_t st) {
     PDSC_REQUIRE(src && conf && keys, "pdsc_nms_keys_grid: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_nms_keys_grid: bs=%d N=%d", bs, N);
     // a radius that is not a positive finite number has no cell width: the N^2 kernel handles it (every point its own maximum
     // for radius <= 0, none for NaN)
-    if (!(radius > 0.f) || !(radius < INFINITY) || !workspace) return pdsc_nms_keys(src, conf, radius, keys, bs, N, stream);
+    if (!(radius > 0.f) || !(radius < INFINITY) || !workspace) {
+        PDSC_REQUIRE(!nvalid, "pdsc_nms_keys_grid: ragged batches need a positive finite nms_radius and the grid workspace");
+        return pdsc_nms_keys(src, conf, radius, keys, bs, N, st);
+    }
     if (workspace_bytes < pdsc_nms_workspace_bytes(bs, N)) {
-        pdsc::set_error("pdsc_nms_keys_grid: workspace %zu < %zu bytes", workspace_bytes, pdsc_nms_workspace_bytes(bs, N));
+        set_error("pdsc_nms_keys_grid: workspace %zu < %zu bytes", workspace_bytes, pdsc_nms_workspace_bytes(bs, N));
         return PDSC_ERR_WORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
-    const size_t ws_pair = pdsc::nms_ws_pair_bytes(N);
-    hipLaunchKernelGGL(pdsc::nms_grid_kernel, dim3(bs), dim3(1024), 0, st, src, conf, radius, (unsigned char*)workspace, ws_pair, N);
-    int rc = pdsc::check_launch("pdsc_nms_keys_grid(grid)");
+    const size_t ws_pair = nms_ws_pair_bytes(N);
+    hipLaunchKernelGGL(nms_grid_kernel, dim3(bs), dim3(1024), 0, st, src, conf, radius, (unsigned char*)workspace, ws_pair, N, nvalid);
+    int rc = check_launch("pdsc_nms_keys_grid(grid)");
     if (rc != PDSC_OK) return rc;
-    hipLaunchKernelGGL(pdsc::nms_window_kernel, dim3(pdsc::ceil_div(N, 256), bs), dim3(256), 0, st, (const unsigned char*)workspace, ws_pair,
-                       nms_radius2(radius), keys, N);
-    return pdsc::check_launch("pdsc_nms_keys_grid(window)");
+    hipLaunchKernelGGL(nms_window_kernel, dim3(ceil_div(N, 256), bs), dim3(256), 0, st, (const unsigned char*)workspace, ws_pair,
+                       nms_radius2(radius), keys, N, nvalid);
+    return check_launch("pdsc_nms_keys_grid(window)");
 }
 
-extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream) {
+int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st) {
     PDSC_REQUIRE(keys && seeds, "pdsc_rank_select: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && num_seeds >= 0 && num_seeds <= N, "pdsc_rank_select: bs=%d N=%d S=%d", bs, N, num_seeds);
     if (num_seeds == 0) return PDSC_OK;
     const size_t lds_bytes = (size_t)num_seeds * sizeof(unsigned long long);
     PDSC_REQUIRE(lds_bytes <= 128 * 1024, "pdsc_rank_select: num_seeds=%d exceeds the single-workgroup LDS list (16384)", num_seeds);
-    const int rc = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::seed_select_kernel), lds_bytes > 65536 ? 128 * 1024 : 65536,
-                                            "pdsc_rank_select(dynamic LDS)");
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&seed_select_kernel), lds_bytes > 65536 ? 128 * 1024 : 65536,
+                                      "pdsc_rank_select(dynamic LDS)");
     if (rc != PDSC_OK) return rc;
-    hipLaunchKernelGGL(pdsc::seed_select_kernel, dim3(bs), dim3(pdsc::SEL_THREADS), lds_bytes, (hipStream_t)stream, keys, seeds, N,
-                       num_seeds);
-    return pdsc::check_launch("pdsc_rank_select");
+    hipLaunchKernelGGL(seed_select_kernel, dim3(bs), dim3(SEL_THREADS), lds_bytes, st, keys, seeds, N, num_seeds, nvalid, svalid);
+    return check_launch("pdsc_rank_select");
 }
 
-extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
-                              int S, int k, void* stream) {
+int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
+                     const int* nvalid, hipStream_t st) {
     PDSC_REQUIRE(normed && seeds && dist_scratch && knn_idx, "pdsc_knn_seeds: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 1 && S > 0, "pdsc_knn_seeds: bs=%d N=%d S=%d", bs, N, S);
     PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K && k <= N - 1, "pdsc_knn_seeds: k=%d (N=%d, max %d)", k, N, PDSC_MAX_K);
     PDSC_REQUIRE((size_t)N * 4 <= 144 * 1024, "pdsc_knn_seeds: N=%d exceeds the single-workgroup LDS row (36864)", N);
-    hipStream_t st = (hipStream_t)stream;
     const long long ldd = pdsc_compat_ld(N);
-    int rc = pdsc::knn_dist_rows(normed, seeds, dist_scratch, ldd, bs, N, S, st);
+    int rc = knn_dist_rows(normed, seeds, dist_scratch, ldd, bs, N, S, st);
     if (rc != PDSC_OK) return rc;
     int idx_bits = 1;
     while ((1 << idx_bits) < N) ++idx_bits;
     const size_t lds_bytes = (size_t)N * sizeof(unsigned int);
     {   // + ~12 KiB static <= 160 KiB
-        const int rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::knn_select_kernel), 144 * 1024, "pdsc_knn_seeds(dynamic LDS)");
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_select_kernel), 144 * 1024, "pdsc_knn_seeds(dynamic LDS)");
         if (rc_lds != PDSC_OK) return rc_lds;
     }
-    hipLaunchKernelGGL(pdsc::knn_select_kernel, dim3(S, bs), dim3(pdsc::KNN_THREADS), lds_bytes, st, dist_scratch, ldd,
-                       knn_idx, N, S, k, idx_bits);
-    return pdsc::check_launch("pdsc_knn_seeds");
+    hipLaunchKernelGGL(knn_select_kernel, dim3(S, bs), dim3(KNN_THREADS), lds_bytes, st, dist_scratch, ldd, knn_idx, N, S, k, idx_bits, nvalid);
+    return check_launch("pdsc_knn_seeds");
+}
+
+}  // namespace pdsc
+
+extern "C" int pdsc_nms_keys_grid(const float* src, const float* conf, float radius, float* keys, void* workspace,
+                                  size_t workspace_bytes, int bs, int N, void* stream) {
+    return pdsc::launch_nms_keys_grid(src, conf, radius, keys, workspace, workspace_bytes, bs, N, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream) {
+    return pdsc::launch_rank_select(keys, seeds, bs, N, num_seeds, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
+                              int S, int k, void* stream) {
+    return pdsc::launch_knn_seeds(normed, seeds, dist_scratch, knn_idx, bs, N, S, k, nullptr, (hipStream_t)stream);
 }

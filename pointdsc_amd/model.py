@@ -255,15 +255,22 @@ class PointDSC(nn.Module):
         """data: corr_pos [bs,N,in_dim], src_keypts [bs,N,3], tgt_keypts [bs,N,3].
         With the key 'testing' (reference :145): final_trans [bs,4,4] (refined), final_labels [bs,N] (0/1 float), M None.
         Without it (validation forward, reference :158-163,:176,:190-191): final_trans = best seed hypothesis,
-        final_labels = confidence logits, M [bs,N,N] feature similarity matrix.  Forward only, eval() mode."""
-        corr_pos, src_keypts, tgt_keypts = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
+        final_labels = confidence logits, M [bs,N,N] feature similarity matrix.  Forward only, eval() mode.
+
+        Ragged batches (testing mode; the reference's real evaluation has a different N per pair and therefore runs one pair
+        per call, evaluation/test_3DMatch.py:126, models/PointDSC.py:210): either pass LISTS of per-pair tensors
+        (corr_pos[i] [N_i,in_dim], src_keypts[i] / tgt_keypts[i] [N_i,3]) -- final_labels is then a list of [N_i] tensors --
+        or padded tensors plus data['num_corr'] (sequence / 1-D tensor of the bs valid counts; rows past a pair's count are
+        ignored, its final_labels are zero there).  Pair i's result is that of a call on its own N_i rows."""
         testing = "testing" in data.keys()
         if self.training:
             raise RuntimeError(
                 "call .eval() first: BatchNorm is folded with its running statistics.  The train()-mode forward (batch "
                 "statistics + autograd, reference libs/trainer.py:68-156) is out of scope; the validation forward "
                 "(eval() mode without the 'testing' key, libs/trainer.py:158-222) is supported.")
-        lib = _lib.load()
+        corr_pos, src_keypts, tgt_keypts = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
+        if isinstance(corr_pos, (list, tuple)):
+            return self._forward_list(list(corr_pos), list(src_keypts), list(tgt_keypts), testing)
         if not corr_pos.is_cuda:
             raise RuntimeError("pointdsc_amd has no CPU path: move the model and data to the GPU (model.cuda())")
         dev = corr_pos.device
@@ -273,6 +280,84 @@ class PointDSC(nn.Module):
         bs, n = corr_pos.shape[0], corr_pos.shape[1]
         if corr_pos.shape[2] != self.in_dim or src_keypts.shape != (bs, n, 3) or tgt_keypts.shape != (bs, n, 3):
             raise ValueError("bad input shapes for PointDSC.forward")
+        counts = data.get("num_corr") if hasattr(data, "get") else None
+        if counts is not None:
+            counts = [int(c) for c in (counts.tolist() if torch.is_tensor(counts) else counts)]
+            if len(counts) != bs or min(counts) < 2 or max(counts) > n:
+                raise ValueError(f"num_corr must hold {bs} counts in [2, {n}]")
+            if all(c == n for c in counts):
+                counts = None
+        return self._run(corr_pos, src_keypts, tgt_keypts, testing, counts)
+
+    def _forward_list(self, corr, src, tgt, testing):
+        """Ragged batch given as lists of per-pair tensors: pad to the longest pair, run, cut the labels back."""
+        if not (len(corr) == len(src) == len(tgt)) or not corr:
+            raise ValueError("corr_pos, src_keypts and tgt_keypts must be lists of the same (non-zero) length")
+        if not corr[0].is_cuda:
+            raise RuntimeError("pointdsc_amd has no CPU path: move the model and data to the GPU (model.cuda())")
+        dev = corr[0].device
+        squeeze = [t.reshape(-1, t.shape[-1]) for t in corr]            # accept [N_i, d] and the reference's [1, N_i, d]
+        counts = [int(t.shape[0]) for t in squeeze]
+        n_max = max(counts)
+
+        def pad(ts, width):
+            out = torch.zeros(len(ts), n_max, width, device=dev, dtype=torch.float32)
+            for i, t in enumerate(ts):
+                t = t.detach().reshape(-1, width).to(device=dev, dtype=torch.float32)
+                if t.shape[0] != counts[i]:
+                    raise ValueError(f"pair {i}: corr_pos / src_keypts / tgt_keypts disagree on the number of correspondences")
+                out[i, : counts[i]] = t
+            return out
+
+        res = self._run(pad(squeeze, self.in_dim), pad(src, 3), pad(tgt, 3), testing, None if min(counts) == n_max else counts)
+        res["final_labels"] = [res["final_labels"][i, : counts[i]] for i in range(len(counts))]
+        return res
+
+    def _ragged_groups(self, counts):
+        """Index groups that can share a launch: the attention's key split (planned from the group's size and its longest pair)
+        must leave the group's shortest pair at least one 32-key tile per split.  Greedy over the pairs sorted by size."""
+        lib = _lib.load()
+        order = sorted(range(len(counts)), key=lambda i: -counts[i])
+        groups, cur = [], []
+        for i in order:
+            trial = cur + [i]
+            ns = int(lib.pdsc_attention_split_default_split(len(trial), counts[trial[0]]))
+            if cur and (counts[i] + 31) // 32 < ns:
+                groups.append(cur)
+                cur = [i]
+            else:
+                cur = trial
+        groups.append(cur)
+        # a group whose plan (decided by its final size) still asks too much of its shortest pair sheds that pair
+        out = []
+        for g in groups:
+            while len(g) > 1 and (counts[g[-1]] + 31) // 32 < int(lib.pdsc_attention_split_default_split(len(g), counts[g[0]])):
+                out.append([g.pop()])
+            out.append(g)
+        return out
+
+    def _run(self, corr_pos, src_keypts, tgt_keypts, testing, counts=None):
+        lib = _lib.load()
+        dev = corr_pos.device
+        bs, n = corr_pos.shape[0], corr_pos.shape[1]
+        if counts is not None:
+            if not testing:
+                raise NotImplementedError("ragged batches are supported in testing mode only (the validation forward returns an N x N matrix per pair)")
+            if self.attention_precision == "fp32":
+                raise NotImplementedError('ragged batches need a split-precision attention mode (attention_precision = "bf16x3")')
+            groups = self._ragged_groups(counts)
+            if len(groups) > 1:                       # too heterogeneous for one launch plan: one call per group of similar sizes
+                final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
+                final_labels = torch.zeros(bs, n, device=dev, dtype=torch.float32)
+                for g in groups:
+                    idx = torch.tensor(g, device=dev)
+                    ng = max(counts[i] for i in g)
+                    cg = [counts[i] for i in g]
+                    r = self._run(corr_pos[idx, :ng].contiguous(), src_keypts[idx, :ng].contiguous(), tgt_keypts[idx, :ng].contiguous(),
+                                  testing, None if min(cg) == ng else cg)
+                    final_trans[idx] = r["final_trans"]
+                    final_labels[idx, :ng] = r["final_labels"]
+                return {"final_trans": final_trans, "final_labels": final_labels, "M": None}
         num_seeds = int(n * self.ratio)                       # python double arithmetic, as the reference (:174)
         cfg = self._config()
         with torch.cuda.device(dev):
@@ -286,16 +371,27 @@ class PointDSC(nn.Module):
             final_labels = torch.empty(bs, n, device=dev, dtype=torch.float32)
             wsp = C.c_void_p(wsplit.data_ptr()) if wsplit is not None else None
             common = (C.byref(cfg), C.c_void_p(wpack.data_ptr()), wsp, C.c_void_p(corr_pos.data_ptr()),
-                      C.c_void_p(src_keypts.data_ptr()), C.c_void_p(tgt_keypts.data_ptr()), bs, n, num_seeds,
-                      C.c_void_p(final_trans.data_ptr()), C.c_void_p(final_labels.data_ptr()))
+                      C.c_void_p(src_keypts.data_ptr()), C.c_void_p(tgt_keypts.data_ptr()), bs, n, num_seeds)
+            outs = (C.c_void_p(final_trans.data_ptr()), C.c_void_p(final_labels.data_ptr()))
             stream = torch.cuda.current_stream().cuda_stream
-            if testing:
-                M = None
-                rc = lib.pdsc_forward_testing(*common, C.c_void_p(ws.data_ptr()), nbytes, stream)
+            M = None
+            if counts is not None:
+                seeds_per = [int(c * self.ratio) for c in counts]
+                if min(seeds_per) < 1:
+                    raise ValueError("every pair needs int(num_corr * ratio) >= 1 seeds (the reference fails on an empty seed set)")
+                cnt = torch.tensor([counts, seeds_per], dtype=torch.int32).to(dev, non_blocking=False)
+                rc = lib.pdsc_forward_testing_ragged(*common, C.c_void_p(cnt[0].data_ptr()), C.c_void_p(cnt[1].data_ptr()), min(counts),
+                                                     *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
+                self._last_counts = cnt      # (keeps the device arrays alive until the next call: the launches are asynchronous)
+                what = "pdsc_forward_testing_ragged"
+            elif testing:
+                rc = lib.pdsc_forward_testing(*common, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
+                what = "pdsc_forward_testing"
             else:
                 M = torch.empty(bs, n, n, device=dev, dtype=torch.float32)
-                rc = lib.pdsc_forward_validation(*common, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
-        _lib.check(rc, "pdsc_forward_testing" if testing else "pdsc_forward_validation")
+                rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
+                what = "pdsc_forward_validation"
+        _lib.check(rc, what)
         return {"final_trans": final_trans, "final_labels": final_labels, "M": M}
 
     def workspace_view(self, name: str, bs: int, n: int, dtype=torch.float32) -> torch.Tensor:

@@ -1593,3 +1593,86 @@ def test_full_size_batch_properties():
     res2 = _forward(model, shuf)
     assert (res2["final_trans"][0].cpu() - res["final_trans"][0].cpu()).abs().max() < 2e-3
     assert float((res2["final_labels"][0].cpu() != lab[0][perm]).float().mean()) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------------
+# ragged batches (real evaluation pairs differ in N; reference evaluation/test_3DMatch.py:126,
+# datasets/dataloader.py:6-31) -- pdsc_forward_testing_ragged
+# ------------------------------------------------------------------------------------------------------
+def _ragged_pairs(sizes, seed0, **kw):
+    return [synthetic.make_pair(n, seed=seed0 + i, **kw) for i, n in enumerate(sizes)]
+
+
+def _as_lists(pairs):
+    return {"corr_pos": [g(p["corr_pos"][0]) for p in pairs], "src_keypts": [g(p["src_keypts"][0]) for p in pairs],
+            "tgt_keypts": [g(p["tgt_keypts"][0]) for p in pairs], "testing": True}
+
+
+@pytest.mark.parametrize("sizes", [(3000, 4100, 5000, 5333), (5000, 4999, 4097, 4096, 4095, 3333, 2600, 5001),
+                                   (1000, 777, 640, 999), (257, 300, 1000, 2053, 5000)])
+def test_ragged_batch_equals_the_single_pair_calls(sizes):
+    """A batch of pairs with different N through pdsc_forward_testing_ragged (lists of per-pair tensors) against the same pairs
+    one call each: inlier masks bit-exact, R/t within 2e-5 (same stages on the same rows; only the launch plans -- fp32
+    summation orders -- are the batch's).  The last case is too heterogeneous for one launch plan: the module groups it."""
+    model, _ = _bench_model("n5000_b32")
+    pairs = _ragged_pairs(sizes, 900 + len(sizes), inlier_ratio=0.3)
+    with torch.no_grad():
+        got = model(_as_lists(pairs))
+        torch.cuda.synchronize()
+        assert isinstance(got["final_labels"], list) and got["final_trans"].shape == (len(sizes), 4, 4) and got["M"] is None
+        for i, p in enumerate(pairs):
+            one = _forward(model, p)
+            assert got["final_labels"][i].shape == (sizes[i],)
+            flips = int((got["final_labels"][i] != one["final_labels"][0]).sum())
+            dT = float((got["final_trans"][i] - one["final_trans"][0]).abs().max())
+            re, te = O.registration_errors(got["final_trans"][i].cpu(), p["gt_trans"][0])
+            assert flips == 0 and dT < 2e-5, (i, sizes[i], flips, dT)
+            assert re < 1.0 and te < 5.0, (i, re, te)
+
+
+def test_ragged_batch_padded_tensors_and_count_list():
+    """The other calling form: tensors padded to the longest pair + data['num_corr']; padding rows hold garbage on purpose
+    (NaN): nothing of a pair's result may depend on them; labels past a pair's count are zero.  Bit-identical to the list form."""
+    model, _ = _bench_model("n5000_b32")
+    sizes = (2500, 3100, 2048, 3099)
+    pairs = _ragged_pairs(sizes, 77, inlier_ratio=0.3)
+    n_max = max(sizes)
+    data = {"testing": True, "num_corr": torch.tensor(sizes)}
+    for k, wdt in (("corr_pos", 6), ("src_keypts", 3), ("tgt_keypts", 3)):
+        t = torch.full((len(sizes), n_max, wdt), float("nan"))
+        for i, p in enumerate(pairs):
+            t[i, : sizes[i]] = p[k][0]
+        data[k] = g(t)
+    with torch.no_grad():
+        a = model(data)
+        b = model(_as_lists(pairs))
+    torch.cuda.synchronize()
+    assert a["final_labels"].shape == (len(sizes), n_max) and bool(torch.isfinite(a["final_trans"]).all())
+    assert torch.equal(a["final_trans"], b["final_trans"])
+    for i, n in enumerate(sizes):
+        assert torch.equal(a["final_labels"][i, :n], b["final_labels"][i]) and float(a["final_labels"][i, n:].abs().sum()) == 0.0
+    # equal counts take the uniform entry point: bitwise the plain batched call
+    same = _ragged_pairs((2048, 2048, 2048), 5, inlier_ratio=0.3)
+    batch = {k: torch.cat([p[k] for p in same]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    u = _forward(model, batch)
+    with torch.no_grad():
+        r = model(dict({k: g(batch[k]) for k in batch}, testing=True, num_corr=[2048, 2048, 2048]))
+    assert torch.equal(u["final_trans"], r["final_trans"]) and torch.equal(u["final_labels"], r["final_labels"])
+
+
+def test_ragged_batch_rejections():
+    model, _ = _bench_model("n5000_b32")
+    pairs = _ragged_pairs((300, 400), 3)
+    data = _as_lists(pairs)
+    model.attention_precision = "fp32"
+    try:
+        with pytest.raises(NotImplementedError):
+            model(data)
+    finally:
+        model.attention_precision = "bf16x3"
+    del data["testing"]
+    with pytest.raises(NotImplementedError):
+        model(data)
+    with pytest.raises(ValueError):
+        model({"corr_pos": g(torch.zeros(2, 100, 6)), "src_keypts": g(torch.zeros(2, 100, 3)), "tgt_keypts": g(torch.zeros(2, 100, 3)),
+               "num_corr": [100, 101], "testing": True})
