@@ -126,6 +126,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of this run's outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="extra measured leg after the timed region (0 = off)")
+    ap.add_argument("--settle-seconds", type=float, default=0.5,
+                    help="untimed load before the timed region so that it does not sit on the clock ramp (0 = exactly W warm-up steps)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed on the CPU baseline (0 = sized for ~10-20 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
     ap.add_argument("--cpu-timeout", type=float, default=240.0, help="wall-clock cap for the CPU baseline leg")
@@ -201,7 +203,29 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    log("warm-up done; timing")
+    # The chip is power-managed: it leaves its idle clocks only after tens of milliseconds of load, so W = 3-5 warm-up steps
+    # of a 2 ms step (the per-GPU share of an 8-GPU run) would leave the timed K steps on the ramp (measured r03: 1707 pairs/s
+    # on the ramp, 1891 sustained, same code).  Keep stepping, untimed, until the GPU has been busy for --settle-seconds in all
+    # (same step count on every rank: decided by rank 0); the count is reported as warmup_settle_steps.
+    settle = 0
+    if args.settle_seconds > 0:
+        t_s = time.perf_counter()
+        probe = 0
+        while probe < 4:
+            step()
+            probe += 1
+        torch.cuda.synchronize()
+        per_step = max((time.perf_counter() - t_s) / 4, 1e-5)
+        settle = min(5000, max(0, int(math.ceil(args.settle_seconds / per_step)) - 4))
+        if world > 1:
+            t = torch.tensor([settle], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            settle = int(t.item())
+        for _ in range(settle):
+            step()
+        torch.cuda.synchronize()
+        settle += 4
+    log(f"warm-up done ({args.warmup} + {settle} settle steps); timing")
 
     n_layers = kw["num_layers"]
     _lib.check(lib.pdsc_profile_enable(args.steps * n_layers + 8), "pdsc_profile_enable")
@@ -291,6 +315,7 @@ def main():
     line = {
         "metric": "point-cloud pairs/sec @ N=%d corr" % N,
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "warmup_settle_steps": settle,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32" if fp32 else ("f32 (attention products as bf16x3 split, f32 accumulate" +

@@ -360,15 +360,17 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         // workgroup-per-tile kernel that small problems take
         const char* var = env_str("PDSC_LAYER_VARIANT");          // same rule as pdsc_layer_fused_split
         const bool block_layer = !x3_gemm && ((var && var[0] == 'b') || (!(var && var[0] == 'w') && pdsc_layer_prefers_block(bs, N)));
-        const bool fuse_merge = fuse_env && ns > 1 && ns <= (block_layer ? 8 : 4);
-        const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;
-        const float* part_ml = fuse_merge ? part_o + (size_t)bs * ns * Npad * C : nullptr;
         // tuning/A-B knob: PDSC_LAYER_FRAG = 0 = natural-layout weights (pdsc_layer_fused_split)
         const bool frag_env = env_int("PDSC_LAYER_FRAG", 1) && !(var && var[0] == 'b');
         // default: wavefront-resident layer kernel on fragment streams; small problems: the workgroup-per-tile kernel (layer.hip)
         const bool frag = frag_env && !x3_gemm && ((var && var[0] == 'w') || !pdsc_layer_prefers_block(bs, N));
         // arithmetic of fc1..fc3 / PointCN in that kernel (enum pdsc_layer_gemm); A/B knob PDSC_LAYER_GEMM = 0 / 1 overrides
         const int gemm = env_int("PDSC_LAYER_GEMM", cfg->layer_gemm) == PDSC_LAYER_GEMM_H3 ? PDSC_LAYER_GEMM_H3 : PDSC_LAYER_GEMM_F32;
+        // (merge_partials.h: 4 splits in layer_wave.hip, 8 in the workgroup-per-tile kernel and in layer_h3.hip)
+        const bool h3_kernel = frag && gemm == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_PF", 1) != 0 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
+        const bool fuse_merge = fuse_env && ns > 1 && ns <= ((block_layer || h3_kernel) ? 8 : 4);
+        const float* part_o = fuse_merge ? (const float*)att_scratch : nullptr;
+        const float* part_ml = fuse_merge ? part_o + (size_t)bs * ns * Npad * C : nullptr;
         const int ws_tail = gemm == PDSC_LAYER_GEMM_H3 ? PDSC_WS_FRAG_TAIL_H3 : PDSC_WS_FRAG_TAIL;
         const int ws_head = gemm == PDSC_LAYER_GEMM_H3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD;
         // H3 + fused merge: the hand-offs attention -> layer kernel -> next layer kernel in point-fragment order (split_layout.h);

@@ -472,16 +472,18 @@ extern "C" int pdsc_spatial_compat_u16(const float* src, const float* tgt, const
     const dim3 grid((unsigned)(nt * (nt + 1) / 2), bs);
     pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
 #ifdef PDSC_EXPERIMENTS
-    // A/B knob (experiments builds only): 0 = r02 kernel (rounded exact fp32 matrix), 2 = fast kernel relying on the
-    // conversion instruction's own clamp
-    const int variant = pdsc::env_int("PDSC_COMPAT16_VARIANT", 1);
+    // A/B knob (experiments builds only): 0 = r02 kernel (rounded exact fp32 matrix), 1 = fast kernel with an explicit
+    // max(c, 0) in front of the conversion
+    const int variant = pdsc::env_int("PDSC_COMPAT16_VARIANT", 2);
     if (variant == 0)
         hipLaunchKernelGGL(pdsc::compat_sym_u16_exact_kernel, dim3(nt, nt, bs), dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N);
-    else if (variant == 2)
-        hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel<false>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N, nt);
+    else if (variant == 1)
+        hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N, nt);
     else
 #endif
-    hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel<true>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N, nt);
+    // v_cvt_pknorm_u16_f32 clamps to [0, 1] itself: bit-identical output with and without the explicit max (measured on every
+    // entry of five matrices, profiles/r03_a_compat_bench.txt), 3 % faster without
+    hipLaunchKernelGGL(pdsc::compat_sym_u16_kernel<false>, grid, dim3(256), 0, st, src, tgt, sigma_spat, compat_u16, ld, N, nt);
     pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
     return pdsc::check_launch("pdsc_spatial_compat_u16");
 }

@@ -24,7 +24,7 @@
 
 namespace pdsc {
 
-constexpr int PDSC_H3_SMALL_TILES = 1536;     // launches with at most this many 32-point tiles take the small-launch shape
+constexpr int PDSC_H3_SMALL_TILES = 1024;     // launches with at most this many 32-point tiles take the small-launch shape
 
 #define LH_STAMP(k) \
     if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
             // merge of the attention's key-split partials, the arithmetic of merge_partials_finish (merge_partials.h)
             auto run = [&](auto ns_tag) {
                 constexpr int NS = decltype(ns_tag)::value;
-                constexpr int GQ = NS <= 2 ? 16 : 8;                 // k-steps per batch of loads (up to 128 registers in flight)
+                constexpr int GQ = NS <= 2 ? 16 : NS <= 4 ? 8 : 4;   // k-steps per batch of loads (up to 128 registers in flight)
                 const size_t slot0 = (size_t)b * NS * a.Npad + (row - (size_t)b * a.N);
                 // element q of split sp: rows order = row `slot`, floats 8q + 4h; point-fragment order = tile base + 256 q + 4 lane
                 const bool pf = a.io_flags & PDSC_IO_PARTIALS_PF;
@@ -151,7 +151,11 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                 case 1: run(std::integral_constant<int, 1>{}); break;
                 case 2: run(std::integral_constant<int, 2>{}); break;
                 case 3: run(std::integral_constant<int, 3>{}); break;
-                default: run(std::integral_constant<int, 4>{}); break;
+                case 4: run(std::integral_constant<int, 4>{}); break;
+                case 5: run(std::integral_constant<int, 5>{}); break;
+                case 6: run(std::integral_constant<int, 6>{}); break;
+                case 7: run(std::integral_constant<int, 7>{}); break;
+                default: run(std::integral_constant<int, 8>{}); break;
             }
         }
     } else {
@@ -364,12 +368,17 @@ bool launch_layer_h3_fits(const LayerArgs& a, bool tail, bool head) {
     return a.wf_tail || !tail;
 }
 
-// launch shape for `tiles` wavefront-tiles: (waves per workgroup, weight-ring depth), see the kernel's NWV / NBUF note
+// launch shape for `tiles` wavefront-tiles: (waves per workgroup, weight-ring depth), see the kernel's NWV / NBUF note.
+// Measured (profiles/r03_a_ab_*.txt, whole forward): 4 pairs of N=5000 (625 tiles) -4.8 % per step with the small-launch
+// shape, 2 pairs (314 tiles) -4.7 %, one pair of N=10000 (313 tiles) -5.1 %; 8 pairs (1250 tiles) +-0.5 %: no gain any more.
+// The ring depth carries most of it ((2,2): +0.5 %, (2,3): -4.5 %, (1,3) / (2,4) / (1,4): -5.0 ... -5.4 %).
 static void h3_launch_shape(int tiles, int* nwv, int* nbuf) {
     *nwv = LW_WAVES; *nbuf = 2;
-    if (tiles <= PDSC_H3_SMALL_TILES) { *nwv = tiles <= 512 ? 1 : 2; *nbuf = 3; }
+    if (tiles <= PDSC_H3_SMALL_TILES) { *nwv = 1; *nbuf = 4; }
+#ifdef PDSC_EXPERIMENTS
     const int force = env_int("PDSC_LAYER_H3_SHAPE", 0);          // A/B knob (experiments builds): 10 * waves + depth, e.g. 23
     if (force == 42 || force == 23 || force == 13 || force == 24 || force == 14 || force == 22) { *nwv = force / 10; *nbuf = force % 10; }
+#endif
 }
 
 int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
@@ -380,14 +389,21 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     const bool fb_pf = a.io_flags & PDSC_IO_FEATB_PF;
     const bool timed = tail && head;
     if (timed) profile_mark_begin(PDSC_PROF_LAYER, st);
-    // every (tail, head, featB order) form in the default shape and in the small-launch shapes
-#define PDSC_H3_LAUNCH(TT, HH, PF)                                                                                                  \
-    do {                                                                                                                            \
+    // every (tail, head, featB order) form in the default shape and in the small-launch shape (+ the A/B shapes)
+#ifdef PDSC_EXPERIMENTS
+#define PDSC_H3_LAUNCH_EXTRA(TT, HH, PF)                                                                                            \
         if (nwv == 2 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 3>), grid, block, 0, st, a);      \
         else if (nwv == 1 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 3>), grid, block, 0, st, a); \
         else if (nwv == 2 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 4>), grid, block, 0, st, a); \
-        else if (nwv == 1 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 4>), grid, block, 0, st, a); \
         else if (nwv == 2 && nbuf == 2) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 2>), grid, block, 0, st, a); \
+        else
+#else
+#define PDSC_H3_LAUNCH_EXTRA(TT, HH, PF)
+#endif
+#define PDSC_H3_LAUNCH(TT, HH, PF)                                                                                                  \
+    do {                                                                                                                            \
+        PDSC_H3_LAUNCH_EXTRA(TT, HH, PF)                                                                                            \
+        if (nwv == 1 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 4>), grid, block, 0, st, a);      \
         else hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF>), grid, block, 0, st, a);                                  \
     } while (0)
     if (tail && head && fb_pf) {
@@ -415,6 +431,7 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
         PDSC_H3_LAUNCH(false, true, false);
     }
 #undef PDSC_H3_LAUNCH
+#undef PDSC_H3_LAUNCH_EXTRA
     if (timed) profile_mark_end(PDSC_PROF_LAYER, st);
     return check_launch("pdsc_layer_fused_frag(h3)");
 }
@@ -439,8 +456,8 @@ extern "C" int pdsc_layer_fused_frag_io(const float* msg, const float* part_o, c
     PDSC_REQUIRE(gemm_format == PDSC_LAYER_GEMM_H3, "pdsc_layer_fused_frag_io: point-fragment hand-offs need gemm_format = PDSC_LAYER_GEMM_H3");
     if (tail) {
         PDSC_REQUIRE(res && wfrag_tail, "pdsc_layer_fused_frag_io: tail needs res and the tail stream");
-        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= MERGE_MAX_SPLIT && Npad >= N,
-                               "pdsc_layer_fused_frag_io: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", MERGE_MAX_SPLIT);
+        if (!msg) PDSC_REQUIRE(part_ml && nsplit >= 1 && nsplit <= MERGE_MAX_SPLIT_H3 && Npad >= N,
+                               "pdsc_layer_fused_frag_io: partials need part_ml, 1 <= nsplit <= %d, Npad >= N", MERGE_MAX_SPLIT_H3);
         PDSC_REQUIRE(!(io_flags & PDSC_IO_PARTIALS_PF) || (!msg && Npad % 32 == 0), "pdsc_layer_fused_frag_io: PF partials come un-merged (msg NULL), Npad a multiple of 32");
     } else {
         PDSC_REQUIRE(feat_in, "pdsc_layer_fused_frag_io: head-only needs feat_in");

@@ -9,6 +9,8 @@ namespace pdsc {
 
 constexpr int MERGE_MAX_SPLIT = 4;        // larger key splits go through attention_combine_kernel ...
 constexpr int MERGE_MAX_SPLIT_BLOCK = 8;  // ... except in the workgroup-per-tile layer kernel (layer.hip: small problems)
+constexpr int MERGE_MAX_SPLIT_H3 = 8;     // ... and in layer_h3.hip (r03: the per-GPU shares of the 8-GPU configurations -- 1-3 pairs of
+                                          //     N = 5000 / 10000 -- are planned with 5-8 key splits: no combine launch, no msg round trip)
 
 __device__ __forceinline__ f32x4 merge_partials_chunk(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                       size_t slot0, size_t sp_stride, int ns, int c4) {

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Experiment: does splitting a small batch over two HIP streams (two workspaces) hide the latency-bound small kernels of
-one half under the attention of the other?   python tools/overlap_probe.py [--n 5000] [--bs 4]"""
+"""Experiments with two HIP streams (two module instances = two workspaces):
+  * does splitting a small batch over two streams hide the latency-bound small kernels of one half under the attention of
+    the other?  (r01/r02: no)
+  * r03: two WHOLE steps in flight -- consecutive forwards of full batches alternate between two streams, so the
+    latency-bound tail of step i (NMS, seed ranking, kNN, solver, scoring, refinement: ~1 ms at 32 pairs on a few CUs) can
+    overlap the compat build and the first layers of step i+1.
+python tools/overlap_probe.py [--n 5000] [--bs 4]"""
 import argparse
 import copy
 import sys
@@ -50,9 +55,18 @@ def main():
         cur.wait_stream(s1); cur.wait_stream(s2)
         return torch.cat([a, b])
 
+    def two_steps_in_flight():
+        # called once per step: even steps on s1 / model, odd steps on s2 / twin; nothing waits until the caller synchronises
+        two_steps_in_flight.i ^= 1
+        with torch.cuda.stream(s1 if two_steps_in_flight.i else s2):
+            return (model if two_steps_in_flight.i else twin)(data)["final_trans"]
+    two_steps_in_flight.i = 0
+
     with torch.no_grad():
         ref = whole()
-        for name, fn in (("one call", whole), ("two halves, one stream", halves_serial), ("two halves, two streams", halves_two_streams)):
+        modes = (("one call", whole),) + ((("two halves, one stream", halves_serial), ("two halves, two streams", halves_two_streams)) if args.bs >= 2 else ()) \
+            + (("whole steps alternating on two streams", two_steps_in_flight),)
+        for name, fn in modes:
             for _ in range(3):
                 out = fn()
             torch.cuda.synchronize()

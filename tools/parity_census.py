@@ -45,7 +45,7 @@ def judge(trans: torch.Tensor, labels: torch.Tensor, fx, n: int, first: int = 0)
     return ok32 | ok64, d32, torch.where(ok32, d32, torch.minimum(d32, d64)), f32, torch.where(ok32, 0, torch.where(ok64, 1, -1))
 
 
-def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0):
+def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0, attention_precision=None):
     fx = np.load(ROOT / "tests" / "golden" / f"census_{name}.npz", allow_pickle=False)
     w = workloads.WORKLOADS[name]
     n = w["num_corr"]
@@ -57,6 +57,8 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
         model.compat_format = compat_format
     if layer_gemm:
         model.layer_gemm = layer_gemm
+    if attention_precision:
+        model.attention_precision = attention_precision
     out = {}
     for step in batches:
         T, L = [], []
@@ -71,7 +73,14 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
         ok, d32, dbest, f32, which = judge(torch.cat(T), torch.cat(L), fx, n)
         d = dbest.numpy()
         hist = [int(((d >= lo) & (d < hi)).sum()) for lo, hi in zip((0.0,) + EDGES, EDGES + (np.inf,))]
+        t64 = torch.from_numpy(fx["ref64_final_trans"][:total]).double()
+        d64 = (torch.cat(T).double() - t64).abs().amax(dim=(1, 2))
+        ref_self = (torch.from_numpy(fx["ref32_final_trans"][:total]).double() - t64).abs().amax(dim=(1, 2))
         out[step] = {"pairs": int(total), "failing_pairs": [int(i) for i in np.flatnonzero(~ok.numpy())],
+                     "failing_detail": [{"pair": int(i), "dT_vs_ref_fp32": float(d32[i]), "dT_vs_ref_fp64": float(d64[i]),
+                                         "label_flips_vs_ref_fp32": int(f32[i]), "reference_fp32_vs_fp64_dT": float(ref_self[i])}
+                                        for i in np.flatnonzero(~ok.numpy())],
+                     "reference_self_disagreement_above_1e-4": [int(i) for i in np.flatnonzero(ref_self.numpy() >= 1e-4)],
                      "label_flips_vs_fp32_reference": int(f32.sum()), "pairs_matched_on_fp64_reference": [int(i) for i in np.flatnonzero(which.numpy() == 1)],
                      "median_dT": float(np.median(d)), "max_dT": float(d.max()), "max_dT_vs_fp32_reference": float(d32.max()),
                      "dT_histogram": dict(zip(["<1e-6", "<1e-5", "<2e-5", "<5e-5", "<1e-4", ">=1e-4"], hist))}
@@ -84,6 +93,7 @@ def main():
     ap.add_argument("--batches", default="0", help="comma list of batch sizes; 0 = the workload's global batch")
     ap.add_argument("--compat-format", default=None)
     ap.add_argument("--layer-gemm", default=None)
+    ap.add_argument("--attention-precision", default=None, help='"fp32" = the exact-fp32 path (with --compat-format f32 --layer-gemm f32)')
     ap.add_argument("--pairs", type=int, default=0, help="first K pairs of each family only")
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
@@ -92,14 +102,17 @@ def main():
         if (a.only and name != a.only) or not (ROOT / "tests" / "golden" / f"census_{name}.npz").exists():
             continue
         batches = [int(x) or w["global_batch"] for x in a.batches.split(",")]
-        rep, model = run_family(name, batches, a.compat_format, a.layer_gemm, a.pairs)
+        rep, model = run_family(name, batches, a.compat_format, a.layer_gemm, a.pairs, a.attention_precision)
         report[name] = rep
         if not a.json:
             for step, r in rep.items():
-                print(f"{name} (N={w['num_corr']}, compat {model.compat_format}, layer_gemm {model.layer_gemm}) batches of {step}: {r['pairs']} pairs, "
-                      f"FAIL {r['failing_pairs']}, label flips vs fp32 ref {r['label_flips_vs_fp32_reference']}, matched on the fp64 ref "
-                      f"{r['pairs_matched_on_fp64_reference']}, max|dT| median {r['median_dT']:.1e} max {r['max_dT']:.1e}, histogram {r['dT_histogram']}",
+                print(f"{name} (N={w['num_corr']}, attention {model.attention_precision}, compat {model.compat_format}, layer_gemm {model.layer_gemm}) "
+                      f"batches of {step}: {r['pairs']} pairs, FAIL {r['failing_pairs']}, label flips vs fp32 ref {r['label_flips_vs_fp32_reference']}, "
+                      f"matched on the fp64 ref {r['pairs_matched_on_fp64_reference']}, max|dT| median {r['median_dT']:.1e} max {r['max_dT']:.1e}, "
+                      f"histogram {r['dT_histogram']}; the reference's own fp32 and fp64 runs differ by >= 1e-4 on {r['reference_self_disagreement_above_1e-4']}",
                       flush=True)
+                for fd in r["failing_detail"]:
+                    print("    ", json.dumps(fd), flush=True)
     if a.json:
         print(json.dumps(report))
     return 1 if any(r["failing_pairs"] for rep in report.values() for r in rep.values()) else 0
