@@ -495,6 +495,9 @@ enum pdsc_profile_kind { PDSC_PROF_ATTENTION = 0, PDSC_PROF_COMPAT = 1, PDSC_PRO
                          PDSC_PROF_NUM_KINDS = 3 };
 int pdsc_profile_enable(int max_records_per_kind);   /* 0 disables and frees the events */
 int pdsc_profile_reset(void);
+/* bracket only every stride-th launch of `kind` (an event record costs the stream a few microseconds and separates the
+ * kernels around it; bench.py samples one attention / layer launch per forward: the launches of a kind do identical work) */
+int pdsc_profile_set_stride(int kind, int stride);
 int pdsc_profile_read(int kind, double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -97,6 +97,7 @@ SIGNATURES = {
     "pdsc_post_refinement": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _vp]),
     "pdsc_profile_enable": (_i, [_i]),
     "pdsc_profile_reset": (_i, []),
+    "pdsc_profile_set_stride": (_i, [_i, _i]),
     "pdsc_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pdsc_match_scratch_bytes": (_sz, [_i, _i]),
     "pdsc_match_descriptors": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

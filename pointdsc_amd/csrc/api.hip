@@ -55,12 +55,15 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
 }
 
 // ---- opt-in event timing -----------------------------------------------------------------------
-struct ProfKind { hipEvent_t* start = nullptr; hipEvent_t* stop = nullptr; int cap = 0, n = 0; bool open = false; };
+// stride: only every stride-th launch of the kind is bracketed by events (an event record costs the stream ~3.5 us and breaks
+// the back-to-back issue of the kernels around it: 50 records per forward were 8 % of a 2 ms step)
+struct ProfKind { hipEvent_t* start = nullptr; hipEvent_t* stop = nullptr; int cap = 0, n = 0, stride = 1; long long calls = 0; bool open = false; };
 static ProfKind g_prof[PDSC_PROF_NUM_KINDS];
 
 void profile_mark_begin(int kind, hipStream_t st) {
     ProfKind& p = g_prof[kind];
     if (p.cap == 0 || p.n >= p.cap) return;
+    if ((p.calls++ % p.stride) != 0) return;
     (void)hipEventRecord(p.start[p.n], st);
     p.open = true;
 }
@@ -243,7 +246,9 @@ extern "C" int pdsc_profile_enable(int max_records) {
         ProfKind& p = g_prof[k];
         for (int i = 0; i < p.cap; ++i) { (void)hipEventDestroy(p.start[i]); (void)hipEventDestroy(p.stop[i]); }
         delete[] p.start; delete[] p.stop;
+        const int keep_stride = p.stride;
         p = ProfKind();
+        p.stride = keep_stride;
         if (max_records > 0) {
             p.start = new hipEvent_t[max_records];
             p.stop = new hipEvent_t[max_records];
@@ -257,7 +262,13 @@ extern "C" int pdsc_profile_enable(int max_records) {
     return PDSC_OK;
 }
 extern "C" int pdsc_profile_reset(void) {
-    for (int k = 0; k < PDSC_PROF_NUM_KINDS; ++k) { g_prof[k].n = 0; g_prof[k].open = false; }
+    for (int k = 0; k < PDSC_PROF_NUM_KINDS; ++k) { g_prof[k].n = 0; g_prof[k].open = false; g_prof[k].calls = 0; }
+    return PDSC_OK;
+}
+extern "C" int pdsc_profile_set_stride(int kind, int stride) {
+    PDSC_REQUIRE(kind >= 0 && kind < PDSC_PROF_NUM_KINDS && stride >= 1, "pdsc_profile_set_stride: kind=%d stride=%d", kind, stride);
+    g_prof[kind].stride = stride;
+    g_prof[kind].calls = 0;
     return PDSC_OK;
 }
 extern "C" int pdsc_profile_read(int kind, double* total_ms, int* launches) {
@@ -358,14 +369,18 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const int fuse_env = env_int("PDSC_FUSE_MERGE", 1);      // tuning/A-B knob
         // the layer kernels merge the key-split partials while loading (merge_partials.h): up to 4 splits, 8 in the
         // workgroup-per-tile kernel that small problems take
-        const char* var = env_str("PDSC_LAYER_VARIANT");          // same rule as pdsc_layer_fused_split
-        const bool block_layer = !x3_gemm && ((var && var[0] == 'b') || (!(var && var[0] == 'w') && pdsc_layer_prefers_block(bs, N)));
+        const char* var = env_str("PDSC_LAYER_VARIANT");          // (experiments builds) b / w: force the workgroup-per-tile / wavefront kernel
+        // arithmetic of fc1..fc3 / PointCN (enum pdsc_layer_gemm); A/B knob PDSC_LAYER_GEMM = 0 / 1 overrides
+        const int gemm = env_int("PDSC_LAYER_GEMM", cfg->layer_gemm) == PDSC_LAYER_GEMM_H3 ? PDSC_LAYER_GEMM_H3 : PDSC_LAYER_GEMM_F32;
+        // Which layer kernel.  H3 GEMMs: always the wavefront-resident layer_h3_kernel -- since r03 its small-launch shape (one
+        // wavefront per workgroup, four weight chunks in flight) also wins where the tiles leave CUs empty (N = 1000 x 1: 0.511 vs
+        // 0.557 ms per forward, N = 5000 x 1: 0.993 vs 1.034, profiles/r03_b_ab_*.txt).  fp32 GEMMs: layer_wave_kernel, or the
+        // workgroup-per-tile kernel of layer.hip for small problems (pdsc_layer_prefers_block).
+        const bool small = pdsc_layer_prefers_block(bs, N) && gemm != PDSC_LAYER_GEMM_H3;
+        const bool block_layer = !x3_gemm && ((var && var[0] == 'b') || (!(var && var[0] == 'w') && small));
         // tuning/A-B knob: PDSC_LAYER_FRAG = 0 = natural-layout weights (pdsc_layer_fused_split)
         const bool frag_env = env_int("PDSC_LAYER_FRAG", 1) && !(var && var[0] == 'b');
-        // default: wavefront-resident layer kernel on fragment streams; small problems: the workgroup-per-tile kernel (layer.hip)
-        const bool frag = frag_env && !x3_gemm && ((var && var[0] == 'w') || !pdsc_layer_prefers_block(bs, N));
-        // arithmetic of fc1..fc3 / PointCN in that kernel (enum pdsc_layer_gemm); A/B knob PDSC_LAYER_GEMM = 0 / 1 overrides
-        const int gemm = env_int("PDSC_LAYER_GEMM", cfg->layer_gemm) == PDSC_LAYER_GEMM_H3 ? PDSC_LAYER_GEMM_H3 : PDSC_LAYER_GEMM_F32;
+        const bool frag = frag_env && !x3_gemm && ((var && var[0] == 'w') || !small);
         // (merge_partials.h: 4 splits in layer_wave.hip, 8 in the workgroup-per-tile kernel and in layer_h3.hip)
         const bool h3_kernel = frag && gemm == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_PF", 1) != 0 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
         const bool fuse_merge = fuse_env && ns > 1 && ns <= ((block_layer || h3_kernel) ? 8 : 4);

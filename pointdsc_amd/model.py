@@ -132,6 +132,8 @@ class PointDSC(nn.Module):
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
+        self._workspaces: Dict[int, torch.Tensor] = {}      # one per in-flight slot (pointdsc_amd.pipeline.InFlight); slot 0 = the plain call
+        self._ws_slot = 0
 
     # ------------------------------------------------------------------------------------------
     def _config(self) -> _lib.PdscConfig:
@@ -244,10 +246,11 @@ class PointDSC(nn.Module):
         return self._wsplit
 
     def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
-        ws = self._workspace
+        ws = self._workspaces.get(self._ws_slot)
         if ws is None or ws.device != device or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._workspace = ws
+            self._workspaces[self._ws_slot] = ws
+        self._workspace = ws                               # workspace_view(): intermediates of the LAST forward
         return ws
 
     # ------------------------------------------------------------------------------------------
@@ -382,7 +385,9 @@ class PointDSC(nn.Module):
                 cnt = torch.tensor([counts, seeds_per], dtype=torch.int32).to(dev, non_blocking=False)
                 rc = lib.pdsc_forward_testing_ragged(*common, C.c_void_p(cnt[0].data_ptr()), C.c_void_p(cnt[1].data_ptr()), min(counts),
                                                      *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
-                self._last_counts = cnt      # (keeps the device arrays alive until the next call: the launches are asynchronous)
+                if not hasattr(self, "_last_counts"):
+                    self._last_counts = {}
+                self._last_counts[self._ws_slot] = cnt      # (keeps the device arrays alive until the slot's next call: the launches are asynchronous)
                 what = "pdsc_forward_testing_ragged"
             elif testing:
                 rc = lib.pdsc_forward_testing(*common, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)

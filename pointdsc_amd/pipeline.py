@@ -1,0 +1,80 @@
+"""Several forwards of one ``PointDSC`` module in flight: consecutive batches alternate between ``depth`` HIP streams, each with
+its own workspace, so that the latency-bound tail of one forward (NMS, seed ranking, kNN, per-seed solver, scoring,
+refinement: a chain of ~15 small launches that occupy a few CUs) overlaps the compat build and the first layers of the next.
+
+Measured on one MI355X (profiles/r03_b_overlap_probe.txt): 32 pairs of N=5000 per step 14.96 -> 14.57 ms, 4 pairs (the
+per-GPU share of the 8-GPU configuration) 2.06 -> 1.89 ms, one pair of N=1000 0.558 -> 0.354 ms per step.  Results are bit
+for bit those of the plain call: every forward is still one ``pdsc_forward_testing`` over its own workspace; only WHEN its
+kernels run changes.  Weights (packed / split buffers) are shared and read-only.
+
+    runner = InFlight(model, depth=2)
+    for data in batches:                   # tensors on the GPU
+        res = runner(data)                 # returns at once; res["ready"] is an event on the forward's stream
+        ...
+    runner.synchronize()                   # or: torch.cuda.current_stream().wait_event(res["ready"]) before using res
+
+The reference has nothing like it (its testing loop is one synchronous call per pair, evaluation/test_3DMatch.py:32-54).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+
+class InFlight:
+    def __init__(self, model, depth: int = 2, device=None):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.model = model
+        self.depth = depth
+        dev = device if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("pointdsc_amd has no CPU path: move the model to the GPU first")
+        self.device = dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [None]
+        self._i = 0
+        self._ensure_weights()
+
+    def _ensure_weights(self) -> None:
+        """The packed / split weight buffers are built lazily by the first forward after a weight change -- on ONE stream; the
+        other streams must not read them before that build has finished."""
+        m = self.model
+        if m._wpack is None or (m.attention_precision != "fp32" and m._wsplit is None):
+            with torch.cuda.device(self.device):
+                m.packed_weights(self.device)
+                if m.attention_precision != "fp32":
+                    m.split_weights(self.device)
+                torch.cuda.current_stream(self.device).synchronize()
+
+    def __call__(self, data: Dict, post: Optional[Callable[[Dict], object]] = None) -> Dict:
+        """Enqueue one forward (and ``post(res)``, e.g. the pose all_gather of a multi-GPU job, behind it on the same
+        stream).  Inputs may have been produced on the caller's current stream: the forward's stream waits for it."""
+        self._ensure_weights()
+        slot = self._i % self.depth
+        self._i += 1
+        s = self.streams[slot]
+        if s is None:                                            # depth 1: the plain synchronous-enqueue call
+            with torch.no_grad():
+                res = self.model(data)
+            if post is not None:
+                res["post"] = post(res)
+            return res
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s), torch.no_grad():
+            self.model._ws_slot = slot
+            try:
+                res = self.model(data)
+            finally:
+                self.model._ws_slot = 0
+            if post is not None:
+                res["post"] = post(res)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        res["ready"] = ev
+        return res
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            if s is not None:
+                s.synchronize()

@@ -137,3 +137,25 @@ def test_single_process_passthrough():
     data = {"corr_pos": torch.randn(3, 10, 6), "testing": True}
     out = sharding.forward_sharded(_fake_forward, data)
     assert torch.equal(out["final_trans"], _fake_forward(data)["final_trans"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,expect_per_rank", [("n5000_b32", 4), ("kitti_n5000_b16", 2), ("lomatch_n10000_b8", 1)])
+def test_eight_rank_bench_rehearsal_on_one_gpu(config, expect_per_rank):
+    """`bench.py --gpus 8` for the BASELINE.json configurations that are sharded over 8 GPUs (4 / 2 / 1 pairs per rank), launched
+    exactly as the driver launches it (torch.distributed.run, one process per rank) but with --backend gloo so that all 8 ranks
+    share the one visible GPU: sharding, the per-rank forwards in flight, the pose all_gather behind each forward, the
+    max-over-ranks timing and the single JSON line.  A rehearsal of the code path, not a scaling measurement."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--config", config, "--no-cpu-baseline", "--sustain-seconds", "0", "--settle-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["pairs_per_gpu"] == expect_per_rank and line["scaling"] == "strong"
+    assert line["value"] > 0 and line["check"]["ok"] is not False and line["in_flight"] == 2
