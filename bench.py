@@ -238,12 +238,20 @@ def main():
     log(f"warm-up done ({args.warmup} + {settle} settle steps); timing")
 
     n_layers = kw["num_layers"]
-    # hipEvents around ONE attention launch and ONE fused layer launch per forward (of 12 / 11 that do identical work) and around
-    # the compat build: bracketing all 24 cost the stream ~50 event records per forward = 8 % of a 2 ms step
-    _lib.check(lib.pdsc_profile_enable(args.steps + 8), "pdsc_profile_enable")
-    _lib.check(lib.pdsc_profile_set_stride(0, n_layers), "pdsc_profile_set_stride")
-    _lib.check(lib.pdsc_profile_set_stride(2, max(n_layers - 1, 1)), "pdsc_profile_set_stride")
-    _lib.check(lib.pdsc_profile_reset(), "pdsc_profile_reset")
+
+    def events_on():
+        # hipEvents around ONE attention launch and ONE fused layer launch per forward (of 12 / 11 that do identical work) and
+        # around the compat build: bracketing all 24 cost the stream ~50 event records per forward = 8 % of a 2 ms step
+        _lib.check(lib.pdsc_profile_enable(args.steps + 8), "pdsc_profile_enable")
+        _lib.check(lib.pdsc_profile_set_stride(0, n_layers), "pdsc_profile_set_stride")
+        _lib.check(lib.pdsc_profile_set_stride(2, max(n_layers - 1, 1)), "pdsc_profile_set_stride")
+        _lib.check(lib.pdsc_profile_reset(), "pdsc_profile_reset")
+
+    # With several forwards in flight the kernels of two streams share the chip, so a kernel's event-to-event time is no longer
+    # its own duration: the roofline events are then recorded during the single-stream K steps that follow the timed region
+    # (same run, same data); with --in-flight 1 they are recorded during the timed region itself.
+    if depth["d"] == 1:
+        events_on()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -256,16 +264,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernels, from the events recorded during the timed region ----
+    # ---- roofline of the dominant kernels, from the recorded events ----
     def read(kind):
         ms, n = C.c_double(0), C.c_int(0)
         _lib.check(lib.pdsc_profile_read(kind, C.byref(ms), C.byref(n)), "pdsc_profile_read")
         return ms.value, n.value
 
-    att_ms, att_n = read(0)
-    cmp_ms, cmp_n = read(1)
-    lay_ms, lay_n = read(2)
-    _lib.check(lib.pdsc_profile_enable(0), "pdsc_profile_enable(0)")
+    if depth["d"] == 1:
+        (att_ms, att_n), (cmp_ms, cmp_n), (lay_ms, lay_n) = read(0), read(1), read(2)
+        _lib.check(lib.pdsc_profile_enable(0), "pdsc_profile_enable(0)")
 
     # ---- sustained leg: the same step for >= sustain_seconds (same step count on every rank) ----
     sustained = None
@@ -290,12 +297,15 @@ def main():
         depth["d"] = 1
         for _ in range(3):
             step()
+        events_on()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         fence()
         one = time.perf_counter() - t0
+        (att_ms, att_n), (cmp_ms, cmp_n), (lay_ms, lay_n) = read(0), read(1), read(2)
+        _lib.check(lib.pdsc_profile_enable(0), "pdsc_profile_enable(0)")
         if world > 1:
             t = torch.tensor([one], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,8 +352,10 @@ def main():
             "frac": None if att_tflops is None else round(att_tflops / att_peak, 4),
             "traffic": None, "launches": att_n, "launches_per_forward": n_layers, "avg_launch_ms": round(att_avg * 1e3, 4),
             "flops_per_launch": att_flops,
-            "timing": "hipEvents on the launch stream around one launch per forward during the timed region (the %d launches of a forward "
-                      "do identical work)" % n_layers}
+            "timing": "hipEvents on the launch stream around one launch per forward (the %d launches of a forward do identical work), "
+                      "recorded during %s" % (n_layers, "the timed region" if depth["d"] == 1 else
+                                              "the single-stream K steps right after the timed region (with forwards in flight the "
+                                              "kernels of two streams overlap and an event pair no longer times one kernel)")}
     if not fp32:
         # `achieved` counts ALGORITHMIC flops (4 C N^2 per pair per launch) against the dense bf16 MFMA peak; the kernel
         # executes 3 bf16 MFMAs per algorithmic product (hi*hi, hi*lo, lo*hi): its matrix-pipe share is 3 x frac.

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import warnings
 import os
 from typing import Dict, Optional
 
@@ -132,6 +133,7 @@ class PointDSC(nn.Module):
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
+        self._h3_range_checked = False
         self._workspaces: Dict[int, torch.Tensor] = {}      # one per in-flight slot (pointdsc_amd.pipeline.InFlight); slot 0 = the plain call
         self._ws_slot = 0
 
@@ -228,6 +230,15 @@ class PointDSC(nn.Module):
         put("SIGMA", 0, self.sigma.detach())
         put("SIGMA_SPAT", 0, self.sigma_spat.detach())
         self._wpack, self._wsplit, self._wpack_key = pack, None, key
+        # H3 (layer_gemm = "h3") carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo: |x| must stay below
+        # 65504.  Checked once per packing: the folded weights here, the activations after the first forward (_run).
+        self._h3_range_checked = False
+        if self.layer_gemm == "h3":
+            wmax = float(pack.abs().max())
+            if not wmax < 3.0e4:
+                warnings.warn(f"pointdsc_amd: folded weights reach |w| = {wmax:.3g}, outside the fp16 range of layer_gemm='h3'; "
+                              "falling back to layer_gemm='f32' for this module", RuntimeWarning)
+                self.layer_gemm = "f32"
         return pack
 
     def split_weights(self, device=None) -> torch.Tensor:
@@ -397,6 +408,17 @@ class PointDSC(nn.Module):
                 rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
                 what = "pdsc_forward_validation"
         _lib.check(rc, what)
+        if self.layer_gemm == "h3" and not self._h3_range_checked and self.attention_precision != "fp32" and self.num_layers > 0:
+            # first forward after (re)packing the weights: the final features must be finite and far from the fp16 limit (one
+            # device->host sync, once per packing); otherwise this call and all later ones use the fp32 GEMMs
+            self._h3_range_checked = True
+            fmax = float(self.workspace_view("featA", bs, n)[: bs * n * 128].abs().max()) if counts is None else \
+                float(torch.nan_to_num(self.workspace_view("featA", bs, n)[: bs * n * 128].reshape(bs, n, 128)[:, : min(counts)], nan=float("inf")).abs().max())
+            if not fmax < 3.0e4:
+                warnings.warn(f"pointdsc_amd: activations reach {fmax:.3g}, outside the fp16 range of layer_gemm='h3'; "
+                              "re-running with layer_gemm='f32' (kept for this module)", RuntimeWarning)
+                self.layer_gemm = "f32"
+                return self._run(corr_pos, src_keypts, tgt_keypts, testing, counts)
         return {"final_trans": final_trans, "final_labels": final_labels, "M": M}
 
     def workspace_view(self, name: str, bs: int, n: int, dtype=torch.float32) -> torch.Tensor:

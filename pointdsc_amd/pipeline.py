@@ -11,7 +11,9 @@ kernels run changes.  Weights (packed / split buffers) are shared and read-only.
     for data in batches:                   # tensors on the GPU
         res = runner(data)                 # returns at once; res["ready"] is an event on the forward's stream
         ...
-    runner.synchronize()                   # or: torch.cuda.current_stream().wait_event(res["ready"]) before using res
+    runner.synchronize()                   # or, per result: torch.cuda.current_stream().wait_event(res["ready"]) (and
+                                           # t.record_stream(current) for result tensors that outlive the runner's next use
+                                           # of the slot) before using res on another stream
 
 The reference has nothing like it (its testing loop is one synchronous call per pair, evaluation/test_3DMatch.py:32-54).
 """
@@ -61,6 +63,12 @@ class InFlight:
                 res["post"] = post(res)
             return res
         s.wait_stream(torch.cuda.current_stream(self.device))
+        # the inputs were allocated on the caller's stream: tell the caching allocator that stream `s` reads them, or a tensor
+        # the caller drops right after this call could be handed out again while the forward is still running
+        for v in data.values():
+            for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(s)
         with torch.cuda.stream(s), torch.no_grad():
             self.model._ws_slot = slot
             try:
