@@ -62,7 +62,7 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline_worker(config: str, pairs: int, threads: int, check_pairs: int) -> None:
+def cpu_baseline_worker(config: str, pairs: int, threads: int, check_pairs: int, force_port: bool = False) -> None:
     """Child process: time the reference's CPU path on `pairs` pairs of the bench workload, then (untimed) run the exact
     oracle on `check_pairs` pairs for the parity check; prints one JSON line."""
     import warnings
@@ -76,7 +76,7 @@ def cpu_baseline_worker(config: str, pairs: int, threads: int, check_pairs: int)
     batch = workloads.batch(config, 0, max(pairs, check_pairs, 1))
     okw = {k: kw[k] for k in ORACLE_KEYS}
     kind, run = "port", None
-    if (REFERENCE_DIR / "models" / "PointDSC.py").exists():
+    if (REFERENCE_DIR / "models" / "PointDSC.py").exists() and not force_port:
         try:
             sys.path.insert(0, str(REFERENCE_DIR))
             from models.PointDSC import PointDSC as RefPointDSC     # the unmodified reference (build container only)
@@ -126,15 +126,19 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of this run's outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="extra measured leg after the timed region (0 = off)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=0,
                     help="forwards in flight: consecutive steps alternate between this many HIP streams (pointdsc_amd/pipeline.py); "
-                         "1 = every step on the current stream.  The single-stream rate is measured and reported either way")
+                         "1 = every step on the current stream; 0 = 2, or 4 captured hipGraphs when a step is one small problem (<= 4096 "
+                         "correspondences: its ~45 launches are latency- and host-bound).  The single-stream rate is measured and reported either way")
+    ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
+                    help="replay each in-flight slot's forward as a captured hipGraph (auto: only when a step is one small problem)")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed load before the timed region so that it does not sit on the clock ramp (0 = exactly W warm-up steps)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed on the CPU baseline (0 = sized for ~10-20 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
     ap.add_argument("--cpu-timeout", type=float, default=240.0, help="wall-clock cap for the CPU baseline leg")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-port", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--check-pairs", type=int, default=2, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -146,7 +150,7 @@ def fp32_att(args):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.config, args.cpu_pairs, args.cpu_threads or (os.cpu_count() or 1), args.check_pairs)
+        cpu_baseline_worker(args.config, args.cpu_pairs, args.cpu_threads or (os.cpu_count() or 1), args.check_pairs, args.force_port)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,8 +193,11 @@ def main():
     last = {}
 
     from pointdsc_amd.pipeline import InFlight
-    runners = {d: InFlight(model, depth=d) for d in sorted({1, max(1, args.in_flight)})}
-    depth = {"d": max(1, args.in_flight)}
+    small = B * N <= 4096                      # one small problem per step: its ~45 launches are latency- and host-bound
+    in_flight = args.in_flight if args.in_flight > 0 else (4 if small else 2)
+    use_graphs = in_flight > 1 and (args.graphs == "on" or (args.graphs == "auto" and small))
+    runners = {d: InFlight(model, depth=d, graphs=use_graphs and d > 1) for d in sorted({1, in_flight})}
+    depth = {"d": in_flight}
 
     def gather(res):
         # the pose gather rides behind its forward on the forward's stream: off the critical path of the next step
@@ -312,7 +319,7 @@ def main():
             one = float(t.item())
         single = {"value": round(total_pairs * args.steps / one, 3), "unit": "pairs/s", "ms_per_step": round(one / args.steps * 1e3, 4),
                   "steps": args.steps}
-        depth["d"] = max(1, args.in_flight)
+        depth["d"] = in_flight
 
     if rank != 0:
         if world > 1:
@@ -377,8 +384,9 @@ def main():
                    "sigma_d": kw["sigma_d"], "inlier_threshold": kw["inlier_threshold"],
                    "compat_format": "f32" if fp32 else model.compat_format, "layer_gemm": model.layer_gemm,
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s); %d forward(s) in flight per GPU "
-                                  "(consecutive steps alternate between HIP streams)"
-                                  % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU", depth["d"])},
+                                  "(consecutive steps alternate between HIP streams%s)"
+                                  % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU", depth["d"],
+                                     ", each replayed as a captured hipGraph" if runners[in_flight].graphs else "")},
         "roofline": roof,
         # H3 kernel: algorithmic HBM bytes per launch / its duration against 8 TB/s; otherwise matrix-pipe issue cycles the
         # launch needs per SIMD / its duration, against a pipe that is busy every cycle at the maximum clock
@@ -402,6 +410,7 @@ def main():
     if sustained is not None:
         line["sustained"] = sustained
     line["in_flight"] = depth["d"]
+    line["hip_graphs"] = bool(runners[in_flight].graphs)
     if single is not None:
         line["single_stream"] = single
     traffic_file = ROOT / "profiles" / "traffic.json"      # PMC-derived HBM bytes per launch, if collected
@@ -464,6 +473,15 @@ def main():
             cj = json.loads(r.stdout.strip().splitlines()[-1])
             what = ("unmodified reference imported from /root/reference" if cj["kind"] == "reference"
                     else "torch-CPU oracle (oracle/pointdsc_oracle.py, timing mode = the reference's own ops)")
+            ratio_file = ROOT / "profiles" / "cpu_baseline_ratio.json"
+            if cj["kind"] == "port" and ratio_file.exists():
+                try:
+                    rj = json.loads(ratio_file.read_text())
+                    what += ("; measured against the unmodified reference in the build container (%s, %d threads): reference %.3f, this "
+                             "port %.3f pairs/s = %.2f x the reference's rate" % (rj["config"], rj["threads"], rj["reference"], rj["port"],
+                                                                                  rj["port_over_reference"]))
+                except Exception:       # noqa: BLE001
+                    pass
             line["cpu_baseline"] = {"value": round(cj["pairs_per_s"], 4), "unit": "pairs/s", "cores": cores,
                                     "kind": cj["kind"], "sample": sample + ", " + what}
             if check is not None and n_chk:

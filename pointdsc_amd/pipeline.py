@@ -15,17 +15,24 @@ kernels run changes.  Weights (packed / split buffers) are shared and read-only.
                                            # t.record_stream(current) for result tensors that outlive the runner's next use
                                            # of the slot) before using res on another stream
 
+``graphs=True`` additionally captures each slot's forward in a hipGraph (``pdsc_forward_testing`` only enqueues kernels: no
+sync, no allocation) and replays it: the ~45 launches of a forward cost the host one call.  That only matters when a forward is
+launch-bound -- one pair of N=1000: 0.243 ms per forward with three eager forwards in flight, 0.149 ms with four captured ones
+(profiles/r03_e_graph_probe.txt); at 32 pairs of N=5000 it changes nothing.  Inputs are copied into per-slot static tensors,
+outputs are returned as copies; ragged batches and the validation forward take the eager path.
+
 The reference has nothing like it (its testing loop is one synchronous call per pair, evaluation/test_3DMatch.py:32-54).
 """
 from __future__ import annotations
 
+import warnings
 from typing import Callable, Dict, Optional
 
 import torch
 
 
 class InFlight:
-    def __init__(self, model, depth: int = 2, device=None):
+    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
@@ -36,6 +43,8 @@ class InFlight:
         self.device = dev
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [None]
         self._i = 0
+        self.graphs = bool(graphs) and depth > 1
+        self._captured = {}                     # slot -> (key, graph, static inputs, static outputs)
         self._ensure_weights()
 
     def _ensure_weights(self) -> None:
@@ -70,17 +79,54 @@ class InFlight:
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(s)
         with torch.cuda.stream(s), torch.no_grad():
-            self.model._ws_slot = slot
-            try:
-                res = self.model(data)
-            finally:
-                self.model._ws_slot = 0
+            res = self._replay(slot, s, data) if self.graphs else None
+            if res is None:
+                self.model._ws_slot = slot
+                try:
+                    res = self.model(data)
+                finally:
+                    self.model._ws_slot = 0
             if post is not None:
                 res["post"] = post(res)
             ev = torch.cuda.Event()
             ev.record(s)
         res["ready"] = ev
         return res
+
+    def _replay(self, slot: int, s, data: Dict):
+        """Replay (capturing first, if needed) the slot's hipGraph of `model(data)`; None = not capturable, run eagerly."""
+        m = self.model
+        corr = data.get("corr_pos")
+        if not (torch.is_tensor(corr) and "testing" in data and data.get("num_corr") is None):
+            return None
+        key = (tuple(corr.shape), m.attention_precision, m.compat_format, m.layer_gemm, m._wpack_key)
+        cap = self._captured.get(slot)
+        if cap is None or cap[0] != key:
+            try:
+                static = {k: data[k].detach().to(torch.float32).contiguous().clone() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+                static["testing"] = True
+                m._ws_slot = slot
+                try:
+                    for _ in range(2):                   # workspace, packed weights, H3 range check: all before the capture
+                        m(static)
+                    s.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s):
+                        out = m(static)
+                finally:
+                    m._ws_slot = 0
+                cap = (key, g, static, out)
+                self._captured[slot] = cap
+            except Exception as e:        # noqa: BLE001  (capture is an optimisation: fall back to the eager path for good)
+                warnings.warn(f"pointdsc_amd.InFlight: hipGraph capture failed ({e!r}); continuing without graphs", RuntimeWarning)
+                self.graphs = False
+                return None
+        _, g, static, out = cap
+        for k in ("corr_pos", "src_keypts", "tgt_keypts"):
+            if data[k].data_ptr() != static[k].data_ptr():
+                static[k].copy_(data[k], non_blocking=True)
+        g.replay()
+        return {"final_trans": out["final_trans"].clone(), "final_labels": out["final_labels"].clone(), "M": None}
 
     def synchronize(self) -> None:
         for s in self.streams:

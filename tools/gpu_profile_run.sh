@@ -1,11 +1,13 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): the round's evidence bundle -> gpurun_out/<tag>_*; copy what should be judged
-# into profiles/.   bash tools/gpu_profile_run.sh <tag> [quick]
-#   <tag>_pytest_gpu.txt                 tail of pytest -m gpu
-#   <tag>_bench_line_<config>.json       one bench.py line per BASELINE.json configuration (check + cpu_baseline included)
-#   <tag>_kernel_stats_<config>.txt      rocprofv3 --kernel-trace summary of a short bench run of that configuration
-#   <tag>_pmc_summary.txt                PMC passes over the headline configuration (tools/gpu_pmc_run.sh)
-#   <tag>_match_bench.txt, <tag>_sm_bench.txt   f-2 / f-3 micro-benches
+# Run on the GPU box (through gpurun): the round's evidence bundle, SHIPPED DEFAULTS -> gpurun_out/<tag>_*; copy what should be
+# judged into profiles/.   bash tools/gpu_profile_run.sh <tag> [quick]
+#   <tag>_pytest_gpu.txt                    tail of pytest -m gpu
+#   <tag>_bench_line_<config>.json          one bench.py line per BASELINE.json configuration (check + cpu_baseline included)
+#   <tag>_bench_line_<config>_<B>pairs.json the per-GPU shares of the 2- / 4- / 8-GPU runs of the sharded configurations
+#   <tag>_kernel_stats_<config>[_<B>pairs].txt  rocprofv3 --kernel-trace summary of a short single-stream bench run
+#   <tag>_pmc_summary.txt                   PMC passes over the headline configuration (tools/gpu_pmc_run.sh)
+#   <tag>_parity_census.txt                 tools/parity_census.py: every census pair at every batch size
+#   <tag>_match_bench.txt, <tag>_sm_bench.txt, <tag>_compat_bench.txt   micro-benches
 set -u
 TAG=${1:-prof}
 QUICK=${2:-}
@@ -15,27 +17,42 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
 CONFIGS="n5000_b32 n1000_b1 kitti_n5000_b16 lomatch_n10000_b8"
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6 > "$OUT/${TAG}_pytest_gpu.txt"
+timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40 > "$OUT/${TAG}_pytest_gpu.txt"
+if [ -z "$QUICK" ]; then
+  # PMC first: the bench lines below quote the HBM traffic of THIS build (profiles/traffic.json is regenerated from the summary)
+  bash "$ROOT/tools/gpu_pmc_run.sh" ${TAG}_pmc --in-flight 1 --settle-seconds 0 > /dev/null 2>&1
+  python tools/traffic_from_pmc.py "$OUT/${TAG}_pmc_summary.txt" n5000_b32 32 > "$OUT/${TAG}_traffic.txt" 2>&1
+  cp profiles/traffic.json "$OUT/${TAG}_traffic.json"
+  cd "$ROOT"
+fi
 for c in $CONFIGS; do
   timeout 400 python bench.py --config $c > "$OUT/${TAG}_bench_$c.log" 2>&1; tail -1 "$OUT/${TAG}_bench_$c.log" > "$OUT/${TAG}_bench_line_$c.json"
 done
+SHARES="n5000_b32:16 n5000_b32:8 n5000_b32:4 kitti_n5000_b16:8 kitti_n5000_b16:4 kitti_n5000_b16:2 lomatch_n10000_b8:4 lomatch_n10000_b8:2 lomatch_n10000_b8:1"
 if [ -z "$QUICK" ]; then
-  for B in 4 8 16; do   # the per-GPU shares of the 8-, 4- and 2-GPU runs of the 32-pair configuration
-    timeout 300 python bench.py --global-batch $B --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_n5000_${B}pairs.json"
+  for s in $SHARES; do
+    c=${s%%:*}; B=${s##*:}
+    timeout 300 python bench.py --config $c --global-batch $B --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_${c}_${B}pairs.json"
   done
+  timeout 900 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
+  timeout 600 python tools/parity_census.py --only n5000_b32 --batches 32,4 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
 fi
 cd /tmp
-for c in $CONFIGS; do
+for s in n5000_b32:32 n1000_b1:1 kitti_n5000_b16:16 lomatch_n10000_b8:8 n5000_b32:4 kitti_n5000_b16:2 lomatch_n10000_b8:1; do
+  c=${s%%:*}; B=${s##*:}
   rm -rf /tmp/prof_$c
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o k -- python "$ROOT/bench.py" --config $c --steps 6 --warmup 1 --no-cpu-baseline --no-check --sustain-seconds 0 > "$OUT/${TAG}_rocprof_$c.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o k -- python "$ROOT/bench.py" --config $c --global-batch $B --in-flight 1 --steps 6 --warmup 1 --settle-seconds 0 --no-cpu-baseline --no-check --sustain-seconds 0 > "$OUT/${TAG}_rocprof_${c}_$B.log" 2>&1
   DB=$(find /tmp/prof_$c -name '*.db' | head -1)
-  [ -n "$DB" ] && python "$ROOT/tools/rocpd_kernel_stats.py" "$DB" > "$OUT/${TAG}_kernel_stats_$c.txt" 2>&1
+  [ -n "$DB" ] && python "$ROOT/tools/rocpd_kernel_stats.py" "$DB" > "$OUT/${TAG}_kernel_stats_${c}_${B}pairs.txt" 2>&1
   rm -rf /tmp/prof_$c
 done
 if [ -z "$QUICK" ]; then
-  bash "$ROOT/tools/gpu_pmc_run.sh" ${TAG}_pmc > /dev/null 2>&1
   cd "$ROOT"
+  timeout 200 python tools/compat_bench.py > "$OUT/${TAG}_compat_bench.txt" 2>&1
   timeout 200 python tools/match_bench.py > "$OUT/${TAG}_match_bench.txt" 2>&1
   timeout 200 python tools/sm_bench.py > "$OUT/${TAG}_sm_bench.txt" 2>&1
+  timeout 200 python tools/overlap_probe.py --n 5000 --bs 32 --steps 40 > "$OUT/${TAG}_overlap_probe.txt" 2>&1
+  timeout 200 python tools/overlap_probe.py --n 5000 --bs 4 --steps 200 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1
+  timeout 200 python tools/overlap_probe.py --n 1000 --bs 1 --steps 500 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1
 fi
-ls -la "$OUT" | tail -30
+ls -la "$OUT" | grep "${TAG}_" | tail -60

@@ -61,3 +61,39 @@ with torch.no_grad():
     t_eager2 = timed(lambda: model(data))
 print(f"{a.config}: replay == eager bit for bit: {same}; eager {t_eager:.4f} ms / forward, graph replay {t_graph:.4f} ms, "
       f"eager again {t_eager2:.4f} ms  ({w['global_batch']} pair(s) per forward)")
+
+# r03: several captured forwards in flight -- one graph per HIP stream / workspace slot, replayed round-robin (the eager form of
+# this is pointdsc_amd.pipeline.InFlight; with graphs the ~45 launches per forward cost the host one call)
+from pointdsc_amd.pipeline import InFlight  # noqa: E402
+with torch.no_grad():
+    for depth in (2, 3, 4, 6):
+        streams = [torch.cuda.Stream() for _ in range(depth)]
+        graphs, outs = [], []
+        for slot, st in enumerate(streams):
+            model._ws_slot = slot
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    model(data)
+            st.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                outs.append(model(data))
+            graphs.append(gr)
+        model._ws_slot = 0
+        torch.cuda.synchronize()
+        i = [0]
+
+        def replay_next():
+            k = i[0] % depth
+            i[0] += 1
+            with torch.cuda.stream(streams[k]):
+                graphs[k].replay()
+
+        t = timed(replay_next)
+        torch.cuda.synchronize()
+        ok = all(torch.equal(o["final_trans"], eager["final_trans"]) for o in outs)
+        runner = InFlight(model, depth=depth)
+        t_eager_inflight = timed(lambda: runner(data))
+        print(f"{a.config}: {depth} captured forwards in flight: {t:.4f} ms / forward (results equal: {ok}); eager InFlight depth {depth}: {t_eager_inflight:.4f} ms")
+

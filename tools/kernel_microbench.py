@@ -20,6 +20,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+import os as _os
+_os.environ.setdefault("POINTDSC_HIP_LIB", str(__import__("pathlib").Path(__file__).resolve().parents[1] / "pointdsc_amd" / "libpointdsc_hip_exp.so"))   # PDSC_* knobs / traces: experiments library (python -m pointdsc_amd.build --experiments)
 
 
 def timed(fn, iters):
