@@ -308,19 +308,20 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = 4 * pdsc::ATT_TILE_FLOATS * sizeof(float);   // 64 KiB
     {
-        int rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<0>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
-        if (rc_lds == PDSC_OK)
-            rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<1>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
+        int rc_lds = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<1>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
         if (rc_lds != PDSC_OK) return rc_lds;
     }
-    const char* env_variant = pdsc::env_str("PDSC_ATT_VARIANT");       // tuning/A-B knob, read per call; default = shipped variant
-    const int variant = env_variant ? atoi(env_variant) : PDSC_ATT_DEFAULT_VARIANT;
     dim3 grid(pdsc::ceil_div(N, pdsc::ATT_BQ), nsplit, bs);
     pdsc::profile_mark_begin(PDSC_PROF_ATTENTION, st);
-    if (variant == 0)
+#ifdef PDSC_EXPERIMENTS
+    const char* env_variant = pdsc::env_str("PDSC_ATT_VARIANT");       // A/B knob; default = shipped variant
+    if ((env_variant ? atoi(env_variant) : PDSC_ATT_DEFAULT_VARIANT) == 0) {
+        const int rc0 = pdsc::ensure_dynamic_lds(reinterpret_cast<const void*>(&pdsc::sc_attention_kernel<0>), lds_bytes, "pdsc_sc_attention(dynamic LDS)");
+        if (rc0 != PDSC_OK) return rc0;
         hipLaunchKernelGGL(pdsc::sc_attention_kernel<0>, grid, dim3(256), lds_bytes, st, a);
-    else
-        hipLaunchKernelGGL(pdsc::sc_attention_kernel<1>, grid, dim3(256), lds_bytes, st, a);
+    } else
+#endif
+    hipLaunchKernelGGL(pdsc::sc_attention_kernel<1>, grid, dim3(256), lds_bytes, st, a);
     pdsc::profile_mark_end(PDSC_PROF_ATTENTION, st);
     int rc = pdsc::check_launch("pdsc_sc_attention");
     if (rc != PDSC_OK) return rc;

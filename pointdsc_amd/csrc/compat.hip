@@ -440,23 +440,27 @@ extern "C" int pdsc_spatial_compat(const float* src, const float* tgt, const flo
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_spatial_compat: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= N && ld % 4 == 0, "pdsc_spatial_compat: ld=%lld must be >= N and a multiple of 4", ld);
     hipStream_t st = (hipStream_t)stream;
-    // tuning/A-B knob (all variants produce identical bits): 0 = full tiles + hipcc IEEE math, 1 = full tiles +
-    // hand-rolled exact math, 2 = symmetric + IEEE math, 3 = symmetric + hand-rolled exact math
-    const int variant = pdsc::env_int("PDSC_COMPAT_VARIANT", PDSC_COMPAT_DEFAULT_VARIANT);
     const dim3 full_grid(pdsc::ceil_div((int)ld, pdsc::CT_COLS), pdsc::ceil_div(N, pdsc::CT_ROWS), bs);
     const int nt = pdsc::ceil_div(N, pdsc::CS_T);
     const dim3 sym_grid(nt, nt, bs);
     pdsc::profile_mark_begin(PDSC_PROF_COMPAT, st);
     if (src_dist)
         hipLaunchKernelGGL((pdsc::compat_kernel<true, true>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, src_dist, ld, N);
-    else if (variant == 0)
-        hipLaunchKernelGGL((pdsc::compat_kernel<false, false>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
-    else if (variant == 1)
-        hipLaunchKernelGGL((pdsc::compat_kernel<false, true>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
-    else if (variant == 2)
-        hipLaunchKernelGGL((pdsc::compat_sym_kernel<false>), sym_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, ld, N);
-    else
+    else {
+#ifdef PDSC_EXPERIMENTS
+        // A/B knob (all variants produce identical bits): 0 = full tiles + hipcc IEEE math, 1 = full tiles + hand-rolled exact
+        // math, 2 = symmetric + IEEE math, 3 = symmetric + hand-rolled exact math (what ships)
+        const int variant = pdsc::env_int("PDSC_COMPAT_VARIANT", PDSC_COMPAT_DEFAULT_VARIANT);
+        if (variant == 0)
+            hipLaunchKernelGGL((pdsc::compat_kernel<false, false>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+        else if (variant == 1)
+            hipLaunchKernelGGL((pdsc::compat_kernel<false, true>), full_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, nullptr, ld, N);
+        else if (variant == 2)
+            hipLaunchKernelGGL((pdsc::compat_sym_kernel<false>), sym_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, ld, N);
+        else
+#endif
         hipLaunchKernelGGL((pdsc::compat_sym_kernel<true>), sym_grid, dim3(256), 0, st, src, tgt, sigma_spat, compat, ld, N);
+    }
     pdsc::profile_mark_end(PDSC_PROF_COMPAT, st);
     return pdsc::check_launch("pdsc_spatial_compat");
 }

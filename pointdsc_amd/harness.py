@@ -135,32 +135,51 @@ def gt_labels_from_trans(src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, gt_
 
 
 def eval_scene(model, pairs: Iterable[Dict[str, np.ndarray]], scene_ind: int = 0, re_thre: float = 15.0, te_thre: float = 30.0,
-               inlier_threshold: float = 0.10, use_mutual: bool = False, device: str = "cuda:0") -> np.ndarray:
+               inlier_threshold: float = 0.10, use_mutual: bool = False, device: str = "cuda:0", batch_size: int = 1) -> np.ndarray:
     """`pairs`: dicts with src_pts [ns,3], tgt_pts [nt,3], src_desc [ns,D], tgt_desc [nt,D], gt_trans [4,4] (numpy).
-    Returns the [num_pair, 12] stats array of the reference's eval_3DMatch_scene."""
+    Returns the [num_pair, 12] stats array of the reference's eval_3DMatch_scene.
+    batch_size > 1 (r03): the correspondence sets of `batch_size` consecutive pairs -- every pair has its own N, as in the
+    reference's evaluation (test_3DMatch.py:126 `num_node='all'`) -- go through ONE ragged call of the model (lists of
+    per-pair tensors); model / data time are then the batch's time divided by its pairs."""
     rows: List[np.ndarray] = []
+    dev = torch.device(device)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+
+    def flush(group):
+        if not group:
+            return
+        t0 = time.perf_counter()
+        if len(group) == 1:
+            c = group[0]["corr"]
+            res = model({"corr_pos": c["corr_pos"], "src_keypts": c["src_keypts"], "tgt_keypts": c["tgt_keypts"], "testing": True})   # test_3DMatch.py:53
+            trans, labels = res["final_trans"], [res["final_labels"][0]]
+        else:
+            res = model({"corr_pos": [x["corr"]["corr_pos"][0] for x in group], "src_keypts": [x["corr"]["src_keypts"][0] for x in group],
+                         "tgt_keypts": [x["corr"]["tgt_keypts"][0] for x in group], "testing": True})
+            trans, labels = res["final_trans"], res["final_labels"]
+        torch.cuda.synchronize(dev)
+        model_time = (time.perf_counter() - t0) / len(group)
+        for i, x in enumerate(group):
+            st = ops.eval_stats(trans[i:i + 1], x["gt_trans"][None], labels[i][None], x["gt_labels"], re_thre, te_thre)[0].cpu().numpy()
+            row = np.zeros(12)
+            row[:9] = st
+            row[9], row[10], row[11] = model_time, x["data_time"], scene_ind
+            rows.append(row)
+
     with torch.no_grad():
+        group = []
         for pair in pairs:
             t0 = time.perf_counter()
-            dev = torch.device(device)
-            g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
             corr = build_correspondences(g(pair["src_desc"]), g(pair["tgt_desc"]), g(pair["src_pts"]), g(pair["tgt_pts"]),
                                          use_mutual=use_mutual)
             gt_trans = g(pair["gt_trans"]).float()
             gt_labels = gt_labels_from_trans(corr["src_keypts"][0], corr["tgt_keypts"][0], gt_trans, inlier_threshold)[None]
-            data = {"corr_pos": corr["corr_pos"], "src_keypts": corr["src_keypts"], "tgt_keypts": corr["tgt_keypts"], "testing": True}
             torch.cuda.synchronize(dev)
-            data_time = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            res = model(data)                                                        # evaluation/test_3DMatch.py:53
-            pred_trans, pred_labels = res["final_trans"], res["final_labels"]
-            torch.cuda.synchronize(dev)
-            model_time = time.perf_counter() - t0
-            st = ops.eval_stats(pred_trans, gt_trans[None], pred_labels, gt_labels, re_thre, te_thre)[0].cpu().numpy()
-            row = np.zeros(12)
-            row[:9] = st
-            row[9], row[10], row[11] = model_time, data_time, scene_ind
-            rows.append(row)
+            group.append({"corr": corr, "gt_trans": gt_trans, "gt_labels": gt_labels, "data_time": time.perf_counter() - t0})
+            if len(group) >= max(1, batch_size):
+                flush(group)
+                group = []
+        flush(group)
     return np.stack(rows) if rows else np.zeros((0, 12))
 
 

@@ -73,3 +73,22 @@ def test_eval_loop_on_the_demo_cloud():
     one = next(iter(harness.demo_pairs(cloud, 1)))
     assert one["src_desc"].shape == (len(cloud), 33) and abs(float(np.linalg.norm(one["src_desc"][0])) - 1.0) < 1e-5
     assert torch.cuda.is_available()
+
+
+@pytest.mark.gpu
+def test_eval_loop_batches_pairs_of_different_size():
+    """batch_size > 1: with the mutual check every pair keeps its own number of correspondences (as in the reference's evaluation,
+    num_node='all'); four of them go through one ragged model call.  Same rows as the one-pair-per-call loop."""
+    from pointdsc_amd import PointDSC, workloads
+    cloud = np.load(FIXTURE)["cloud_bin_0"]
+    model = PointDSC(**workloads.BASE_MODEL)
+    model.load_state_dict(workloads.state_dict("n5000_b32", model.state_dict()))
+    model = model.eval().cuda()
+    one = harness.eval_scene(model, harness.demo_pairs(cloud, 5, corrupt=0.3), use_mutual=True, batch_size=1)
+    many = harness.eval_scene(model, harness.demo_pairs(cloud, 5, corrupt=0.3), use_mutual=True, batch_size=4)
+    assert one.shape == many.shape == (5, 12)
+    assert len(set(one[:, 3].astype(int).tolist())) > 1, "the pairs were meant to differ"                # column 3: input inliers of the pair
+    assert (one[:, 0] == many[:, 0]).all() and (one[:, 0] == 1).all()
+    assert np.abs(one[:, 1] - many[:, 1]).max() < 0.05 and np.abs(one[:, 2] - many[:, 2]).max() < 0.1  # RE [deg], TE [cm]
+    assert np.abs(one[:, [3, 5]] - many[:, [3, 5]]).max() <= 2                                           # inlier counts (in / true positives)
+    assert np.abs(one[:, [4, 6, 7, 8]] - many[:, [4, 6, 7, 8]]).max() < 0.01                             # ratios / P / R / F1

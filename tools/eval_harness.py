@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--outlier-share", type=float, default=0.6, help="share of stand-in descriptors replaced by noise")
     ap.add_argument("--snapshot", default=None, help="released model_best.pkl (load_state_dict(strict=False)); default: seeded weights")
     ap.add_argument("--mutual", action="store_true", help="mutual nearest neighbours only (datasets/ThreeDMatch.py:286-288)")
+    ap.add_argument("--batch-size", type=int, default=1, help="pairs per (ragged) model call; the reference evaluates one pair per call")
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
     if a.pcd1:
@@ -44,7 +45,7 @@ def main():
         model.load_state_dict(workloads.state_dict("n5000_b32", model.state_dict()))
     model = model.eval().cuda()
     stats = harness.eval_scene(model, harness.demo_pairs(cloud, a.num_pairs, corrupt=a.outlier_share), scene_ind=0,
-                               inlier_threshold=kw["inlier_threshold"], use_mutual=a.mutual)
+                               inlier_threshold=kw["inlier_threshold"], use_mutual=a.mutual, batch_size=a.batch_size)
     summ = harness.summarize(stats)
     if a.json:
         print(json.dumps({"stats_columns": harness.STATS_NAMES, "stats": stats.tolist(), "summary": summ}))

@@ -49,6 +49,8 @@ done
 if [ -z "$QUICK" ]; then
   cd "$ROOT"
   timeout 200 python tools/compat_bench.py > "$OUT/${TAG}_compat_bench.txt" 2>&1
+  timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_probe.py > "$OUT/${TAG}_rccl_probe.txt" 2>&1
+  timeout 300 python tools/graph_probe.py --config n1000_b1 --iters 1000 > "$OUT/${TAG}_graph_probe.txt" 2>&1
   timeout 200 python tools/match_bench.py > "$OUT/${TAG}_match_bench.txt" 2>&1
   timeout 200 python tools/sm_bench.py > "$OUT/${TAG}_sm_bench.txt" 2>&1
   timeout 200 python tools/overlap_probe.py --n 5000 --bs 32 --steps 40 > "$OUT/${TAG}_overlap_probe.txt" 2>&1

@@ -73,5 +73,32 @@ assert torch.equal(back, res["final_trans"])
 out = sharding.gather_results(res["final_trans"], res["final_labels"], B * world)
 assert torch.equal(out["final_trans"], res["final_trans"])
 print(f"all_gather_into_tensor: fp32 poses {tuple(flat.shape)}, uint8 pose|label payload {tuple(flat8.shape)}: round trip exact", flush=True)
+# r03: the bench's in-flight pattern -- the gather of step i rides behind forward i on forward i's side stream, the settle
+# count is broadcast from rank 0, the timed region ends with one fence
+from pointdsc_amd.pipeline import InFlight  # noqa: E402
+
+t = torch.tensor([7], dtype=torch.int64, device=dev)
+dist.broadcast(t, src=0)
+assert int(t.item()) == 7
+runner = InFlight(model, depth=2)
+gathered = []
+
+
+def gather_direct(r):
+    p = r["final_trans"].reshape(B, 16).contiguous()
+    o = torch.empty((world * B, 16), dtype=p.dtype, device=dev)
+    dist.all_gather_into_tensor(o, p)        # under torch.cuda.stream(side): enqueued behind the forward on that stream
+    return o
+
+
+fence()
+t0 = time.perf_counter()
+for _ in range(6):
+    gathered.append(runner(data, post=gather_direct))
+fence()
+dt = time.perf_counter() - t0
+for g_ in gathered:
+    assert torch.equal(g_["post"][rank * B:(rank + 1) * B].reshape(B, 4, 4), res["final_trans"])
+print(f"6 forwards in flight on two streams, one all_gather_into_tensor behind each: {dt / 6 * 1e3:.2f} ms per step, gathers exact", flush=True)
 dist.destroy_process_group()
 print("RCCL_PROBE_OK", flush=True)
