@@ -42,6 +42,13 @@ class InFlight:
             raise RuntimeError("pointdsc_amd has no CPU path: move the model to the GPU first")
         self.device = dev
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [None]
+        # workspace slots of the module, private to this runner (slot 0 = the module's plain calls): two runners on one module
+        # must never share a workspace, their streams are not ordered against each other
+        if not hasattr(model, "_next_ws_slot"):
+            model._next_ws_slot = 1
+        self._slots = list(range(model._next_ws_slot, model._next_ws_slot + depth)) if depth > 1 else [0]
+        if depth > 1:
+            model._next_ws_slot += depth
         self._i = 0
         self.graphs = bool(graphs) and depth > 1
         self._captured = {}                     # slot -> (key, graph, static inputs, static outputs)
@@ -81,7 +88,7 @@ class InFlight:
         with torch.cuda.stream(s), torch.no_grad():
             res = self._replay(slot, s, data) if self.graphs else None
             if res is None:
-                self.model._ws_slot = slot
+                self.model._ws_slot = self._slots[slot]
                 try:
                     res = self.model(data)
                 finally:
@@ -105,7 +112,7 @@ class InFlight:
             try:
                 static = {k: data[k].detach().to(torch.float32).contiguous().clone() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
                 static["testing"] = True
-                m._ws_slot = slot
+                m._ws_slot = self._slots[slot]
                 try:
                     for _ in range(2):                   # workspace, packed weights, H3 range check: all before the capture
                         m(static)
@@ -132,3 +139,11 @@ class InFlight:
         for s in self.streams:
             if s is not None:
                 s.synchronize()
+
+    def close(self) -> None:
+        """Wait for the forwards in flight and release this runner's workspaces (2.6 GB each for 32 pairs of N = 5000)."""
+        self.synchronize()
+        self._captured.clear()
+        if self.depth > 1:
+            for k in self._slots:
+                self.model._workspaces.pop(k, None)

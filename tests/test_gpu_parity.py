@@ -1761,8 +1761,9 @@ def test_forwards_in_flight_reproduce_the_plain_calls():
     pairs = _ragged_pairs((2100, 2600, 2222), 31, inlier_ratio=0.3)
     with torch.no_grad():
         want = model(_as_lists(pairs))
-    got = [runner(_as_lists(pairs)) for _ in range(3)] + [gr(_as_lists(pairs))]         # (ragged: eager path in either runner)
-    runner.synchronize()
+    got = [runner(_as_lists(pairs)) for _ in range(3)] + [gr(_as_lists(pairs))]         # (ragged: eager path in either runner; the two
+    runner.synchronize()                                                                # runners own disjoint workspace slots)
+    gr.synchronize()
     for r in got:
         assert torch.equal(r["final_trans"], want["final_trans"])
         assert all(torch.equal(a, b) for a, b in zip(r["final_labels"], want["final_labels"]))
