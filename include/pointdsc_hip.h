@@ -415,6 +415,22 @@ int pdsc_forward_testing_ragged(const pdsc_config* cfg, const float* wpack, cons
                                 float* final_trans, float* final_labels,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- whole path on two streams (throughput loops with several forwards in flight, pointdsc_amd/pipeline.py) --------
+ * Same result as pdsc_forward_testing (num_corr == NULL) / pdsc_forward_testing_ragged.  The encoder (compat build, 12 attention
+ * + layer launches) is enqueued on `stream`; everything after it -- classifier, NMS, seed ranking, kNN, per-seed solver,
+ * scoring, refinement: a sequential chain of ~15 small launches -- on `tail_stream`, which the caller creates with a HIGHER
+ * priority: while forward i's tail runs, forward i+1's encoder (another stream) keeps the chip full, and the tail's few
+ * workgroups are dispatched ahead of the attention launch's queued ones instead of behind them.  fork_event / join_event:
+ * caller-owned hipEvent_t (no timing needed), recorded on stream / tail_stream; on return `stream` waits for join_event, so
+ * work enqueued on `stream` afterwards is ordered after the results.  Nothing is allocated; capturable in a hipGraph. */
+int pdsc_forward_testing_streams(const pdsc_config* cfg, const float* wpack, const void* wsplit,
+                                 const float* corr_pos, const float* src_keypts, const float* tgt_keypts,
+                                 int bs, int N, int num_seeds, const int* num_corr /* NULL: uniform batch */,
+                                 const int* num_seeds_per_pair, int n_min,
+                                 float* final_trans, float* final_labels,
+                                 void* workspace, size_t workspace_bytes,
+                                 void* stream, void* tail_stream, void* fork_event, void* join_event);
+
 /* ---- validation forward -------------------------------------------------
  * replaces PointDSC.forward(data) WITHOUT the 'testing' key on a module in eval() mode (libs/trainer.py:158-222
  * calls it so): models/PointDSC.py:158-163 (feature similarity matrix M), :176 (seeds = top int(N*ratio) by

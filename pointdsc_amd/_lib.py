@@ -113,6 +113,7 @@ SIGNATURES = {
     "pdsc_conv_mask_all_pairs": (_i, [_vp, _i, _vp]),
     "pdsc_forward_testing": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pdsc_forward_testing_ragged": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pdsc_forward_testing_streams": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

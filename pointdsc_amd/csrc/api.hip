@@ -299,8 +299,11 @@ extern "C" int pdsc_profile_read(int kind, double* total_ms, int* launches) {
 static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
                        const float* src, const float* tgt, int bs, int N, int num_seeds,
                        float* final_trans, float* final_labels, float* Mout, long long ldM, void* workspace,
-                       size_t workspace_bytes, void* stream, const int* nvalid = nullptr, const int* svalid = nullptr, int n_min = 0) {
+                       size_t workspace_bytes, void* stream, const int* nvalid = nullptr, const int* svalid = nullptr, int n_min = 0,
+                       void* tail_stream = nullptr, void* ev_fork = nullptr, void* ev_join = nullptr) {
     if (!config_ok(cfg)) return PDSC_ERR_ARG;
+    PDSC_REQUIRE(!tail_stream || (ev_fork && ev_join && tail_stream != stream),
+                 "pdsc_forward_testing_streams: a tail stream (different from the main stream) needs the fork and join events");
     struct SlotGuard {       // the fused-layer entry points read the count array from the thread-local slot (ragged.h)
         explicit SlotGuard(const int* p) { layer_nvalid_slot() = p; }
         ~SlotGuard() { layer_nvalid_slot() = nullptr; }
@@ -473,6 +476,17 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_TRY(pdsc_linear(t64a, C / 2, W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i), nullptr, 0, t64b, C / 2, M, C / 2, C / 2, 1, stream));
         PDSC_TRY(pdsc_linear(t64b, C / 2, W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i), featB, C, featA, C, M, C / 2, C, 0, stream));
     }
+    // pdsc_forward_testing_streams: everything after the encoder -- a strictly sequential chain of ~15 small, latency-bound
+    // launches -- goes to the caller's second (high-priority) stream: with several forwards in flight its workgroups are then
+    // dispatched ahead of the queued workgroups of another forward's attention launch instead of behind them.
+    void* const main_stream = stream;
+    if (tail_stream) {
+        if (hipEventRecord((hipEvent_t)ev_fork, (hipStream_t)main_stream) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)tail_stream, (hipEvent_t)ev_fork, 0) != hipSuccess)
+            return check_launch("pdsc_forward_testing_streams(fork)");
+        stream = tail_stream;
+        hst = (hipStream_t)tail_stream;
+    }
     // Step 2.1 (:156,:171,:174): normalise, confidence head, NMS seeds
     PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), nullptr, 0, h1, 32, M, C, 32, 1, stream));
     PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
@@ -510,6 +524,11 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         if (hipMemcpyAsync(final_labels, conf, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
             return check_launch("pdsc_forward_validation(copy logits)");
     }
+    if (tail_stream) {       // join: whatever the caller enqueues on the main stream next is ordered after the results
+        if (hipEventRecord((hipEvent_t)ev_join, (hipStream_t)tail_stream) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)main_stream, (hipEvent_t)ev_join, 0) != hipSuccess)
+            return check_launch("pdsc_forward_testing_streams(join)");
+    }
     return PDSC_OK;
 }
 
@@ -528,6 +547,17 @@ extern "C" int pdsc_forward_testing_ragged(const pdsc_config* cfg, const float* 
     PDSC_REQUIRE(num_corr && num_seeds_per_pair, "pdsc_forward_testing_ragged: the per-pair count arrays (device, [bs] int32) are required");
     return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, final_labels, nullptr, 0,
                        workspace, workspace_bytes, stream, num_corr, num_seeds_per_pair, n_min);
+}
+
+extern "C" int pdsc_forward_testing_streams(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                                            const float* src, const float* tgt, int bs, int N, int num_seeds, const int* num_corr,
+                                            const int* num_seeds_per_pair, int n_min, float* final_trans, float* final_labels,
+                                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, void* fork_event,
+                                            void* join_event) {
+    PDSC_REQUIRE((num_corr == nullptr) == (num_seeds_per_pair == nullptr), "pdsc_forward_testing_streams: both count arrays or neither");
+    PDSC_REQUIRE(tail_stream && fork_event && join_event, "pdsc_forward_testing_streams: tail stream and both events are required");
+    return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, final_labels, nullptr, 0,
+                       workspace, workspace_bytes, stream, num_corr, num_seeds_per_pair, n_min, tail_stream, fork_event, join_event);
 }
 
 extern "C" int pdsc_forward_validation(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,

@@ -134,6 +134,7 @@ class PointDSC(nn.Module):
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
         self._h3_range_checked = False
+        self._tail: Dict[int, tuple] = {}       # workspace slot -> (high-priority tail stream, fork event, join event): pipeline.InFlight
         self._workspaces: Dict[int, torch.Tensor] = {}      # one per in-flight slot (pointdsc_amd.pipeline.InFlight); slot 0 = the plain call
         self._ws_slot = 0
 
@@ -389,16 +390,24 @@ class PointDSC(nn.Module):
             outs = (C.c_void_p(final_trans.data_ptr()), C.c_void_p(final_labels.data_ptr()))
             stream = torch.cuda.current_stream().cuda_stream
             M = None
+            tail = self._tail.get(self._ws_slot) if testing else None
+            cnt = None
             if counts is not None:
                 seeds_per = [int(c * self.ratio) for c in counts]
                 if min(seeds_per) < 1:
                     raise ValueError("every pair needs int(num_corr * ratio) >= 1 seeds (the reference fails on an empty seed set)")
                 cnt = torch.tensor([counts, seeds_per], dtype=torch.int32).to(dev, non_blocking=False)
-                rc = lib.pdsc_forward_testing_ragged(*common, C.c_void_p(cnt[0].data_ptr()), C.c_void_p(cnt[1].data_ptr()), min(counts),
-                                                     *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
                 if not hasattr(self, "_last_counts"):
                     self._last_counts = {}
                 self._last_counts[self._ws_slot] = cnt      # (keeps the device arrays alive until the slot's next call: the launches are asynchronous)
+            ragged = (C.c_void_p(cnt[0].data_ptr()), C.c_void_p(cnt[1].data_ptr()), min(counts)) if cnt is not None else (None, None, 0)
+            if tail is not None:
+                # encoder on the current stream, the latency-bound tail on the slot's high-priority stream (pdsc_forward_testing_streams)
+                rc = lib.pdsc_forward_testing_streams(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream,
+                                                      tail[0].cuda_stream, tail[1].cuda_event, tail[2].cuda_event)
+                what = "pdsc_forward_testing_streams"
+            elif cnt is not None:
+                rc = lib.pdsc_forward_testing_ragged(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
                 what = "pdsc_forward_testing_ragged"
             elif testing:
                 rc = lib.pdsc_forward_testing(*common, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)

@@ -15,6 +15,12 @@ kernels run changes.  Weights (packed / split buffers) are shared and read-only.
                                            # t.record_stream(current) for result tensors that outlive the runner's next use
                                            # of the slot) before using res on another stream
 
+``tail_streams=True`` enqueues each forward on TWO streams (``pdsc_forward_testing_streams``): the encoder on the slot's stream,
+everything after it on a high-priority companion stream, so that the tail's few workgroups are dispatched ahead of the queued
+workgroups of the other slot's attention launch.  Measured (profiles/r03_f_inflight_ab.txt, interleaved in one process): 4 pairs
+of N=5000 1.998 -> 1.954 ms per step (+2.2 %), 16-32 pairs +-0.5 %, one pair of N=1000 -10 %: worth it for small multi-pair
+batches only (bench.py turns it on for 4097..32768 correspondences per step); depth 3 is slower than depth 2 everywhere.
+
 ``graphs=True`` additionally captures each slot's forward in a hipGraph (``pdsc_forward_testing`` only enqueues kernels: no
 sync, no allocation) and replays it: the ~45 launches of a forward cost the host one call.  That only matters when a forward is
 launch-bound -- one pair of N=1000: 0.243 ms per forward with three eager forwards in flight, 0.149 ms with four captured ones
@@ -32,7 +38,7 @@ import torch
 
 
 class InFlight:
-    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False):
+    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False, tail_streams: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
@@ -49,6 +55,18 @@ class InFlight:
         self._slots = list(range(model._next_ws_slot, model._next_ws_slot + depth)) if depth > 1 else [0]
         if depth > 1:
             model._next_ws_slot += depth
+        # Each slot's forward is enqueued on two streams (pdsc_forward_testing_streams): the encoder on the slot's stream, the
+        # latency-bound tail (classifier ... refinement: ~15 small launches) on a HIGH-priority companion stream, so that its few
+        # workgroups are dispatched ahead of the queued workgroups of the other slot's attention launch.
+        self.tail_streams = bool(tail_streams) and depth > 1 and not graphs     # (captured forwards are launch-bound problems: one stream)
+        if self.tail_streams:
+            for k, st in zip(self._slots, self.streams):
+                tail = torch.cuda.Stream(device=dev, priority=-1)
+                fork, join = torch.cuda.Event(), torch.cuda.Event()
+                fork.record(st)
+                join.record(tail)                      # (creates the underlying hipEvents: their handles are passed to the library)
+                model._tail[k] = (tail, fork, join)
+            torch.cuda.synchronize(dev)
         self._i = 0
         self.graphs = bool(graphs) and depth > 1
         self._captured = {}                     # slot -> (key, graph, static inputs, static outputs)
@@ -138,7 +156,7 @@ class InFlight:
     def synchronize(self) -> None:
         for s in self.streams:
             if s is not None:
-                s.synchronize()
+                s.synchronize()          # (every forward ends with its main stream waiting for its tail stream)
 
     def close(self) -> None:
         """Wait for the forwards in flight and release this runner's workspaces (2.6 GB each for 32 pairs of N = 5000)."""
@@ -147,3 +165,4 @@ class InFlight:
         if self.depth > 1:
             for k in self._slots:
                 self.model._workspaces.pop(k, None)
+                self.model._tail.pop(k, None)

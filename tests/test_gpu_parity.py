@@ -1737,7 +1737,16 @@ def test_forwards_in_flight_reproduce_the_plain_calls():
     batches = [workloads.batch("n5000_b32", 3 * i, 3) for i in range(5)]
     plain = [_forward(model, b) for b in batches]
     model.invalidate_packed_weights()                      # the runner must rebuild them before going multi-stream
-    runner = InFlight(model, depth=2)
+    runner = InFlight(model, depth=2, tail_streams=True)   # (each forward: encoder on the slot's stream, tail on its high-priority stream)
+    assert runner.tail_streams
+    plain_streams = InFlight(model, depth=2)
+    for b, p in list(zip(batches, plain))[:2]:
+        data = {k: g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+        data["testing"] = True
+        o = plain_streams(data)
+        plain_streams.synchronize()
+        assert torch.equal(o["final_trans"], p["final_trans"]) and torch.equal(o["final_labels"], p["final_labels"])
+    plain_streams.close()
     outs = []
     for b in batches:
         data = {k: g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
