@@ -130,10 +130,10 @@ def parse():
                     help="forwards in flight: consecutive steps alternate between this many HIP streams (pointdsc_amd/pipeline.py); "
                          "1 = every step on the current stream; 0 = 2, or 4 captured hipGraphs when a step is one small problem (<= 4096 "
                          "correspondences: its ~45 launches are latency- and host-bound).  The single-stream rate is measured and reported either way")
-    ap.add_argument("--tail-streams", choices=["auto", "on", "off"], default="auto",
+    ap.add_argument("--tail-streams", choices=["on", "off"], default="on",
                     help="with forwards in flight: enqueue each forward's latency-bound tail on a high-priority companion stream "
-                         "(pdsc_forward_testing_streams).  Measured (profiles/r03_f_inflight_ab.txt): +2.2 %% at 4 pairs of N=5000, +-0.5 %% at "
-                         "16-32 pairs, -10 %% for single pairs of N=1000; auto = on for per-GPU batches of 4097..32768 correspondences")
+                         "(pdsc_forward_testing_streams; profiles/r03_h_inflight_ab.txt, r03_i_inflight_ab.txt: -2.6 %% per step at 32 "
+                         "pairs of N=5000, -6 %% at 4 pairs, -13 %% for one pair of N=10000; not used on the hipGraph path)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay each in-flight slot's forward as a captured hipGraph (auto: only when a step is one small problem)")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
@@ -200,7 +200,7 @@ def main():
     small = B * N <= 4096                      # one small problem per step: its ~45 launches are latency- and host-bound
     in_flight = args.in_flight if args.in_flight > 0 else (4 if small else 2)
     use_graphs = in_flight > 1 and (args.graphs == "on" or (args.graphs == "auto" and small))
-    use_tail = args.tail_streams == "on" or (args.tail_streams == "auto" and 4096 < B * N <= 32768)
+    use_tail = args.tail_streams == "on"
     runners = {d: InFlight(model, depth=d, graphs=use_graphs and d > 1, tail_streams=use_tail) for d in sorted({1, in_flight})}
     depth = {"d": in_flight}
 

@@ -772,7 +772,9 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     const bool creg = !c16 && env_int("PDSC_ATT_CREG", 0) != 0;
     const size_t stage_bytes = 2 * (size_t)(SPL_TILE_BYTES + (creg ? 0 : nw * 32 * (c16 ? 64 : 128)));
     const size_t patch_bytes = (size_t)nw * 32 * (PDSC_CHANNELS * 4 + 16);
-    const size_t lds_bytes = stage_bytes > patch_bytes ? stage_bytes : patch_bytes;
+    // (point-fragment partials leave straight from the accumulators: no transposition patches, so the workgroup asks for its
+    //  two stages only -- 96 KiB with the unorm16 matrix -- and leaves the rest of the CU's 160 KiB to other kernels)
+    const size_t lds_bytes = (a.part_frag || stage_bytes > patch_bytes) ? stage_bytes : patch_bytes;
     const unsigned grid = (unsigned)(a.nq * nsplit * bs);
     int rc = PDSC_OK;
     const bool trace = nw == 8 && a.trace;

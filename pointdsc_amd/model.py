@@ -134,7 +134,7 @@ class PointDSC(nn.Module):
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
         self._h3_range_checked = False
-        self._tail: Dict[int, tuple] = {}       # workspace slot -> (high-priority tail stream, fork event, join event): pipeline.InFlight
+        self._tail: Dict[int, tuple] = {}       # workspace slot -> (high-priority tail stream, fork event, join event): pipeline.InFlight(tail_streams=True)
         self._workspaces: Dict[int, torch.Tensor] = {}      # one per in-flight slot (pointdsc_amd.pipeline.InFlight); slot 0 = the plain call
         self._ws_slot = 0
 

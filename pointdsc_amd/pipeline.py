@@ -15,11 +15,16 @@ kernels run changes.  Weights (packed / split buffers) are shared and read-only.
                                            # t.record_stream(current) for result tensors that outlive the runner's next use
                                            # of the slot) before using res on another stream
 
-``tail_streams=True`` enqueues each forward on TWO streams (``pdsc_forward_testing_streams``): the encoder on the slot's stream,
-everything after it on a high-priority companion stream, so that the tail's few workgroups are dispatched ahead of the queued
-workgroups of the other slot's attention launch.  Measured (profiles/r03_f_inflight_ab.txt, interleaved in one process): 4 pairs
-of N=5000 1.998 -> 1.954 ms per step (+2.2 %), 16-32 pairs +-0.5 %, one pair of N=1000 -10 %: worth it for small multi-pair
-batches only (bench.py turns it on for 4097..32768 correspondences per step); depth 3 is slower than depth 2 everywhere.
+``tail_streams=True`` (default) enqueues each forward on TWO streams (``pdsc_forward_testing_streams``): the encoder on the
+slot's stream, everything after it on a high-priority companion stream, so that the tail's few workgroups are dispatched ahead
+of the queued workgroups of the other slot's attention launch.  Measured, interleaved in one process, final build
+(profiles/r03_h_inflight_ab.txt, r03_i_inflight_ab.txt; ms per step: one stream / two plain streams / two streams + tail streams
+/ three plain streams): 32 pairs of N=5000 15.08 / 15.06 / 14.69 / 14.71; 16 pairs 8.59 / 8.60 / 8.20 / 8.25; 8 pairs 4.46 / 4.48
+/ 4.09 / 4.04; 4 pairs 2.05 / 2.06 / 1.93 / 1.96; KITTI 16 pairs 8.81 / 8.82 / 8.39 / 8.42, 2 pairs 1.44 / 1.46 / 1.23 / 1.15;
+N=10000 8 pairs 14.92 / 14.95 / 14.57 / 14.60, 1 pair 2.33 / 2.37 / 2.04 / 1.95.  Two plain streams alone gain nothing with the
+final attention kernel (they did, 1.4-5 %, while its workgroups still reserved 132 KiB of LDS: r03_f / r03_g); single pairs of
+N=1000 lose 10 % with tail streams and take the hipGraph path below instead.  (Also tried and removed: holding forward i+1 back
+until forward i's encoder is done so that the two overlap tail-on-head -- as slow as one stream, r03_g.)
 
 ``graphs=True`` additionally captures each slot's forward in a hipGraph (``pdsc_forward_testing`` only enqueues kernels: no
 sync, no allocation) and replays it: the ~45 launches of a forward cost the host one call.  That only matters when a forward is
@@ -38,7 +43,7 @@ import torch
 
 
 class InFlight:
-    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False, tail_streams: bool = False):
+    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False, tail_streams: bool = True):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
@@ -63,8 +68,8 @@ class InFlight:
             for k, st in zip(self._slots, self.streams):
                 tail = torch.cuda.Stream(device=dev, priority=-1)
                 fork, join = torch.cuda.Event(), torch.cuda.Event()
-                fork.record(st)
-                join.record(tail)                      # (creates the underlying hipEvents: their handles are passed to the library)
+                fork.record(st)                        # (creates the underlying hipEvents: their handles are passed to the library)
+                join.record(tail)
                 model._tail[k] = (tail, fork, join)
             torch.cuda.synchronize(dev)
         self._i = 0

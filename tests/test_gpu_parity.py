@@ -1680,6 +1680,30 @@ def test_ragged_batch_equals_the_single_pair_calls(sizes):
         assert loose <= 1, loose
 
 
+@pytest.mark.parametrize("sizes,gemm,fmt", [((1000, 777, 640, 999), "f32", "f32"), ((3000, 4100, 5000, 5333), "f32", "u16"),
+                                            ((2053, 2600), "h3", "f32")])
+def test_ragged_batch_other_arithmetic_modes(sizes, gemm, fmt):
+    """Ragged batches through the other kernels: fp32 layer GEMMs (small problems: the workgroup-per-tile kernel; larger ones:
+    layer_wave_kernel) and the fp32 spatial-consistency matrix."""
+    model, _ = _bench_model("n5000_b32")
+    pairs = _ragged_pairs(sizes, 400 + len(sizes), inlier_ratio=0.3)
+    model.layer_gemm, model.compat_format = gemm, fmt
+    try:
+        with torch.no_grad():
+            got = model(_as_lists(pairs))
+            torch.cuda.synchronize()
+            loose = 0
+            for i, p in enumerate(pairs):
+                one = _forward(model, p)
+                flips = int((got["final_labels"][i] != one["final_labels"][0]).sum())
+                dT = float((got["final_trans"][i] - one["final_trans"][0]).abs().max())
+                assert flips == 0 and dT < 1e-4, (i, sizes[i], flips, dT)
+                loose += dT >= 2e-5
+            assert loose <= 1
+    finally:
+        model.layer_gemm, model.compat_format = LAYER_GEMM_DEFAULT, COMPAT_FORMAT_DEFAULT
+
+
 def test_ragged_batch_padded_tensors_and_count_list():
     """The other calling form: tensors padded to the longest pair + data['num_corr']; padding rows hold garbage on purpose
     (NaN): nothing of a pair's result may depend on them; labels past a pair's count are zero.  Bit-identical to the list form."""
@@ -1739,7 +1763,7 @@ def test_forwards_in_flight_reproduce_the_plain_calls():
     model.invalidate_packed_weights()                      # the runner must rebuild them before going multi-stream
     runner = InFlight(model, depth=2, tail_streams=True)   # (each forward: encoder on the slot's stream, tail on its high-priority stream)
     assert runner.tail_streams
-    plain_streams = InFlight(model, depth=2)
+    plain_streams = InFlight(model, depth=2, tail_streams=False)
     for b, p in list(zip(batches, plain))[:2]:
         data = {k: g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
         data["testing"] = True

@@ -1,0 +1,10 @@
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out; cd $ROOT
+: > $OUT/r03_i_inflight_ab.txt
+timeout 300 python tools/inflight_ab.py --config kitti_n5000_b16 --steps 50 >> $OUT/r03_i_inflight_ab.txt 2>&1
+timeout 300 python tools/inflight_ab.py --config kitti_n5000_b16 --batch 2 --steps 200 >> $OUT/r03_i_inflight_ab.txt 2>&1
+timeout 300 python tools/inflight_ab.py --config lomatch_n10000_b8 --steps 30 >> $OUT/r03_i_inflight_ab.txt 2>&1
+timeout 300 python tools/inflight_ab.py --config lomatch_n10000_b8 --batch 1 --steps 150 >> $OUT/r03_i_inflight_ab.txt 2>&1
+timeout 300 python tools/inflight_ab.py --batch 16 --steps 50 >> $OUT/r03_i_inflight_ab.txt 2>&1
+timeout 300 python tools/inflight_ab.py --batch 8 --steps 80 >> $OUT/r03_i_inflight_ab.txt 2>&1
+grep -v amdgpu $OUT/r03_i_inflight_ab.txt
