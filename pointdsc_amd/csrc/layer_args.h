@@ -38,6 +38,7 @@ struct LayerArgs {
 
 int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st);      // layer_wave.hip
 int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st);        // layer_h3.hip (H3 fragment streams only)
+int launch_layer_h3_coop(const LayerArgs& a, bool tail, bool head, hipStream_t st);   // layer_coop.hip (same contract, few tiles)
 bool launch_layer_h3_fits(const LayerArgs& a, bool tail, bool head);                  // ... and only this output set
 
 }  // namespace pdsc

@@ -25,6 +25,7 @@
 namespace pdsc {
 
 constexpr int PDSC_H3_SMALL_TILES = 1024;     // launches with at most this many 32-point tiles take the small-launch shape
+constexpr int PDSC_H3_COOP_TILES = 256;       // ... and with at most this many (a workgroup per CU) the four-wavefronts-per-tile kernel (layer_coop.hip)
 
 #define LH_STAMP(k) \
     if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
@@ -388,6 +389,16 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     const dim3 grid(ceil_div(waves, nwv)), block(64 * nwv);
     const bool fb_pf = a.io_flags & PDSC_IO_FEATB_PF;
     const bool timed = tail && head;
+    int coop_tiles = PDSC_H3_COOP_TILES;
+#ifdef PDSC_EXPERIMENTS
+    coop_tiles = env_int("PDSC_LAYER_H3_COOP", coop_tiles);        // A/B knob (experiments builds): tile-count threshold, 0 = never
+#endif
+    if (waves <= coop_tiles && !a.trace) {
+        if (timed) profile_mark_begin(PDSC_PROF_LAYER, st);
+        const int rc = launch_layer_h3_coop(a, tail, head, st);
+        if (timed) profile_mark_end(PDSC_PROF_LAYER, st);
+        return rc;
+    }
     if (timed) profile_mark_begin(PDSC_PROF_LAYER, st);
     // every (tail, head, featB order) form in the default shape and in the small-launch shape (+ the A/B shapes)
 #ifdef PDSC_EXPERIMENTS

@@ -652,6 +652,54 @@ def test_h3_layer_kernel_merges_up_to_eight_key_splits(n, bs, nsplit):
     assert torch.equal(ops.pf_to_rows(fb_p, bs, ops.pf_rows(n))[:, :n].reshape(m, 128), fb_r)
 
 
+@pytest.mark.parametrize("n,nsplit", [(4100, 2), (5000, 3), (8190, 5)])
+def test_four_wavefront_layer_kernel_equals_the_wavefront_per_tile_kernel(n, nsplit):
+    """r03: launches of at most 256 tiles (N = 1000 x 1: 32 tiles, one dependency chain of 42 weight chunks per wavefront) take
+    layer_h3_coop_kernel (csrc/layer_coop.hip): four wavefronts share a tile's output tiles and hand the stages' operands over
+    in LDS.  Same MFMA order per output tile, so it must agree with layer_h3_kernel bit for bit: a batch of 2-3 pairs (more
+    than 256 tiles: one wavefront per tile) against the same pairs one at a time (at most 256 tiles each), in every form the
+    forward launches -- tail + head with point-fragment hand-offs, tail + head in rows, head only, tail only."""
+    bs = 3 if n < 5000 else 2
+    assert bs * ((n + 31) // 32) > 256 >= (n + 31) // 32
+    gen = torch.Generator().manual_seed(4400 + n)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    m = bs * n
+    batch = synthetic.make_batch(bs, n, seed=29 + n)
+    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    qkv = torch.cat([rnd(m, 128) * 0.3 * QSCALE, rnd(m, 128) * 0.3, rnd(m, 128)], dim=-1)
+    qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+    msg = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit)
+    pf, _ = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit, merge=False, layout="pf")
+    res = g(rnd(m, 128))
+    res_pf = ops.rows_to_pf(res, bs, n)
+    tail_w = [g(x) for x in (rnd(64, 128) / 11, rnd(64), rnd(64, 64) / 8, rnd(64), rnd(128, 64) / 8, rnd(128))]
+    head_w = [g(x) for x in (rnd(128, 128) / 11, rnd(128), rnd(384, 128) / 11, rnd(384))]
+    npad, prow = (n + 255) // 256 * 256, ops.pf_rows(n)
+    po = pf.view(torch.float32)[:bs * nsplit * npad * 128].reshape(bs, -1)
+    ml = pf.view(torch.float32)[bs * nsplit * npad * 128:bs * nsplit * npad * 130].reshape(bs, -1)
+    q_bytes, kv_bytes = qs.numel() // bs, kv.numel() // bs
+    flags = ops.PF_PARTIALS | ops.PF_RES | ops.PF_FEATB
+
+    _, fb_io, qs_io, kv_io = ops.layer_fused_io(res_pf, None, tail_w, head_w, bs, n, flags, partials=(pf, nsplit))
+    _, fb_r, _, qs_r, kv_r = ops.layer_fused_split(msg, res, None, tail_w, head_w, bs, n, frag=True, gemm="h3", want_feat=False)
+    _, fb_h, _, qs_h, kv_h = ops.layer_fused_split(None, None, res, None, head_w, bs, n, frag=True, gemm="h3")
+    ft_t, _, _, _, _ = ops.layer_fused_split(msg, res, None, tail_w, None, bs, n, frag=True, gemm="h3")
+    for b in range(bs):
+        rows = slice(b * n, (b + 1) * n)
+        one = torch.cat([po[b], ml[b]]).contiguous().view(torch.uint8)
+        _, fb1, qs1, kv1 = ops.layer_fused_io(res_pf.view(bs, -1)[b].contiguous(), None, tail_w, head_w, 1, n, flags, partials=(one, nsplit))
+        assert torch.equal(fb1, fb_io.view(bs, -1)[b])
+        assert torch.equal(qs1, qs_io.view(bs, -1)[b]) and torch.equal(kv1, kv_io.view(bs, -1)[b])
+        _, fb1, _, qs1, kv1 = ops.layer_fused_split(msg[rows].contiguous(), res[rows].contiguous(), None, tail_w, head_w, 1, n, frag=True,
+                                                    gemm="h3", want_feat=False)
+        assert torch.equal(fb1, fb_r[rows]) and torch.equal(qs1, qs_r.view(bs, -1)[b]) and torch.equal(kv1, kv_r.view(bs, -1)[b])
+        _, fb1, _, qs1, kv1 = ops.layer_fused_split(None, None, res[rows].contiguous(), None, head_w, 1, n, frag=True, gemm="h3")
+        assert torch.equal(fb1, fb_h[rows]) and torch.equal(qs1, qs_h.view(bs, -1)[b]) and torch.equal(kv1, kv_h.view(bs, -1)[b])
+        ft1, _, _, _, _ = ops.layer_fused_split(msg[rows].contiguous(), res[rows].contiguous(), None, tail_w, None, 1, n, frag=True, gemm="h3")
+        assert torch.equal(ft1, ft_t[rows])
+    assert q_bytes * bs == qs_io.numel() and kv_bytes * bs == kv_io.numel() and prow * 128 * bs == fb_io.numel()
+
+
 @pytest.mark.parametrize("n,bs,nsplit", [(33, 2, 2), (1000, 3, 3), (3001, 2, 2), (5000, 2, 2), (5000, 5, 4)])
 def test_point_fragment_hand_offs_reproduce_the_row_order_chain(n, bs, nsplit):
     """The forward with layer_gemm = "h3" hands the key-split partials (attention -> layer kernel) and featB (layer kernel ->
