@@ -391,7 +391,7 @@ def main():
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s); %d forward(s) in flight per GPU "
                                   "(consecutive steps alternate between HIP streams%s)"
                                   % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU", depth["d"],
-                                     ", each replayed as a captured hipGraph" if runners[in_flight].graphs else "")},
+                                     ", each replayed as a captured hipGraph" if (runners[in_flight].graphs and runners[in_flight]._captured) else "")},
         "roofline": roof,
         # H3 kernel: algorithmic HBM bytes per launch / its duration against 8 TB/s; otherwise matrix-pipe issue cycles the
         # launch needs per SIMD / its duration, against a pipe that is busy every cycle at the maximum clock
@@ -415,7 +415,7 @@ def main():
     if sustained is not None:
         line["sustained"] = sustained
     line["in_flight"] = depth["d"]
-    line["hip_graphs"] = bool(runners[in_flight].graphs)
+    line["hip_graphs"] = bool(runners[in_flight].graphs and runners[in_flight]._captured)
     line["tail_streams"] = bool(runners[in_flight].tail_streams)
     if single is not None:
         line["single_stream"] = single

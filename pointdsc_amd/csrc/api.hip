@@ -54,6 +54,16 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
     return PDSC_OK;
 }
 
+__global__ void fill_u32_kernel(unsigned int* p, unsigned int value, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = value;
+}
+int launch_fill_u32(unsigned int* p, unsigned int value, size_t count, hipStream_t st) {
+    if (count == 0) return PDSC_OK;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, p, value, count);
+    return check_launch("fill");
+}
+
 // ---- opt-in event timing -----------------------------------------------------------------------
 // stride: only every stride-th launch of the kind is bracketed by events (an event record costs the stream ~3.5 us and breaks
 // the back-to-back issue of the kernels around it: 50 records per forward were 8 % of a 2 ms step)
@@ -206,6 +216,9 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("best", (size_t)bs * sizeof(int));
     L.add("initial_trans", (size_t)bs * 16 * f);
     L.add("solves", (size_t)bs * sizeof(int));
+#ifdef PDSC_EXPERIMENTS
+    L.add("score_dbg", (size_t)bs * S * 16 * f);        // diagnostics of the scoring kernel (score.hip, DBG)
+#endif
     return L;
 }
 
@@ -512,7 +525,13 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     } else
         PDSC_TRY(pdsc_seed_solve(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig, conv_mask, nullptr,
                                  seed_trans, seed_w, bs, N, S, k, cfg->num_iterations, stream));
+#ifdef PDSC_EXPERIMENTS
+    score_debug_slot() = env_int("PDSC_SCORE_DEBUG", 0) ? F("score_dbg") : nullptr;
+#endif
     PDSC_TRY(launch_score_hypotheses(seed_trans, src, tgt, cfg->inlier_threshold, counts, bs, N, S, nvalid, hst));
+#ifdef PDSC_EXPERIMENTS
+    score_debug_slot() = nullptr;
+#endif
     if (mode == 0) {
         PDSC_TRY(launch_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S, nvalid, hst));
         // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis

@@ -55,8 +55,12 @@ __device__ __forceinline__ void coop_finish(const f32x16& acc, const f32x16& cro
         for (int e = 0; e < 4; ++e) v[g][e] = QKV ? acc[4 * g + e] : fmaf(cross[4 * g + e], H3_INV, acc[4 * g + e]);
 }
 
-template <bool T, bool H, bool FB_PF>
-__global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerArgs a) {
+// NB: depth of the wavefront's weight-chunk ring.  4, with the operands re-read from LDS per chunk and the partials loaded in
+// batches, fits 256 registers (236), so two workgroups share a CU: launches of 257..512 tiles (the per-GPU shares of the 8-GPU
+// configurations: 2 pairs of N = 5000, 1 pair of N = 10000) run in one round.  A ring of 6 (382 registers, one workgroup per
+// CU) measured 1-2 % SLOWER even at 32 tiles (profiles/r03_k_ab_coop.txt) and is not instantiated.
+template <bool T, bool H, bool FB_PF, int NB>
+__global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) CoopOps ops;
     __shared__ __attribute__((aligned(16))) float Vs_all[LC_WAVES][32 * LW_VLD];
     const int lane = threadIdx.x & 63;
@@ -73,34 +77,44 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
     float* Vs = Vs_all[w];
     unsigned char* patch = reinterpret_cast<unsigned char*>(Vs);
 
-    // ---- this wavefront's weight chunks, in the order it uses them; six register buffers -----------------------------------
+    // ---- this wavefront's weight chunks in the order it uses them: sequence position k = 0..11 --------------------------------
+    //   0, 1: fc1 tile w (waves 0, 1 only)   2: fc2 tile w (waves 0, 1 only)   3: fc3 tile w   4, 5: pcn tile w
+    //   6, 7: q|k|v tile w (Q)   8, 9: tile 4 + w (K)   10, 11: tile 8 + w (V)
     // tail stream: fc1 tile t = chunks 2t, 2t+1; fc2 tile t = 4 + t; fc3 tile t = 6 + t.  head stream: pcn tile t = 2t, 2t+1;
-    // q|k|v tile t = 8 + 2t, 9 + 2t.  Bias fragments by tile ordinal (layer_wave.h).
-    WChunk W[6];
+    // q|k|v tile t = 8 + 2t, 9 + 2t.  Bias fragments by tile ordinal (layer_wave.h).  Position k lives in ring slot k % NB and
+    // is requested as soon as position k - NB has been consumed.
+    constexpr int K0 = T ? 0 : 4, K1 = H ? 12 : 4;
+    WChunk W[NB];
     const bool low = w < 2;                                          // fc1 / fc2 have two output tiles: waves 0 and 1
-    if constexpr (T) {
-        if (low) {
-            load_chunk_frag(W[0], a.wf_tail, 2 * w, LW_TAIL_CHUNKS, w, lane);
-            load_chunk_frag(W[1], a.wf_tail, 2 * w + 1, LW_TAIL_CHUNKS, -1, lane);
-            load_chunk_frag(W[2], a.wf_tail, 4 + w, LW_TAIL_CHUNKS, 2 + w, lane);
+    auto issue = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k >= K0 && k < K1) {
+            WChunk& dst = W[k % NB];
+            if constexpr (k < 2) { if (low) load_chunk_frag(dst, a.wf_tail, 2 * w + k, LW_TAIL_CHUNKS, k == 0 ? w : -1, lane); }
+            else if constexpr (k == 2) { if (low) load_chunk_frag(dst, a.wf_tail, 4 + w, LW_TAIL_CHUNKS, 2 + w, lane); }
+            else if constexpr (k == 3) load_chunk_frag(dst, a.wf_tail, 6 + w, LW_TAIL_CHUNKS, 4 + w, lane);
+            else if constexpr (k < 6) load_chunk_frag(dst, a.wf_head, 2 * w + (k - 4), LW_HEAD_CHUNKS, k == 4 ? w : -1, lane);
+            else {
+                const int t = w + 4 * ((k - 6) >> 1);
+                load_chunk_frag(dst, a.wf_head, 8 + 2 * t + (k & 1), LW_HEAD_CHUNKS, (k & 1) ? -1 : 4 + t, lane);
+            }
         }
-        load_chunk_frag(W[3], a.wf_tail, 6 + w, LW_TAIL_CHUNKS, 4 + w, lane);
-    }
-    if constexpr (H) {
-        load_chunk_frag(W[4], a.wf_head, 2 * w, LW_HEAD_CHUNKS, w, lane);
-        load_chunk_frag(W[5], a.wf_head, 2 * w + 1, LW_HEAD_CHUNKS, -1, lane);
-    }
-    auto load_qkv = [&](WChunk& dst, int j, int c) {                 // chunk c of this wave's j-th q|k|v tile (tile w + 4j)
-        const int t = w + 4 * j;
-        load_chunk_frag(dst, a.wf_head, 8 + 2 * t + c, LW_HEAD_CHUNKS, c == 0 ? 4 + t : -1, lane);
     };
-    if constexpr (!T && H) { load_qkv(W[0], 0, 0); load_qkv(W[1], 0, 1); load_qkv(W[2], 1, 0); load_qkv(W[3], 1, 1); }
-
+    static_for<K0, K0 + NB>([&](auto kc) { issue(kc); });
+    // chunk at position k on the matrix cores (operands: k-steps 4c .. 4c+3 of LDS set `set`), then the request for k + NB
+    f32x16 acc, cross;
+    auto run_chunk = [&](auto kc, int set, int c, bool first, auto qkv_c) {
+        constexpr int k = decltype(kc)::value;
+        u32x4 oh[4], ol[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { oh[g] = ops.v[set][4 * c + g][0][lane]; ol[g] = ops.v[set][4 * c + g][1][lane]; }
+        coop_chunk<decltype(qkv_c)::value>(acc, cross, W[k % NB], oh, ol, first);
+        issue(std::integral_constant<int, k + NB>{});
+    };
+    using std::false_type; using std::true_type;
     auto put = [&](int set, int kk, const u32x4& oh, const u32x4& ol) { ops.v[set][kk][0][lane] = oh; ops.v[set][kk][1][lane] = ol; };
     f32x4 y3[4];            // this wave's 32 channels (32w + 8s + 4h + e) of the residual rows, then of feat
-    f32x16 acc, cross;
     f32x4 v[4];
-    u32x4 oh[8], ol[8];
 
     if constexpr (T) {
         // ---- stage 0: operand of fc1 = the attention's message; this wave converts channels 32w .. 32w+31 (k-steps 2w, 2w+1)
@@ -116,13 +130,10 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
                 const bool pf = a.io_flags & PDSC_IO_PARTIALS_PF;
                 const size_t e0 = pf ? ((size_t)b * NS * a.Npad + (size_t)tile * 32) * PDSC_CHANNELS + lane * 4 : slot0 * PDSC_CHANNELS + 4 * h;
                 const int eq = pf ? 256 : 8;
+                // q per batch of loads: everything at once in the latency form; <= 32 registers of partials in flight in the
+                // two-workgroups-per-CU form (256 registers)
+                constexpr int GQ = NB > 4 ? 4 : NS <= 2 ? 4 : NS <= 4 ? 2 : 1;
                 float wsp[NS], ls[NS];
-                f32x4 pv[4][NS];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int sp = 0; sp < NS; ++sp)
-                        pv[q][sp] = *reinterpret_cast<const f32x4*>(a.part_o + e0 + (size_t)sp * a.Npad * PDSC_CHANNELS + (size_t)eq * (4 * w + q));
 #pragma unroll
                 for (int sp = 0; sp < NS; ++sp) {
                     const float2 ml = *reinterpret_cast<const float2*>(a.part_ml + (slot0 + (size_t)sp * a.Npad) * 2);
@@ -139,14 +150,27 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
                 }
                 const float rden = 1.0f / den;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                for (int q0 = 0; q0 < 4; q0 += GQ) {
+                    f32x4 pv[GQ][NS];
 #pragma unroll
-                    for (int sp = 0; sp < NS; ++sp)
+                    for (int q = 0; q < GQ; ++q)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s[e] = fmaf(pv[q][sp][e], wsp[sp], s[e]);
+                        for (int sp = 0; sp < NS; ++sp)
+                            pv[q][sp] = *reinterpret_cast<const f32x4*>(a.part_o + e0 + (size_t)sp * a.Npad * PDSC_CHANNELS + (size_t)eq * (4 * w + q0 + q));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x0[q][e] = s[e] * rden;
+                    for (int q = 0; q < GQ; ++q) {
+                        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[e] = fmaf(pv[q][sp][e], wsp[sp], s[e]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x0[q0 + q][e] = s[e] * rden;
+                            if constexpr (GQ < 4) asm volatile("" : "+v"(x0[q0 + q][e]));    // materialise: the next batch's loads reuse the registers
+                        }
+                    }
+                    if constexpr (GQ < 4) __builtin_amdgcn_sched_barrier(0);
                 }
             };
             switch (a.nsplit) {
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
             make_kstep<true>(x0[0], x0[1], ph, pl); put(0, 2 * w, ph, pl);
             make_kstep<true>(x0[2], x0[3], ph, pl); put(0, 2 * w + 1, ph, pl);
         }
-        // residual rows of this wave's fc3 tile (needed four stages on: the loads fly under fc1 / fc2)
+        // residual rows of this wave's fc3 tile (needed three stages on: the loads fly under fc1 / fc2)
         {
             const bool pf = a.io_flags & PDSC_IO_RES_PF;
             const float* r0 = a.res + (pf ? (size_t)gw * PF_TILE_FLOATS + lane * 4 : row * PDSC_CHANNELS + 4 * h);
@@ -177,10 +201,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
 
         // ---- fc1: 128 -> 64, output tile w on waves 0 and 1 --------------------------------------------------------------
         if (low) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) { oh[kk] = ops.v[0][kk][0][lane]; ol[kk] = ops.v[0][kk][1][lane]; }
-            coop_chunk<false>(acc, cross, W[0], oh, ol, true);
-            coop_chunk<false>(acc, cross, W[1], oh + 4, ol + 4, false);
+            run_chunk(std::integral_constant<int, 0>{}, 0, 0, true, false_type{});
+            run_chunk(std::integral_constant<int, 1>{}, 0, 1, false, false_type{});
             coop_finish<false>(acc, cross, v);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -189,15 +211,15 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
             u32x4 ph, pl;
             make_kstep<true>(v[0], v[1], ph, pl); put(1, 2 * w, ph, pl);
             make_kstep<true>(v[2], v[3], ph, pl); put(1, 2 * w + 1, ph, pl);
+        } else {
+            issue(std::integral_constant<int, NB>{});                 // (waves 2, 3: positions 0..2 are empty, their slots free)
+            issue(std::integral_constant<int, NB + 1>{});
         }
-        if constexpr (H) { load_qkv(W[0], 0, 0); load_qkv(W[1], 0, 1); }       // (all four waves: the fc1 buffers are free)
         __syncthreads();
 
         // ---- fc2: 64 -> 64, output tile w on waves 0 and 1 ---------------------------------------------------------------
         if (low) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { oh[kk] = ops.v[1][kk][0][lane]; ol[kk] = ops.v[1][kk][1][lane]; }
-            coop_chunk<false>(acc, cross, W[2], oh, ol, true);
+            run_chunk(std::integral_constant<int, 2>{}, 1, 0, true, false_type{});
             coop_finish<false>(acc, cross, v);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -206,14 +228,13 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
             u32x4 ph, pl;
             make_kstep<true>(v[0], v[1], ph, pl); put(0, 2 * w, ph, pl);
             make_kstep<true>(v[2], v[3], ph, pl); put(0, 2 * w + 1, ph, pl);
+        } else {
+            issue(std::integral_constant<int, NB + 2>{});
         }
-        if constexpr (H) load_qkv(W[2], 1, 0);
         __syncthreads();
 
         // ---- fc3: 64 -> 128, output tile w; feat = residual + fc3 --------------------------------------------------------
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { oh[kk] = ops.v[0][kk][0][lane]; ol[kk] = ops.v[0][kk][1][lane]; }
-        coop_chunk<false>(acc, cross, W[3], oh, ol, true);
+        run_chunk(std::integral_constant<int, 3>{}, 0, 0, true, false_type{});
         coop_finish<false>(acc, cross, v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -222,7 +243,6 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
             // tail-only launches return feat; lanes beyond the pair's last point hold copies of its last row
             if constexpr (!H) *reinterpret_cast<f32x4*>(a.feat_out + row * PDSC_CHANNELS + 32 * w + 8 * s + 4 * h) = y3[s];
         }
-        if constexpr (H) load_qkv(W[3], 1, 1);
     } else {
         // head only (first layer): feat comes in as rows
 #pragma unroll
@@ -238,12 +258,9 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
         __syncthreads();
 
         // ---- pcn: 128 -> 128, output tile w; featB = relu -----------------------------------------------------------------
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) { oh[kk] = ops.v[1][kk][0][lane]; ol[kk] = ops.v[1][kk][1][lane]; }
-        coop_chunk<false>(acc, cross, W[4], oh, ol, true);
-        coop_chunk<false>(acc, cross, W[5], oh + 4, ol + 4, false);
+        run_chunk(std::integral_constant<int, 4>{}, 1, 0, true, false_type{});
+        run_chunk(std::integral_constant<int, 5>{}, 1, 1, false, false_type{});
         coop_finish<false>(acc, cross, v);
-        load_qkv(W[4], 2, 0); load_qkv(W[5], 2, 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -269,14 +286,12 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
         __syncthreads();
 
         // ---- q | k | v: 128 -> 384; this wave's Q tile w, K tile w, V tile w ---------------------------------------------------
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) { oh[kk] = ops.v[0][kk][0][lane]; ol[kk] = ops.v[0][kk][1][lane]; }
         unsigned char* img = a.kv + (size_t)gw * SPL_TILE_STRIDE;
         const int n0 = 32 * w;
 
         // Q rows (hi[128] | lo[128]) bf16 through the patch: row = (hi 64 B | lo 64 B) of this tile's 32 channels
-        coop_chunk<true>(acc, cross, W[0], oh, ol, true);
-        coop_chunk<true>(acc, cross, W[1], oh + 4, ol + 4, false);
+        run_chunk(std::integral_constant<int, 6>{}, 0, 0, true, true_type{});
+        run_chunk(std::integral_constant<int, 7>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -295,8 +310,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
 
         // K image, chunk-major (split_layout.h): after the half swap lane (key l31, half h) holds chunk 4w + s of its key for the
         // hi (h = 0) / lo (h = 1) plane
-        coop_chunk<true>(acc, cross, W[2], oh, ol, true);
-        coop_chunk<true>(acc, cross, W[3], oh + 4, ol + 4, false);
+        run_chunk(std::integral_constant<int, 8>{}, 0, 0, true, true_type{});
+        run_chunk(std::integral_constant<int, 9>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -309,8 +324,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
         }
 
         // V^T image: transpose 32 keys x 32 channels through the wave-private LDS patch
-        coop_chunk<true>(acc, cross, W[4], oh, ol, true);
-        coop_chunk<true>(acc, cross, W[5], oh + 4, ol + 4, false);
+        run_chunk(std::integral_constant<int, 10>{}, 0, 0, true, true_type{});
+        run_chunk(std::integral_constant<int, 11>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);
         wave_lds_sync();                                                              // (the Q passes have read the patch)
 #pragma unroll
@@ -340,11 +355,11 @@ __global__ __launch_bounds__(64 * LC_WAVES, 1) void layer_h3_coop_kernel(LayerAr
 int launch_layer_h3_coop(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     const dim3 grid(a.bs * ceil_div(a.N, 32)), block(64 * LC_WAVES);
     const bool fb_pf = a.io_flags & PDSC_IO_FEATB_PF;
-    if (tail && head && fb_pf) hipLaunchKernelGGL((layer_h3_coop_kernel<true, true, true>), grid, block, 0, st, a);
-    else if (head && !tail && fb_pf) hipLaunchKernelGGL((layer_h3_coop_kernel<false, true, true>), grid, block, 0, st, a);
-    else if (tail && head) hipLaunchKernelGGL((layer_h3_coop_kernel<true, true, false>), grid, block, 0, st, a);
-    else if (tail) hipLaunchKernelGGL((layer_h3_coop_kernel<true, false, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((layer_h3_coop_kernel<false, true, false>), grid, block, 0, st, a);
+    if (tail && head && fb_pf) hipLaunchKernelGGL((layer_h3_coop_kernel<true, true, true, 4>), grid, block, 0, st, a);
+    else if (head && !tail && fb_pf) hipLaunchKernelGGL((layer_h3_coop_kernel<false, true, true, 4>), grid, block, 0, st, a);
+    else if (tail && head) hipLaunchKernelGGL((layer_h3_coop_kernel<true, true, false, 4>), grid, block, 0, st, a);
+    else if (tail) hipLaunchKernelGGL((layer_h3_coop_kernel<true, false, false, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((layer_h3_coop_kernel<false, true, false, 4>), grid, block, 0, st, a);
     return check_launch("pdsc_layer_fused_frag(h3, four wavefronts per tile)");
 }
 

@@ -24,8 +24,10 @@
 
 namespace pdsc {
 
-constexpr int PDSC_H3_SMALL_TILES = 1024;     // launches with at most this many 32-point tiles take the small-launch shape
-constexpr int PDSC_H3_COOP_TILES = 256;       // ... and with at most this many (a workgroup per CU) the four-wavefronts-per-tile kernel (layer_coop.hip)
+// launches with at most this many 32-point tiles take the four-wavefronts-per-tile kernel (layer_coop.hip).  Measured, whole
+// forward, interleaved A/B (profiles/r03_j / r03_k / r03_l_ab_coop.txt): 32 tiles (N=1000 x 1) -25 %, 157 (N=5000 x 1) -11 %,
+// 313-314 (1 pair of N=10000, 2 of N=5000) -3 ... -5 %, 625 -0.5 %, 1250 -1.5 %, 2500 (16 pairs) -0.9 %, 5000 (32 pairs) +0.9 %
+constexpr int PDSC_H3_COOP_TILES = 2560;
 
 #define LH_STAMP(k) \
     if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
@@ -41,12 +43,11 @@ constexpr int stage_tiles(int stage) { return stage == ST_FC1 || stage == ST_FC2
 // launch -- 1: weights loaded once, 2: no global stores (8 / 16 / 32 / 64: no Q / K / V / featB stores), 4: no partial /
 // residual loads.  profiles/r02_j_layer_knockout*.txt: all three off = 30 us of 181; loads 69, stores 54, weights 21.
 // FB_PF: featB leaves in point-fragment order (split_layout.h) instead of rows
-// NWV / NBUF (r03): wavefronts per workgroup and depth of the weight-chunk ring.  The default (4 waves, 2 buffers) is tuned
-// for launches with more tiles than the chip has SIMDs (several wavefronts per SIMD hide each other's L2 round trips).  With
-// fewer tiles (the per-GPU shares of the 8-GPU configurations: 4 pairs of N=5000 = 625 tiles on 1024 SIMDs) every wavefront
-// is alone on its SIMD and its chain is paced by the round trip of each 8 KiB chunk; 4-wave workgroups also leave 100 of the
-// 256 CUs idle while the busy ones pull 4 x 344 KiB through one L1.  The small-launch form: 1 or 2 waves per workgroup
-// (tiles spread over all CUs) and a ring of 3 or 4 chunks in flight (the register budget of a lone wavefront is 512).
+// NWV / NBUF: wavefronts per workgroup and depth of the weight-chunk ring.  The product launches (4, 2) only: several
+// wavefronts per SIMD hide each other's L2 round trips, which needs more tiles than the chip has SIMDs.  Launches of at most
+// PDSC_H3_COOP_TILES tiles go to layer_coop.hip instead (a lone wavefront per tile is one 42-chunk dependency chain, 28 us
+// whatever the tile count); the r03 small-launch shapes (1-2 waves, ring of 3-4: -5 % at 313-625 tiles, superseded by the
+// four-wavefront kernel) are instantiated in experiments builds only (A/B knob PDSC_LAYER_H3_SHAPE).
 template <bool T, bool H, bool TRACE = false, int PIPE = 6, int EXP = 0, bool FB_PF = false, int NWV = LW_WAVES, int NBUF = 2>
 __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) float Vs_all[NWV][32 * LW_VLD];
@@ -369,13 +370,10 @@ bool launch_layer_h3_fits(const LayerArgs& a, bool tail, bool head) {
     return a.wf_tail || !tail;
 }
 
-// launch shape for `tiles` wavefront-tiles: (waves per workgroup, weight-ring depth), see the kernel's NWV / NBUF note.
-// Measured (profiles/r03_a_ab_*.txt, whole forward): 4 pairs of N=5000 (625 tiles) -4.8 % per step with the small-launch
-// shape, 2 pairs (314 tiles) -4.7 %, one pair of N=10000 (313 tiles) -5.1 %; 8 pairs (1250 tiles) +-0.5 %: no gain any more.
-// The ring depth carries most of it ((2,2): +0.5 %, (2,3): -4.5 %, (1,3) / (2,4) / (1,4): -5.0 ... -5.4 %).
+// launch shape (waves per workgroup, weight-ring depth), see the kernel's NWV / NBUF note
 static void h3_launch_shape(int tiles, int* nwv, int* nbuf) {
     *nwv = LW_WAVES; *nbuf = 2;
-    if (tiles <= PDSC_H3_SMALL_TILES) { *nwv = 1; *nbuf = 4; }
+    (void)tiles;
 #ifdef PDSC_EXPERIMENTS
     const int force = env_int("PDSC_LAYER_H3_SHAPE", 0);          // A/B knob (experiments builds): 10 * waves + depth, e.g. 23
     if (force == 42 || force == 23 || force == 13 || force == 24 || force == 14 || force == 22) { *nwv = force / 10; *nbuf = force % 10; }
@@ -403,7 +401,8 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     // every (tail, head, featB order) form in the default shape and in the small-launch shape (+ the A/B shapes)
 #ifdef PDSC_EXPERIMENTS
 #define PDSC_H3_LAUNCH_EXTRA(TT, HH, PF)                                                                                            \
-        if (nwv == 2 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 3>), grid, block, 0, st, a);      \
+        if (nwv == 1 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 4>), grid, block, 0, st, a);      \
+        else if (nwv == 2 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 3>), grid, block, 0, st, a); \
         else if (nwv == 1 && nbuf == 3) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 3>), grid, block, 0, st, a); \
         else if (nwv == 2 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 4>), grid, block, 0, st, a); \
         else if (nwv == 2 && nbuf == 2) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 2, 2>), grid, block, 0, st, a); \
@@ -414,8 +413,7 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
 #define PDSC_H3_LAUNCH(TT, HH, PF)                                                                                                  \
     do {                                                                                                                            \
         PDSC_H3_LAUNCH_EXTRA(TT, HH, PF)                                                                                            \
-        if (nwv == 1 && nbuf == 4) hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF, 1, 4>), grid, block, 0, st, a);      \
-        else hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF>), grid, block, 0, st, a);                                  \
+        hipLaunchKernelGGL((layer_h3_kernel<TT, HH, false, 6, 0, PF>), grid, block, 0, st, a);                                       \
     } while (0)
     if (tail && head && fb_pf) {
 #ifdef PDSC_LAYER_DIAG      // knock-out build (PDSC_HIPCC_EXTRA=-DPDSC_LAYER_DIAG python -m pointdsc_amd.build --force; tools/layer_bench.py)

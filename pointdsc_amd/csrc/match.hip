@@ -206,7 +206,7 @@ extern "C" int pdsc_match_descriptors(const float* src_desc, const float* tgt_de
     }
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* keys = (unsigned long long*)scratch;
-    if (hipMemsetAsync(keys, 0xff, (size_t)Ns * sizeof(unsigned long long), st) != hipSuccess) return check_launch("pdsc_match_descriptors(memset)");
+    if (const int rc = launch_fill_u32((unsigned int*)keys, 0xFFFFFFFFu, (size_t)Ns * 2, st); rc != PDSC_OK) return rc;
     // split the targets so that ~1024 workgroups exist, in whole staged tiles
     const int src_blocks = ceil_div(Ns, MT_SRC);
     int splits = ceil_div(1024, src_blocks);

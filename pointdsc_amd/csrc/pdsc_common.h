@@ -27,6 +27,11 @@ int check_launch(const char* what);
 // the attribute is per device -- and checked: returns PDSC_OK or PDSC_ERR_LAUNCH with the error text set.  Thread-safe.
 int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 
+// buffer := value, as a kernel launch on `st` (NOT hipMemsetAsync: profiles/r03_p_diverge_probe.txt -- with several forwards in
+// flight, and above all inside replayed hipGraphs, the zeroing of the hypothesis counters was not reliably ordered before the
+// scoring kernel's atomicAdds that follow it on the same stream; a kernel node is)
+int launch_fill_u32(unsigned int* p, unsigned int value, size_t count, hipStream_t st);
+
 // opt-in event timing of the roofline kernels (api.hip); no-ops unless pdsc_profile_enable() was called
 void profile_mark_begin(int kind, hipStream_t st);
 void profile_mark_end(int kind, hipStream_t st);

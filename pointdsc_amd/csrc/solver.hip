@@ -309,7 +309,7 @@ extern "C" int pdsc_seed_solve(const float* normed, const float* src, const floa
     PDSC_REQUIRE(num_iterations >= 0 && num_iterations <= PDSC_MAX_POWER_ITERS, "pdsc_seed_solve: num_iterations=%d (max %d)",
                  num_iterations, PDSC_MAX_POWER_ITERS);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(conv_mask, 0xFF, sizeof(unsigned int) * bs, st) != hipSuccess) return pdsc::check_launch("memset");
+    if (const int rc = pdsc::launch_fill_u32(conv_mask, 0xFFFFFFFFu, (size_t)bs, st); rc != PDSC_OK) return rc;
     const int nb = pdsc::ceil_div(k, 16);
 #define PDSC_SOLVE(NBV) pdsc::launch_seed_solve<NBV>(normed, src, tgt, knn_idx, sigma, sigma_spat, eig_iters, conv_mask, seed_M, seed_trans, \
                                                      seed_weights, bs, N, S, k, num_iterations, st)

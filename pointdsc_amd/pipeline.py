@@ -31,6 +31,16 @@ sync, no allocation) and replays it: the ~45 launches of a forward cost the host
 launch-bound -- one pair of N=1000: 0.243 ms per forward with three eager forwards in flight, 0.149 ms with four captured ones
 (profiles/r03_e_graph_probe.txt); at 32 pairs of N=5000 it changes nothing.  Inputs are copied into per-slot static tensors,
 outputs are returned as copies; ragged batches and the validation forward take the eager path.
+Exactness under concurrency (r03; tools/inflight_race_probe.py, tools/inflight_diverge_probe.py, profiles/r03_*_probe.txt): with
+several forwards sharing the chip -- above all three replayed graphs of 2-3 pairs of N=5000 -- up to 35 % of the forwards first
+came back with a pose off by 1e-4 ... 6e-4 (labels equal).  Both causes sat in the hypothesis scoring stage and are fixed in
+the library: (1) hipMemsetAsync of the vote counters was not reliably ordered before the atomicAdds that followed it on the
+same stream (now: no memset, no atomics; csrc/score.hip, csrc/pdsc_common.h launch_fill_u32); (2) the compiler-vectorised
+packed-fp32 form of the residual test (v_pk_fma_f32 with op_sel broadcasts) miscounted a few votes on one half of the seed pairs
+while other kernels were co-resident -- inputs verified equal, a recount inside the same launch right, the affected half moving
+with the instruction schedule -- and score.hip is now built without SLP vectorisation (pointdsc_amd/build.py).  After both:
+0 differing forwards in 8000-12000 per mode (plain streams, tail streams, replayed graphs; 1, 2 and 3 pairs of N=5000, single
+pairs of N=1000).
 
 The reference has nothing like it (its testing loop is one synchronous call per pair, evaluation/test_3DMatch.py:32-54).
 """

@@ -652,15 +652,16 @@ def test_h3_layer_kernel_merges_up_to_eight_key_splits(n, bs, nsplit):
     assert torch.equal(ops.pf_to_rows(fb_p, bs, ops.pf_rows(n))[:, :n].reshape(m, 128), fb_r)
 
 
-@pytest.mark.parametrize("n,nsplit", [(4100, 2), (5000, 3), (8190, 5)])
+@pytest.mark.parametrize("n,nsplit", [(4100, 2), (5000, 3), (8190, 5), (16384, 8)])
 def test_four_wavefront_layer_kernel_equals_the_wavefront_per_tile_kernel(n, nsplit):
-    """r03: launches of at most 256 tiles (N = 1000 x 1: 32 tiles, one dependency chain of 42 weight chunks per wavefront) take
+    """r03: launches of at most 2560 tiles (N = 1000 x 1: 32 tiles, one dependency chain of 42 weight chunks per wavefront) take
     layer_h3_coop_kernel (csrc/layer_coop.hip): four wavefronts share a tile's output tiles and hand the stages' operands over
-    in LDS.  Same MFMA order per output tile, so it must agree with layer_h3_kernel bit for bit: a batch of 2-3 pairs (more
-    than 256 tiles: one wavefront per tile) against the same pairs one at a time (at most 256 tiles each), in every form the
+    in LDS.  Same MFMA order per output tile, so it must agree with layer_h3_kernel bit for bit: a batch of pairs with more than
+    2560 tiles (one wavefront per tile) against the same pairs one at a time (at most 2560 tiles each), in every form the
     forward launches -- tail + head with point-fragment hand-offs, tail + head in rows, head only, tail only."""
-    bs = 3 if n < 5000 else 2
-    assert bs * ((n + 31) // 32) > 256 >= (n + 31) // 32
+    tiles = (n + 31) // 32
+    bs = 2560 // tiles + 1
+    assert bs * tiles > 2560 >= tiles
     gen = torch.Generator().manual_seed(4400 + n)
     rnd = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
     m = bs * n
@@ -1830,14 +1831,14 @@ def test_forwards_in_flight_reproduce_the_plain_calls():
     # ... and with every slot's forward replayed as a captured hipGraph (static per-slot inputs, outputs returned as copies)
     gr = InFlight(model, depth=3, graphs=True)
     outs = []
-    for rep in range(2):
+    for rep in range(4):
         for b in batches:
             data = {k: g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
             data["testing"] = True
             outs.append(gr(data))
     gr.synchronize()
-    assert gr.graphs, "hipGraph capture fell back to the eager path"
-    for o, p in zip(outs, plain + plain):
+    assert gr.graphs and gr._captured, "hipGraph capture fell back to the eager path"
+    for o, p in zip(outs, plain * 4):
         assert torch.equal(o["final_trans"], p["final_trans"]) and torch.equal(o["final_labels"], p["final_labels"])
     pairs = _ragged_pairs((2100, 2600, 2222), 31, inlier_ratio=0.3)
     with torch.no_grad():
@@ -1848,6 +1849,29 @@ def test_forwards_in_flight_reproduce_the_plain_calls():
     for r in got:
         assert torch.equal(r["final_trans"], want["final_trans"])
         assert all(torch.equal(a, b) for a, b in zip(r["final_labels"], want["final_labels"]))
+
+
+def test_replayed_hipgraph_forwards_reproduce_the_plain_calls():
+    """InFlight(graphs=True) on the launch-bound shape it exists for (one pair of N = 1000 per forward, bench.py's n1000_b1): every
+    slot's forward is captured once and replayed; 4 forwards in flight, 400 replays over 8 different pairs, each bit-identical to
+    the plain call (static per-slot inputs are overwritten between replays, outputs come back as copies)."""
+    from pointdsc_amd.pipeline import InFlight
+    model, _ = _bench_model("n1000_b1")
+    datas, plain = [], []
+    for i in range(8):
+        b = workloads.batch("n1000_b1", i, 1)
+        d = {k: g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+        d["testing"] = True
+        datas.append(d)
+        plain.append(_forward(model, b))
+    gr = InFlight(model, depth=4, graphs=True)
+    outs = [gr(datas[i % 8]) for i in range(400)]
+    gr.synchronize()
+    assert gr.graphs and len(gr._captured) == 4, "hipGraph capture fell back to the eager path"
+    bad = [i for i, o in enumerate(outs) if not (torch.equal(o["final_trans"], plain[i % 8]["final_trans"]) and
+                                                 torch.equal(o["final_labels"], plain[i % 8]["final_labels"]))]
+    assert not bad, f"replayed forwards differing from the plain call: {bad[:10]} of {len(outs)}"
+    gr.close()
 
 
 def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():

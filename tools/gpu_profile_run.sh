@@ -56,5 +56,11 @@ if [ -z "$QUICK" ]; then
   timeout 200 python tools/overlap_probe.py --n 5000 --bs 32 --steps 40 > "$OUT/${TAG}_overlap_probe.txt" 2>&1
   timeout 200 python tools/overlap_probe.py --n 5000 --bs 4 --steps 200 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1
   timeout 200 python tools/overlap_probe.py --n 1000 --bs 1 --steps 500 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1
+  # forwards in flight against the plain calls, bit for bit (product library): plain streams / tail streams / replayed graphs
+  ( PROBE_REPS=1500 PROBE_MODE=plain PROBE_B=2 timeout 200 python tools/inflight_diverge_probe.py | tail -2
+    PROBE_REPS=1500 PROBE_MODE=tail PROBE_B=3 timeout 200 python tools/inflight_diverge_probe.py | tail -2
+    PROBE_REPS=1500 PROBE_MODE=graphs PROBE_B=3 timeout 200 python tools/inflight_diverge_probe.py | tail -2
+    PROBE_REPS=1500 PROBE_MODE=graphs PROBE_B=2 timeout 200 python tools/inflight_diverge_probe.py | tail -2
+    PROBE_REPS=2500 PROBE_MODE=graphs PROBE_CONFIG=n1000_b1 PROBE_B=1 timeout 200 python tools/inflight_diverge_probe.py | tail -2 ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_inflight_exactness.txt"
 fi
 ls -la "$OUT" | grep "${TAG}_" | tail -60
