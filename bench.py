@@ -395,7 +395,7 @@ def main():
         "roofline": roof,
         # H3 kernel: algorithmic HBM bytes per launch / its duration against 8 TB/s; otherwise matrix-pipe issue cycles the
         # launch needs per SIMD / its duration, against a pipe that is busy every cycle at the maximum clock
-        "roofline_layer": ({"kernel": "layer_h3_kernel", "bound": "hbm",
+        "roofline_layer": ({"kernel": "layer_h3_coop_kernel" if lib.pdsc_layer_h3_uses_coop(B, N) else "layer_h3_kernel", "bound": "hbm",
                             "achieved": None if lay_gbs is None else round(lay_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": None if lay_gbs is None else round(lay_gbs / PEAK_HBM_GBS, 4),
                             "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 4
+#define PDSC_VERSION 5
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32
@@ -63,7 +63,8 @@ typedef struct pdsc_config {
 
 /* Arithmetic of the point-wise GEMMs whose results land on the residual stream (fc1..fc3 of fc_message, PointCN;
  * models/PointDSC.py:12-23,56-61) inside the fused layer kernel (split-precision attention modes).  H3 runs on
- * layer_h3_kernel at every size; F32 on layer_wave_kernel, or on the workgroup-per-tile kernel for small problems
+ * layer_h3_kernel, or on the bit-identical layer_h3_coop_kernel for launches of at most 2560 tiles
+ * (pdsc_layer_h3_uses_coop(bs, N) == 1); F32 on layer_wave_kernel, or on the workgroup-per-tile kernel for small problems
  * (pdsc_layer_prefers_block(bs, N) == 1):
  *   F32: v_mfma_f32_32x32x2_f32, exact fp32 products (600 MFMAs x 64 matrix-pipe cycles per 32-point tile).
  *   H3 : every fp32 operand as fp16 hi + fp16 lo' (lo' = (x - hi) * 2048), product = hi*hi + (hi*lo' + lo'*hi) / 2048 on
@@ -243,6 +244,8 @@ int pdsc_layer_fused_x3(const float* msg, const float* part_o, const float* part
 #define PDSC_WS_FRAG_TAIL_H3 102   /* the same streams built with gemm_format = PDSC_LAYER_GEMM_H3 */
 #define PDSC_WS_FRAG_HEAD_H3 103
 int pdsc_layer_prefers_block(int bs, int N);   /* 1: with layer_gemm = F32, pdsc_forward_* takes the workgroup-per-tile kernel for this size */
+int pdsc_layer_h3_uses_coop(int bs, int N);    /* 1: with layer_gemm = H3, a launch over bs x N points takes layer_h3_coop_kernel (four
+                                                * wavefronts per 32-point tile: at most 2560 tiles), 0: layer_h3_kernel */
 size_t pdsc_wfrag_tail_bytes(void);
 size_t pdsc_wfrag_head_bytes(void);
 int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,

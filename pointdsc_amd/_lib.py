@@ -60,6 +60,7 @@ SIGNATURES = {
     "pdsc_wsplit_build": (_i, [_cfgp, _vp, _vp, _vp]),
     "pdsc_layer_fused_x3": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 17 + [_i, _i, _vp]),
     "pdsc_layer_prefers_block": (_i, [_i, _i]),
+    "pdsc_layer_h3_uses_coop": (_i, [_i, _i]),
     "pdsc_wfrag_tail_bytes": (_sz, []),
     "pdsc_wfrag_head_bytes": (_sz, []),
     "pdsc_wfrag_build_tail": (_i, [_vp] * 8),
@@ -139,7 +140,7 @@ def load() -> C.CDLL:
             raise PointDSCLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.pdsc_version() != 4:
+    if lib.pdsc_version() != 5:
         raise PointDSCLibraryError(f"unexpected library version {lib.pdsc_version()}")
     _lib = lib
     return lib

@@ -451,6 +451,15 @@ using namespace pdsc;
 
 extern long long* pdsc_layer_trace_buffer(void);
 
+extern "C" int pdsc_layer_h3_uses_coop(int bs, int N) {
+    if (bs <= 0 || N <= 0) return 0;
+    int coop_tiles = PDSC_H3_COOP_TILES;
+#ifdef PDSC_EXPERIMENTS
+    coop_tiles = env_int("PDSC_LAYER_H3_COOP", coop_tiles);
+#endif
+    return (long long)bs * ceil_div(N, 32) <= coop_tiles ? 1 : 0;
+}
+
 extern "C" int pdsc_layer_fused_frag_io(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
                                         const float* res, const float* feat_in, float* feat_out, float* featB_out,
                                         void* q_split, void* kv_tiles, const void* wfrag_tail, const void* wfrag_head,
