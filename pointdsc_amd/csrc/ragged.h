@@ -15,6 +15,8 @@ int launch_nms_keys_grid(const float* src, const float* conf, float radius, floa
 int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st);
 int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
                      const int* nvalid, hipStream_t st);
+int launch_score_hypotheses_slp(const float* seed_trans, const float* src, const float* tgt, float thr2, int* counts, int bs, int N, int S,
+                                const int* nvalid, hipStream_t st);      // score_slp.hip (experiments builds)
 float*& score_debug_slot();      // score.hip (experiments builds: diagnostics of the next scoring launch)
 int launch_score_hypotheses(const float* seed_trans, const float* src, const float* tgt, float inlier_threshold, int* counts, int bs,
                             int N, int S, const int* nvalid, hipStream_t st);

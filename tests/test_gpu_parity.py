@@ -1874,6 +1874,31 @@ def test_replayed_hipgraph_forwards_reproduce_the_plain_calls():
     gr.close()
 
 
+@pytest.mark.parametrize("mode", ["plain streams", "tail streams", "hipGraphs"])
+def test_forwards_in_flight_stay_exact_under_load(mode):
+    """Regression test of r03's exactness findings: batches of 2 pairs of N = 5000 kept in flight -- the shape on
+    which the old scoring stage (hipMemsetAsync + atomics; compiler-paired packed-fp32 inlier test) lost votes on 0.2-35 % of the
+    forwards depending on the mode -- 600 forwards per mode, every one bit-identical to the plain call on the same batch."""
+    from pointdsc_amd.pipeline import InFlight
+    model, _ = _bench_model("n5000_b32")
+    datas, plain = [], []
+    for i in range(4):
+        b = workloads.batch("n5000_b32", 2 * i, 2)
+        d = {k: g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+        d["testing"] = True
+        datas.append(d)
+        plain.append(_forward(model, b))
+    runner = InFlight(model, depth=3, graphs=True) if mode == "hipGraphs" else InFlight(model, depth=2, tail_streams=(mode == "tail streams"))
+    bad = 0
+    for rep in range(150):
+        outs = [runner(d) for d in datas]
+        runner.synchronize()
+        bad += sum(not (torch.equal(o["final_trans"], p["final_trans"]) and torch.equal(o["final_labels"], p["final_labels"]))
+                   for o, p in zip(outs, plain))
+    runner.close()
+    assert bad == 0, f"{bad} of 600 forwards in flight ({mode}) differ from the plain call"
+
+
 def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():
     """layer_gemm = "h3" carries the operands of the fc_message / PointCN GEMMs as fp16 hi + lo (|x| < 65504).  A checkpoint whose
     folded weights or activations leave that range must not produce inf / NaN silently: the module checks the packed weights
