@@ -18,6 +18,7 @@ export TMPDIR=/tmp
 cd "$ROOT"
 CONFIGS="n5000_b32 n1000_b1 kitti_n5000_b16 lomatch_n10000_b8"
 timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40 > "$OUT/${TAG}_pytest_gpu.txt"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -5 > "$OUT/${TAG}_smoke.txt"
 if [ -z "$QUICK" ]; then
   # PMC first: the bench lines below quote the HBM traffic of THIS build (profiles/traffic.json is regenerated from the summary)
   bash "$ROOT/tools/gpu_pmc_run.sh" ${TAG}_pmc --in-flight 1 --settle-seconds 0 > /dev/null 2>&1

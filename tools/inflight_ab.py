@@ -34,7 +34,9 @@ data["testing"] = True
 runners = {"one stream": InFlight(model, depth=1),
            "2 in flight": InFlight(model, depth=2, tail_streams=False),
            "2 in flight + high-priority tail streams": InFlight(model, depth=2, tail_streams=True),
-           "3 in flight": InFlight(model, depth=3, tail_streams=False)}
+           "3 in flight": InFlight(model, depth=3, tail_streams=False),
+           "3 in flight + high-priority tail streams": InFlight(model, depth=3, tail_streams=True),
+           "4 in flight": InFlight(model, depth=4, tail_streams=False)}
 ref = None
 times = {k: [] for k in runners}
 for name, r in runners.items():
