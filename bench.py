@@ -342,7 +342,7 @@ def main():
     # with the H3 GEMMs (model.layer_gemm = "h3", wavefront-resident kernel) the launch needs 16 k matrix-pipe cycles per tile
     # and is bound by HBM: per point it reads the key-split partials (ns x (512 + 8) B) and the residual row (512 B) and
     # writes featB (512 B), the Q rows (512 B) and its share of the K/V tile image (32 KiB / 32)
-    lay_h3 = (not fp32_att(args)) and model.layer_gemm == "h3" and not lib.pdsc_layer_prefers_block(B, N)
+    lay_h3 = (not fp32_att(args)) and model.layer_gemm == "h3"      # (since r03 the H3 arithmetic has its own kernels at every size)
     lay_ns = int(lib.pdsc_attention_split_default_split(B, N))
     lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 32768 / 32.0) * N * B
     lay_gbs = lay_bytes / lay_avg / 1e9 if lay_n else None

@@ -35,7 +35,7 @@ __device__ __forceinline__ float residual_sq(const float* __restrict__ T, float 
 //     forwards in flight the memset was not reliably ordered before the atomics that followed it on the same stream (counters
 //     far off on 16-35 % of replayed hipGraph forwards, and now and then on eager multi-stream forwards): no memset, no atomics,
 //     no partial counts any more (launch_fill_u32 replaces the library's other hipMemsetAsync calls);
-//   * THIS FILE IS COMPILED WITH -fno-slp-vectorize (pointdsc_amd/build.py).  The SLP vectoriser pairs the residual tests of
+//   * score.hip IS COMPILED WITH -fno-slp-vectorize (pointdsc_amd/build.py).  The SLP vectoriser pairs the residual tests of
 //     two seeds into packed fp32 instructions (v_pk_mul/fma/add_f32 with op_sel broadcasts of the just-loaded point); in that
 //     form one half of the seed pairs came out a few votes short on 0.2-0.7 % of the forwards whenever kernels of other forwards
 //     were co-resident -- transforms and points verified equal, a recount later in the same launch right, the affected half
