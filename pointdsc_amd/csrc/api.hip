@@ -388,9 +388,9 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const char* var = env_str("PDSC_LAYER_VARIANT");          // (experiments builds) b / w: force the workgroup-per-tile / wavefront kernel
         // arithmetic of fc1..fc3 / PointCN (enum pdsc_layer_gemm); A/B knob PDSC_LAYER_GEMM = 0 / 1 overrides
         const int gemm = env_int("PDSC_LAYER_GEMM", cfg->layer_gemm) == PDSC_LAYER_GEMM_H3 ? PDSC_LAYER_GEMM_H3 : PDSC_LAYER_GEMM_F32;
-        // Which layer kernel.  H3 GEMMs: always the wavefront-resident layer_h3_kernel -- since r03 its small-launch shape (one
-        // wavefront per workgroup, four weight chunks in flight) also wins where the tiles leave CUs empty (N = 1000 x 1: 0.511 vs
-        // 0.557 ms per forward, N = 5000 x 1: 0.993 vs 1.034, profiles/r03_b_ab_*.txt).  fp32 GEMMs: layer_wave_kernel, or the
+        // Which layer kernel.  H3 GEMMs: layer_h3_kernel, or the bit-identical layer_h3_coop_kernel for launches of at most 2560
+        // tiles (launch_layer_h3 decides) -- never the fp32 kernels: N = 1000 x 1 0.384 ms per forward against 0.557 with the
+        // workgroup-per-tile fp32 kernel (profiles/r03_b_ab_*.txt, r03_k_ab_coop.txt).  fp32 GEMMs: layer_wave_kernel, or the
         // workgroup-per-tile kernel of layer.hip for small problems (pdsc_layer_prefers_block).
         const bool small = pdsc_layer_prefers_block(bs, N) && gemm != PDSC_LAYER_GEMM_H3;
         const bool block_layer = !x3_gemm && ((var && var[0] == 'b') || (!(var && var[0] == 'w') && small));

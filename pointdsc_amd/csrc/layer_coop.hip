@@ -1,4 +1,4 @@
-// a-2 fused layer, small-launch form: FOUR wavefronts per 32-point tile (layer_h3.hip has one).
+// a-2 fused layer for launches of at most PDSC_H3_COOP_TILES tiles: FOUR wavefronts per 32-point tile (layer_h3.hip has one).
 //   tail of layer i   : feat  = featB + fc3( relu(fc2'( relu(fc1'(msg)) )) )         (reference models/PointDSC.py:43-45)
 //   head of layer i+1 : featB = relu(pcn'(feat)) ; (q|k|v) = Wqkv featB + b            (models/PointDSC.py:75, :36-38)
 // With few tiles (N = 1000 x 1: 32 tiles on 256 CUs) a launch of layer_h3_kernel is ONE wavefront's dependency chain: 42
