@@ -58,6 +58,15 @@ __global__ void fill_u32_kernel(unsigned int* p, unsigned int value, size_t coun
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) p[i] = value;
 }
+__global__ void copy_u32_kernel(unsigned int* __restrict__ dst, const unsigned int* __restrict__ src, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int launch_copy_u32(unsigned int* dst, const unsigned int* src, size_t count, hipStream_t st) {
+    if (count == 0) return PDSC_OK;
+    const size_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(copy_u32_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, dst, src, count);
+    return check_launch("copy");
+}
 int launch_fill_u32(unsigned int* p, unsigned int value, size_t count, hipStream_t st) {
     if (count == 0) return PDSC_OK;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, p, value, count);
@@ -540,8 +549,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,
                                   bs, N, S, stream));
-        if (hipMemcpyAsync(final_labels, conf, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-            return check_launch("pdsc_forward_validation(copy logits)");
+        PDSC_TRY(launch_copy_u32((unsigned int*)final_labels, (const unsigned int*)conf, (size_t)M, (hipStream_t)stream));
     }
     if (tail_stream) {       // join: whatever the caller enqueues on the main stream next is ordered after the results
         if (hipEventRecord((hipEvent_t)ev_join, (hipStream_t)tail_stream) != hipSuccess ||

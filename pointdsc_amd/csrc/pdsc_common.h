@@ -31,6 +31,7 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 // flight, and above all inside replayed hipGraphs, the zeroing of the hypothesis counters was not reliably ordered before the
 // scoring kernel's atomicAdds that follow it on the same stream; a kernel node is)
 int launch_fill_u32(unsigned int* p, unsigned int value, size_t count, hipStream_t st);
+int launch_copy_u32(unsigned int* dst, const unsigned int* src, size_t count, hipStream_t st);      // dst[i] = src[i], likewise a kernel
 
 // opt-in event timing of the roofline kernels (api.hip); no-ops unless pdsc_profile_enable() was called
 void profile_mark_begin(int kind, hipStream_t st);

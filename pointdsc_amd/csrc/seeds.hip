@@ -506,8 +506,7 @@ extern "C" int pdsc_nms_keys(const float* src, const float* conf, float radius, 
     const float radius2 = nms_radius2_fwd(radius);
     {
         hipStream_t st = (hipStream_t)stream;
-        if (hipMemcpyAsync(keys, conf, (size_t)bs * N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return pdsc::check_launch("pdsc_nms_keys(copy)");
+        if (const int rc = pdsc::launch_copy_u32((unsigned int*)keys, (const unsigned int*)conf, (size_t)bs * N, st); rc != PDSC_OK) return rc;
         const int row_blocks = pdsc::ceil_div(N, pdsc::NMS2_ROWS);
         int splits = pdsc::ceil_div(1024, row_blocks * bs);             // ~1024 workgroups
         const int min_splits = pdsc::ceil_div(N, pdsc::NMS2_MAX_SLICE);
