@@ -408,7 +408,10 @@ int pdsc_forward_testing(const pdsc_config* cfg, const float* wpack, const void*
  *   num_corr           [bs] int32, DEVICE: correspondences of pair b (2 <= num_corr[b] <= N)
  *   num_seeds_per_pair [bs] int32, DEVICE: int(num_corr[b] * ratio) >= 1, computed by the caller in double precision (:174)
  *   num_seeds          = max_b num_seeds_per_pair[b],   n_min = min_b num_corr[b] (host copies; n_min must leave every pair
- *                        at least one 32-key tile per attention key split: ceil(n_min / 32) >= pdsc_attention_split_default_split(bs, N))
+ *                        at least one 32-key tile per attention key split: ceil(n_min / 32) >= pdsc_attention_split_default_split(bs, N),
+ *                        and n_min > min(cfg->k, N - 1): the reference clamps k per pair, k = min(k, num_corr - 1)
+ *                        (models/PointDSC.py:250), one launch has one k -- a pair of at most k rows is its own call;
+ *                        PDSC_ERR_ARG otherwise)
  * Pair b's results are those of pdsc_forward_testing on its own num_corr[b] rows (same stages on the same data; only the
  * launch plans, i.e. fp32 summation orders, are the batch's): final_trans [bs][16], final_labels [bs][N] with rows
  * >= num_corr[b] zero.  Workspace: pdsc_workspace_bytes(cfg, bs, N, num_seeds).  Split-precision attention modes only. */
@@ -463,6 +466,10 @@ int pdsc_conv_mask_all_pairs(unsigned int* conv_mask, int bs, void* stream);
 size_t pdsc_match_scratch_bytes(int Ns, int Nt);
 int pdsc_match_descriptors(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
                            float* nn_dist, void* scratch, size_t scratch_bytes, void* stream);
+/* the 3DLoMatch caller's form (evaluation/test_3DLoMatch.py:45-46): nn_idx[i] = argmax_j <src_desc_i, tgt_desc_j> (torch.argmax:
+ * first index among equal maxima, NaN counts as the maximum); nn_dot[i] (optional) = that inner product.  Same scratch. */
+int pdsc_match_descriptors_ip(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
+                              float* nn_dot, void* scratch, size_t scratch_bytes, void* stream);
 /* corr[c] = (i, src2tgt[i]) for i ascending; with tgt2src != NULL only the mutual nearest neighbours
  * (tgt2src[src2tgt[i]] == i, ThreeDMatch.py:286-288) are kept.  corr [Ns][2] (capacity), *count = rows written. */
 int pdsc_select_correspondences(const int* src2tgt, const int* tgt2src, int Ns, int* corr, int* count, void* stream);

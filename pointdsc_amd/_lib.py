@@ -102,6 +102,7 @@ SIGNATURES = {
     "pdsc_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pdsc_match_scratch_bytes": (_sz, [_i, _i]),
     "pdsc_match_descriptors": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pdsc_match_descriptors_ip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pdsc_select_correspondences": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "pdsc_build_corr_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pdsc_sm_workspace_bytes": (_sz, [_i, _i]),

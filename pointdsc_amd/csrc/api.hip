@@ -172,7 +172,7 @@ static long long wpack_offset(const pdsc_config* c, int section, int layer) {
 // ---- workspace layout --------------------------------------------------------------------------
 struct WsEntry { const char* name; size_t bytes; size_t offset; };
 struct WsLayout {
-    WsEntry e[32];
+    WsEntry e[40];
     int n = 0;
     size_t total = 0;
     void add(const char* name, size_t bytes) {
@@ -225,6 +225,7 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("best", (size_t)bs * sizeof(int));
     L.add("initial_trans", (size_t)bs * 16 * f);
     L.add("solves", (size_t)bs * sizeof(int));
+    L.add("refine_trace", (size_t)bs * PDSC_REFINE_TRACE * sizeof(int));      // inlier count per refinement iteration, -1 padded (parity census)
 #ifdef PDSC_EXPERIMENTS
     L.add("score_dbg", (size_t)bs * S * 16 * f);        // diagnostics of the scoring kernel (score.hip, DBG)
 #endif
@@ -336,6 +337,11 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_REQUIRE(cfg->attention_precision != PDSC_ATT_FP32, "pdsc_forward_testing_ragged: needs a split-precision attention mode "
                      "(the exact-fp32 attention kernel takes one N per launch)");
         PDSC_REQUIRE(n_min >= 2 && n_min <= N, "pdsc_forward_testing_ragged: n_min=%d (N=%d)", n_min, N);
+        // one launch has one neighbour count k = min(cfg->k, N - 1); the reference clamps per pair, k_b = min(k, num_corr_b - 1)
+        // (models/PointDSC.py:250): a pair with fewer than k + 1 correspondences must be its own call
+        PDSC_REQUIRE(n_min > (cfg->k < N - 1 ? cfg->k : N - 1), "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has no "
+                     "more than k=%d: the reference clamps k per pair (k = min(k, num_corr - 1)); run such a pair in its own call",
+                     n_min, cfg->k < N - 1 ? cfg->k : N - 1);
         PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
                      "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
                      "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
@@ -544,7 +550,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     if (mode == 0) {
         PDSC_TRY(launch_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S, nvalid, hst));
         // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
-        PDSC_TRY(launch_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N, nvalid, hst));
+        PDSC_TRY(launch_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N, nvalid, hst, I("refine_trace")));
     } else {
         // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,

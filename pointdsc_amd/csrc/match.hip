@@ -24,7 +24,21 @@ __device__ __forceinline__ unsigned long long match_key(float dist, int idx) {
     return ((unsigned long long)bits << 32) | (unsigned int)idx;
 }
 
+// MODE 1 (evaluation/test_3DLoMatch.py:45-46): source_idx = argmax_j <src_i, tgt_j> -- torch.argmax: first index among equal
+// maxima, NaN counts as the maximum.  The key orders LARGER inner products first: bits = ~monotone(dot), NaN -> 0.
+__device__ __forceinline__ unsigned int ip_bits(float dot) {
+    if (dot != dot) return 0u;
+    const unsigned int u = __float_as_uint(dot + 0.0f);                 // -0 -> +0 (equal for argmax)
+    const unsigned int mono = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~mono;                                                        // 0 only for mono = 0xFFFFFFFF, a NaN pattern: reserved for NaN above
+}
+__device__ __forceinline__ float ip_from_bits(unsigned int bits) {
+    const unsigned int mono = ~bits;
+    return __uint_as_float((mono & 0x80000000u) ? (mono & 0x7fffffffu) : ~mono);
+}
+
 // keys[i] = min over the workgroup's target range of match_key(distance(i, j), j)
+template <int MODE>
 __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__ src, const float* __restrict__ tgt, int Ns, int Nt,
                                                        int D, int tgt_per_split, unsigned long long* __restrict__ keys) {
     constexpr int KP = MT_MAXD;                      // descriptor columns held (zero padded)
@@ -49,7 +63,7 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
             }
         }
     }
-    float best = INFINITY;
+    float best = MODE == 0 ? INFINITY : -INFINITY;
     int best_j = 0x7fffffff;
     bool best_nan = false;
 
@@ -78,20 +92,23 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float d = sqrtf((2.0f - 2.0f * acc[r]) + 1e-6f);          // reference arithmetic, fp32
+                const float d = MODE == 0 ? sqrtf((2.0f - 2.0f * acc[r]) + 1e-6f) : acc[r];          // reference arithmetic, fp32
                 const bool dn = d != d;
-                const bool take = j < j_end && !best_nan && (dn || d < best || (d == best && j < best_j));
+                const bool better = MODE == 0 ? d < best : d > best;
+                const bool take = j < j_end && !best_nan && (dn || better || (d == best && j < best_j));
                 if (take) { best = d; best_j = j; best_nan = dn; }
             }
         }
     }
     // merge the two halves of the targets, then the splits
-    unsigned long long key = match_key(best_nan ? NAN : best, best_j);
+    unsigned long long key = MODE == 0 ? match_key(best_nan ? NAN : best, best_j)
+                                       : (((unsigned long long)ip_bits(best_nan ? NAN : best) << 32) | (unsigned int)best_j);
     const unsigned long long other = __shfl_xor(key, 32, 64);
     key = other < key ? other : key;
     if (h == 0 && s0 + l31 < Ns && best_j != 0x7fffffff) atomicMin(keys + s0 + l31, key);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void match_decode_kernel(const unsigned long long* __restrict__ keys, int* __restrict__ idx,
                                                            float* __restrict__ dist, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -100,7 +117,8 @@ __global__ __launch_bounds__(256) void match_decode_kernel(const unsigned long l
     idx[i] = (int)(unsigned int)(k & 0xffffffffu);
     if (dist) {
         const unsigned int bits = (unsigned int)(k >> 32);
-        dist[i] = bits == 0u ? NAN : __uint_as_float(bits);      // bits 0 <=> NaN distance (a true 0 cannot occur: + 1e-6)
+        if (MODE == 0) dist[i] = bits == 0u ? NAN : __uint_as_float(bits);      // bits 0 <=> NaN distance (a true 0 cannot occur: + 1e-6)
+        else dist[i] = bits == 0u ? NAN : ip_from_bits(bits);
     }
 }
 
@@ -196,8 +214,8 @@ extern "C" size_t pdsc_match_scratch_bytes(int Ns, int Nt) {
     return (size_t)(Ns > Nt ? Ns : Nt) * sizeof(unsigned long long);
 }
 
-extern "C" int pdsc_match_descriptors(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
-                                      float* nn_dist, void* scratch, size_t scratch_bytes, void* stream) {
+static int match_launch(int mode, const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
+                        float* nn_dist, void* scratch, size_t scratch_bytes, void* stream) {
     PDSC_REQUIRE(src_desc && tgt_desc && nn_idx && scratch, "pdsc_match_descriptors: null pointer");
     PDSC_REQUIRE(Ns > 0 && Nt > 0 && D >= 1 && D <= MT_MAXD, "pdsc_match_descriptors: Ns=%d Nt=%d D=%d (D <= %d)", Ns, Nt, D, MT_MAXD);
     if (scratch_bytes < (size_t)Ns * sizeof(unsigned long long)) {
@@ -214,11 +232,24 @@ extern "C" int pdsc_match_descriptors(const float* src_desc, const float* tgt_de
     if (splits > max_splits) splits = max_splits;
     const int per = ceil_div(ceil_div(Nt, splits), MT_TGT) * MT_TGT;
     splits = ceil_div(Nt, per);
-    hipLaunchKernelGGL(match_nn_kernel, dim3(src_blocks, splits), dim3(256), 0, st, src_desc, tgt_desc, Ns, Nt, D, per, keys);
+    if (mode == 0) hipLaunchKernelGGL(match_nn_kernel<0>, dim3(src_blocks, splits), dim3(256), 0, st, src_desc, tgt_desc, Ns, Nt, D, per, keys);
+    else hipLaunchKernelGGL(match_nn_kernel<1>, dim3(src_blocks, splits), dim3(256), 0, st, src_desc, tgt_desc, Ns, Nt, D, per, keys);
     int rc = check_launch("pdsc_match_descriptors");
     if (rc != PDSC_OK) return rc;
-    hipLaunchKernelGGL(match_decode_kernel, dim3(ceil_div(Ns, 256)), dim3(256), 0, st, keys, nn_idx, nn_dist, Ns);
+    if (mode == 0) hipLaunchKernelGGL(match_decode_kernel<0>, dim3(ceil_div(Ns, 256)), dim3(256), 0, st, keys, nn_idx, nn_dist, Ns);
+    else hipLaunchKernelGGL(match_decode_kernel<1>, dim3(ceil_div(Ns, 256)), dim3(256), 0, st, keys, nn_idx, nn_dist, Ns);
     return check_launch("pdsc_match_descriptors(decode)");
+}
+
+extern "C" int pdsc_match_descriptors(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
+                                      float* nn_dist, void* scratch, size_t scratch_bytes, void* stream) {
+    return match_launch(0, src_desc, tgt_desc, Ns, Nt, D, nn_idx, nn_dist, scratch, scratch_bytes, stream);
+}
+
+// evaluation/test_3DLoMatch.py:45-46: dists = einsum('ac,bc->ab', src_feats, tgt_feats); source_idx = argmax(dists, -1)
+extern "C" int pdsc_match_descriptors_ip(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
+                                         float* nn_dot, void* scratch, size_t scratch_bytes, void* stream) {
+    return match_launch(1, src_desc, tgt_desc, Ns, Nt, D, nn_idx, nn_dot, scratch, scratch_bytes, stream);
 }
 
 extern "C" int pdsc_select_correspondences(const int* src2tgt, const int* tgt2src, int Ns, int* corr, int* count, void* stream) {

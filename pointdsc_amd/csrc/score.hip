@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict
 __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ initial_trans, const float* __restrict__ src,
                                                       const float* __restrict__ tgt, float thr, int max_iters,
                                                       float* __restrict__ final_trans, int* __restrict__ solves, int NS,
-                                                      const int* __restrict__ nvalid) {
+                                                      const int* __restrict__ nvalid, int* __restrict__ trace) {
     __shared__ float red[8 * 9];
     __shared__ float Tc[16];
     const int t = threadIdx.x, b = blockIdx.x;
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ i
     const float* srcb = src + (size_t)b * NS * 3;
     const float* tgtb = tgt + (size_t)b * NS * 3;
     if (t < 16) Tc[t] = initial_trans[(size_t)b * 16 + t];
+    // trace (optional) [bs][PDSC_REFINE_TRACE]: the inlier count of every iteration evaluated (models/PointDSC.py:424-425), -1 after
+    // the last one -- the discrete part of the loop, compared by the parity census with the reference's own sequence
+    if (trace && t < PDSC_REFINE_TRACE) trace[(size_t)b * PDSC_REFINE_TRACE + t] = -1;
     __syncthreads();
     int prev = 0, solved = 0;
     for (int it = 0; it < max_iters; ++it) {
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ i
         }
         block_sum<8, 8>(acc, red);
         const int n_inl = (int)acc[0];                              // exact: counts < 2^24
+        if (trace && t == 0 && it < PDSC_REFINE_TRACE) trace[(size_t)b * PDSC_REFINE_TRACE + it] = n_inl;
         if (n_inl == prev) break;                                   // abs(int(inlier_num - previous)) < 1
         prev = n_inl;
         const float den = acc[1] + 1e-6f;
@@ -154,10 +158,10 @@ int launch_select_best(const int* counts, const float* seed_trans, const float* 
 }
 
 int launch_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold, int max_iters,
-                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st) {
+                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st, int* trace) {
     PDSC_REQUIRE(initial_trans && src && tgt && final_trans, "pdsc_post_refinement: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && max_iters >= 0, "pdsc_post_refinement: bs=%d N=%d iters=%d", bs, N, max_iters);
-    hipLaunchKernelGGL(refine_kernel, dim3(bs), dim3(512), 0, st, initial_trans, src, tgt, threshold, max_iters, final_trans, solves, N, nvalid);
+    hipLaunchKernelGGL(refine_kernel, dim3(bs), dim3(512), 0, st, initial_trans, src, tgt, threshold, max_iters, final_trans, solves, N, nvalid, trace);
     return check_launch("pdsc_post_refinement");
 }
 
@@ -175,5 +179,5 @@ extern "C" int pdsc_select_best(const int* counts, const float* seed_trans, cons
 
 extern "C" int pdsc_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold,
                                     int max_iters, float* final_trans, int* solves, int bs, int N, void* stream) {
-    return pdsc::launch_post_refinement(initial_trans, src, tgt, threshold, max_iters, final_trans, solves, bs, N, nullptr, (hipStream_t)stream);
+    return pdsc::launch_post_refinement(initial_trans, src, tgt, threshold, max_iters, final_trans, solves, bs, N, nullptr, (hipStream_t)stream, nullptr);
 }

@@ -278,7 +278,8 @@ extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, 
     int rc = check_launch("pdsc_sm_baseline(matrix)");
     if (rc != PDSC_OK) return rc;
     // v0 = 1 (bit pattern of 1.0f)
-    if (hipMemsetD32Async((hipDeviceptr_t)va, 0x3f800000, (size_t)bs * N, st) != hipSuccess) return check_launch("pdsc_sm_baseline(ones)");
+    rc = launch_fill_u32((unsigned int*)va, 0x3f800000u, (size_t)bs * N, st);      // a kernel, like every other fill of the library (no hipMemsetAsync)
+    if (rc != PDSC_OK) return rc;
     rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sm_matvec_kernel), 160 * 1024 - 64, "pdsc_sm_baseline(dynamic LDS)");
     if (rc != PDSC_OK) return rc;
     const int nblocks = ceil_div(N, SMV_ROWS);

@@ -332,7 +332,12 @@ class PointDSC(nn.Module):
         """Index groups that can share a launch: the attention's key split (planned from the group's size and its longest pair)
         must leave the group's shortest pair at least one 32-key tile per split.  Greedy over the pairs sorted by size."""
         lib = _lib.load()
-        order = sorted(range(len(counts)), key=lambda i: -counts[i])
+        # a pair with no more than k correspondences takes the reference's per-pair clamp k = min(k, num_corr - 1)
+        # (models/PointDSC.py:250): one launch has one k, so such a pair runs as its own (uniform) call
+        small = [[i] for i in range(len(counts)) if counts[i] <= self.k]
+        order = sorted((i for i in range(len(counts)) if counts[i] > self.k), key=lambda i: -counts[i])
+        if not order:
+            return small
         groups, cur = [], []
         for i in order:
             trial = cur + [i]
@@ -349,7 +354,7 @@ class PointDSC(nn.Module):
             while len(g) > 1 and (counts[g[-1]] + 31) // 32 < int(lib.pdsc_attention_split_default_split(len(g), counts[g[0]])):
                 out.append([g.pop()])
             out.append(g)
-        return out
+        return out + small
 
     def _run(self, corr_pos, src_keypts, tgt_keypts, testing, counts=None):
         lib = _lib.load()
@@ -361,7 +366,7 @@ class PointDSC(nn.Module):
             if self.attention_precision == "fp32":
                 raise NotImplementedError('ragged batches need a split-precision attention mode (attention_precision = "bf16x3")')
             groups = self._ragged_groups(counts)
-            if len(groups) > 1:                       # too heterogeneous for one launch plan: one call per group of similar sizes
+            if len(groups) > 1 or min(counts) <= self.k:      # too heterogeneous for one launch plan (or pairs of at most k rows): one call per group
                 final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
                 final_labels = torch.zeros(bs, n, device=dev, dtype=torch.float32)
                 for g in groups:

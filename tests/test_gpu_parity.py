@@ -1535,6 +1535,37 @@ def test_build_correspondences_matches_reference_golden(name):
     assert np.array_equal(res["tgt_keypts"][0].cpu().numpy(), tkp[fx["ref_corr"][:, 1]])
 
 
+@pytest.mark.parametrize("name", ["corr_lomatch_n1000_d32", "corr_lomatch_n5000_d32"])
+def test_inner_product_matching_matches_the_3dlomatch_callers_lines(name):
+    """metric="ip": argmax of the inner products, the form of evaluation/test_3DLoMatch.py:45-48 (fixture: those four reference
+    lines executed on seeded NON-unit descriptors, oracle/check_lomatch_matching_against_reference.py -- on most rows the
+    arg-min of sqrt(2 - 2<s,t> + 1e-6) picks another target there).  Index work: exact; corr_pos to the rounding of the mean."""
+    from oracle.check_lomatch_matching_against_reference import make_inputs
+    from pointdsc_amd import correspondences
+    fx = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    src, tgt, skp, tkp = make_inputs(dict(ns=int(fx["ns"]), nt=int(fx["nt"]), d=int(fx["d"]), seed=int(fx["seed"])))
+    idx, dot = correspondences.match_descriptors(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), want_dist=True, metric="ip")
+    assert np.array_equal(idx.cpu().numpy(), fx["ref_source_idx"])
+    assert np.abs(dot.cpu().numpy() - fx["ref_best_dot"]).max() < 4e-6
+    l2 = correspondences.match_descriptors(g(torch.from_numpy(src)), g(torch.from_numpy(tgt))).cpu().numpy()
+    assert (l2 != fx["ref_source_idx"]).sum() > 100           # the two callers' forms really differ on this input
+    res = correspondences.build_correspondences(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), g(torch.from_numpy(skp)),
+                                                g(torch.from_numpy(tkp)), metric="ip")
+    assert np.array_equal(res["corr"].cpu().numpy()[:, 1], fx["ref_source_idx"])
+    assert np.abs(res["corr_pos"][0].cpu().numpy() - fx["ref_corr_pos"]).max() < 1e-5
+    assert np.array_equal(res["tgt_keypts"][0].cpu().numpy(), tkp[fx["ref_source_idx"]])
+    # torch.argmax semantics on special values: first index among equal maxima, NaN counts as the maximum
+    s = torch.zeros(3, 8); t = torch.zeros(5, 8)
+    s[0, 0] = 1.0; s[1, 1] = -1.0; s[2, 2] = 1.0
+    t[1, 0] = 2.0; t[3, 0] = 2.0; t[4, 1] = 1.0                    # row 0: tie between targets 1 and 3 -> 1; row 1: all <= 0; row 2: all zero -> 0
+    for with_nan in (False, True):
+        if with_nan:
+            t[2, 2] = float("nan")                                 # 0 * NaN = NaN: target 2 is NaN for every row -> index 2 everywhere
+        want = torch.argmax(torch.einsum("ac,bc->ab", s, t), dim=-1).numpy()
+        got = correspondences.match_descriptors(g(s), g(t), metric="ip").cpu().numpy()
+        assert np.array_equal(got, want), (with_nan, got, want)
+
+
 def test_match_descriptors_ties_and_ragged_sizes():
     """Equal distances -> the first index (np.argmin); sizes that are not multiples of any tile; D not a multiple of 8."""
     from oracle import correspondence_oracle as CO

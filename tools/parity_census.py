@@ -45,8 +45,107 @@ def judge(trans: torch.Tensor, labels: torch.Tensor, fx, n: int, first: int = 0)
     return ok32 | ok64, d32, torch.where(ok32, d32, torch.minimum(d32, d64)), f32, torch.where(ok32, 0, torch.where(ok64, 1, -1))
 
 
+def decisions(model, bs: int, n: int):
+    """The discrete decisions of the LAST forward, read from its workspace: per pair the seeds (correspondence indices, ranked),
+    their inlier votes, the chosen seed's position and the refinement's inlier count per iteration (-1 padded)."""
+    S = int(n * model.ratio)
+    v = lambda name, cnt: model.workspace_view(name, bs, n, torch.int32)[:cnt].cpu().numpy().copy()
+    k = min(model.k, n - 1)
+    return {"seeds": v("seeds", bs * S).reshape(bs, S), "counts": v("counts", bs * S).reshape(bs, S), "best": v("best", bs),
+            "trace": v("refine_trace", bs * 24).reshape(bs, 24), "knn": v("knn_idx", bs * S * k).reshape(bs, S, k)}
+
+
+def set_hash(idx) -> int:
+    """oracle/make_census_internals.py:set_hash -- 64-bit FNV-1a over the ascending neighbour indices."""
+    h = 0xcbf29ce484222325
+    for b in np.sort(np.asarray(idx, dtype=np.int64)).astype("<i4").tobytes():
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+# A seed's neighbour set is "decided by round-off" when the reference's own gap between the last neighbour kept and the first
+# one left out (distances 2 - 2<f_i,f_j> of unit features, models/common.py:60-68) is below this: 4 x the 5e-6 to which this
+# implementation's features follow the reference's fp32 features (DESIGN.md section 2; the reference's own fp32 and fp64
+# features differ by ~1e-6).  The recorded gap of every excused pair is printed and stored, not just compared.
+KNN_TIE_GAP = 2e-5
+
+
+def knn_tie(dec, ix, i: int, corr: int):
+    """(differs, gap): does the neighbour set of the seed sitting on correspondence `corr` differ between this run and the
+    reference's fp32 run, and what boundary gap did the reference record for that seed."""
+    rp, gp = np.flatnonzero(ix["seeds32"][i] == corr), np.flatnonzero(dec["seeds"] == corr)
+    if len(rp) == 0 or len(gp) == 0 or "knn_hash32" not in ix:
+        return None, None
+    return bool(set_hash(dec["knn"][gp[0]]) != int(ix["knn_hash32"][i][rp[0]])), float(ix["knn_gap32"][i][rp[0]])
+
+
+def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None):
+    """Why pair i may leave BASELINE.json's contract: checked against what the reference itself decided on that pair
+    (tests/golden/census_internals_<name>.npz, oracle/make_census_internals.py).  Returns (excused, text).
+      tie          the GPU chose another hypothesis than the reference (models/PointDSC.py:329 argmax over integer vote counts), the
+                   reference's own votes put the GPU's choice within ONE vote of its maximum and the GPU's votes put the reference's
+                   choice within one vote of the GPU's maximum;
+      refinement   same hypothesis, but the refinement loop (:421-437) leaves the reference's recorded inlier-count sequence, first
+                   by exactly one vote (a correspondence on the threshold of that iteration; the recorded margin is printed);
+      knn-tie      the seed in question carries another hypothesis here than in the reference because its neighbour set (topk over
+                   feature distances, models/common.py:68) differs, and the reference itself recorded that seed's topk boundary gap
+                   below KNN_TIE_GAP: which 40 correspondences vote for the hypothesis is decided by round-off in the reference too;
+      label-edge   same hypothesis, pose inside the contract, and every flipped label belongs to a correspondence whose residual
+                   under the REFERENCE's recorded hypothesis is within 8 fp32 ulps of the coordinate magnitude of the threshold.
+    Anything else is not excused."""
+    seeds_r, counts_r, best_r = ix["seeds32"][i], ix["counts32"][i], int(ix["best32"][i])
+    g_corr, r_corr = int(dec["seeds"][dec["best"]]), int(seeds_r[best_r])
+    if g_corr != r_corr:
+        pos = np.flatnonzero(seeds_r == g_corr)
+        gpos = np.flatnonzero(dec["seeds"] == r_corr)
+        if len(pos) == 0 or len(gpos) == 0:
+            return False, f"hypothesis of correspondence {g_corr} chosen, reference chose {r_corr}; seed sets differ"
+        rc_g, rmax = int(counts_r[pos[0]]), int(counts_r.max())
+        gc_r, gmax = int(dec["counts"][gpos[0]]), int(dec["counts"].max())
+        ok = rc_g >= rmax - 1 and gc_r >= gmax - 1
+        msg = (f"tie: chose the hypothesis of correspondence {g_corr} (reference votes {rc_g} of max {rmax}), reference chose {r_corr} "
+               f"(votes here {gc_r} of max {gmax}); {int((counts_r >= rmax - 1).sum())} reference hypotheses within one vote of its maximum")
+        if not ok:
+            # the votes differ by more than one: legitimate only if one of the two seeds carries ANOTHER hypothesis here than in the
+            # reference because its neighbour set sits on a recorded topk tie
+            for corr in (g_corr, r_corr):
+                differs, gap = knn_tie(dec, ix, i, corr)
+                if differs and gap <= KNN_TIE_GAP:
+                    return True, msg + f"; knn-tie: the neighbour set of seed {corr} differs from the reference's, whose recorded boundary gap is {gap:.1e}"
+                msg += f"; seed {corr}: neighbour set {'differs' if differs else 'equal'}, reference gap {gap if gap is None else format(gap, '.1e')}"
+        return ok, msg
+    tr_r, tr_g = ix["refine_counts32"][i], dec["trace"][:21]
+    if not np.array_equal(tr_r, tr_g):
+        j = int(np.flatnonzero(tr_r != tr_g)[0])
+        a, b = int(tr_g[j]), int(tr_r[j])
+        # (both loops stop on the same rule, so two sequences that agree up to j-1 both have an entry at j)
+        ok = a >= 0 and b >= 0 and abs(a - b) <= 1
+        msg = (f"refinement: same seed, inlier count {a} vs reference {b} at iteration {j} ({tr_g[tr_g >= 0].tolist()} vs "
+               f"{tr_r[tr_r >= 0].tolist()}), reference margin there {float(ix['refine_margin32'][i][j]):.1e}")
+        if not ok:       # more than one vote apart: only if the seed's hypothesis itself is another one here (recorded topk tie)
+            differs, gap = knn_tie(dec, ix, i, g_corr)
+            if differs and gap <= KNN_TIE_GAP:
+                return True, msg + f"; knn-tie: the seed's neighbour set differs from the reference's, whose recorded boundary gap is {gap:.1e}"
+            msg += f"; neighbour set {'differs' if differs else 'equal'}, reference gap {gap if gap is None else format(gap, '.1e')}"
+        return ok, msg
+    differs, gap = knn_tie(dec, ix, i, g_corr)
+    if differs:
+        return gap <= KNN_TIE_GAP, (f"knn-tie: same seed ({g_corr}), same refinement sequence, but its neighbour set differs from the reference's, "
+                                    f"whose recorded boundary gap is {gap:.1e} (allowed {KNN_TIE_GAP:.0e})")
+    if flipped is not None and len(flipped) and batch_row is not None:
+        T = ix["initial_trans32"][i]
+        src, tgt = batch_row["src_keypts"].double().numpy(), batch_row["tgt_keypts"].double().numpy()
+        res = np.linalg.norm(src[flipped] @ T[:3, :3].T + T[:3, 3] - tgt[flipped], axis=1)
+        eps = 8 * 2.0 ** -24 * scale
+        ok = bool((np.abs(res - thr) <= eps).all())
+        return ok, f"label-edge: same hypothesis and refinement; flipped correspondences {list(map(int, flipped))} have residuals {np.abs(res - thr).tolist()} from the threshold (allowed {eps:.1e})"
+    return False, f"same hypothesis, same refinement sequence, neighbour set {'equal' if differs is not None else 'not recorded'}: no recorded discrete cause"
+
+
 def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0, attention_precision=None):
     fx = np.load(ROOT / "tests" / "golden" / f"census_{name}.npz", allow_pickle=False)
+    ixp = ROOT / "tests" / "golden" / f"census_internals_{name}.npz"
+    ix = np.load(ixp, allow_pickle=False) if ixp.exists() else None
     w = workloads.WORKLOADS[name]
     n = w["num_corr"]
     total = fx["ref32_final_trans"].shape[0] if pairs <= 0 else min(pairs, fx["ref32_final_trans"].shape[0])
@@ -61,16 +160,34 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
         model.attention_precision = attention_precision
     out = {}
     for step in batches:
-        T, L = [], []
+        T, L, D = [], [], []
         for first in range(0, total, step):
-            batch = workloads.batch(name, first, min(step, total - first))
+            g = min(step, total - first)
+            batch = workloads.batch(name, first, g)
             data = {k: batch[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
             data["testing"] = True
             with torch.no_grad():
                 r = model(data)
             T.append(r["final_trans"].cpu())
             L.append(r["final_labels"].cpu())
+            dec = decisions(model, g, n)
+            D += [{k: v[b] for k, v in dec.items()} for b in range(g)]
         ok, d32, dbest, f32, which = judge(torch.cat(T), torch.cat(L), fx, n)
+        strict = (d32 < 1e-4) & (f32 == 0)                 # the contract against the reference's fp32 output, nothing else
+        # pairs on which the reference does not reproduce ITSELF between its fp32 and fp64 runs (pose >= 1e-4 apart or another label
+        # mask): no well-defined target; recorded by oracle/make_census_goldens.py
+        ref_self = np.abs(fx["ref32_final_trans"][:total].astype(np.float64) - fx["ref64_final_trans"][:total]).max(axis=(1, 2))
+        ill = (ref_self >= 1e-4) | (fx["ref32_final_labels_bits"][:total] != fx["ref64_final_labels_bits"][:total]).any(axis=1)
+        verdicts = {}
+        if ix is not None:
+            l32 = np.unpackbits(fx["ref32_final_labels_bits"][:total], axis=1)[:, :n]
+            Lall = torch.cat(L).numpy()
+            for i in np.flatnonzero(~strict.numpy()):
+                one = workloads.batch(name, int(i), 1)
+                flipped = np.flatnonzero((Lall[i] > 0) != (l32[i] > 0))
+                verdicts[int(i)] = explain(int(i), D[i], ix, {k: one[k][0] for k in ("src_keypts", "tgt_keypts")},
+                                           float(w["model"]["inlier_threshold"]), float(w["pair"]["scale"]),
+                                           flipped if float(d32[i]) < 1e-4 else None)
         d = dbest.numpy()
         hist = [int(((d >= lo) & (d < hi)).sum()) for lo, hi in zip((0.0,) + EDGES, EDGES + (np.inf,))]
         t64 = torch.from_numpy(fx["ref64_final_trans"][:total]).double()
@@ -83,7 +200,12 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
                      "reference_self_disagreement_above_1e-4": [int(i) for i in np.flatnonzero(ref_self.numpy() >= 1e-4)],
                      "label_flips_vs_fp32_reference": int(f32.sum()), "pairs_matched_on_fp64_reference": [int(i) for i in np.flatnonzero(which.numpy() == 1)],
                      "median_dT": float(np.median(d)), "max_dT": float(d.max()), "max_dT_vs_fp32_reference": float(d32.max()),
-                     "dT_histogram": dict(zip(["<1e-6", "<1e-5", "<2e-5", "<5e-5", "<1e-4", ">=1e-4"], hist))}
+                     "dT_histogram": dict(zip(["<1e-6", "<1e-5", "<2e-5", "<5e-5", "<1e-4", ">=1e-4"], hist)),
+                     "outside_fp32_contract": [int(i) for i in np.flatnonzero(~strict.numpy())],
+                     "outside_fp32_contract_detail": [{"pair": i, "dT_vs_ref_fp32": float(d32[i]), "label_flips": int(f32[i]), "excused": bool(v[0]),
+                                                       "reference_not_self_consistent": bool(ill[i]), "why": v[1]} for i, v in verdicts.items()],
+                     "reference_not_self_consistent": [int(i) for i in np.flatnonzero(ill)],
+                     "unexcused": [i for i, v in verdicts.items() if not v[0] and not ill[i]] if ix is not None else None}
     return out, model
 
 
@@ -113,9 +235,12 @@ def main():
                       flush=True)
                 for fd in r["failing_detail"]:
                     print("    ", json.dumps(fd), flush=True)
+                print(f"    outside the fp32 contract: {r['outside_fp32_contract']}; unexcused by the reference's recorded decisions: {r['unexcused']}", flush=True)
+                for fd in r["outside_fp32_contract_detail"]:
+                    print("      ", json.dumps(fd), flush=True)
     if a.json:
         print(json.dumps(report))
-    return 1 if any(r["failing_pairs"] for rep in report.values() for r in rep.values()) else 0
+    return 1 if any((r["unexcused"] if r["unexcused"] is not None else r["failing_pairs"]) for rep in report.values() for r in rep.values()) else 0
 
 
 if __name__ == "__main__":

@@ -1,0 +1,332 @@
+// Standalone reproducer for the packed-fp32 vote miscount of r03 (DESIGN.md "Forwards in flight: exactness"): NO PointDSC forward.
+//
+//   bash tools/pk_f32_repro_build.sh && tools/pk_f32_repro.bin [reps] [path to libpointdsc_hip.so] [comma list of hogs, default all]
+//
+// What r03 saw: the hypothesis-scoring kernel (csrc/score_kernel.h), in the form the SLP vectoriser gives it (two seeds per
+// v_pk_mul/fma/add_f32, the just-loaded point broadcast with op_sel), came out a few votes short on the ODD seed of some pairs
+// (the high half of the packed registers) in 0.2-0.7 % of the forwards -- only while kernels of other forwards were co-resident.
+// This program launches the SAME kernel source (score_kernel.h is included, not copied) on a fixed synthetic problem whose
+// exact counts are computed on the host with the same fma chain, next to synthetic co-resident kernels ("hogs") on other
+// streams, and counts launches whose votes differ from the host's.  Forms of the inner loop:
+//     scalar   score_kernel<0,0> built with -fno-slp-vectorize (pk_f32_repro_noslp.hip): what the product ships
+//     slp      score_kernel<0,1> built with default flags: the compiler's packed form (the r03 failure)
+//     pk_asm   hand-written v_pk_*_f32, operands broadcast into register pairs first: packed math, NO op_sel
+//     pk_opsel hand-written v_pk_*_f32 reading the loaded point registers through op_sel / op_sel_hi: the compiler's operand form
+// Hogs: none | mfma (bf16 32x32x16 chains, the matrix pipe + power) | valu (packed fma chains) | mem (HBM stream) | lds (ds_read_b128)
+//       | att (the product's own split-precision attention launch -- LDS-DMA staging, s_setprio -- on random operands, through the C ABI of
+//       libpointdsc_hip.so, if the path is given) | att32 (the exact-fp32 attention launch: fp32 MFMA, ordinary LDS staging).
+// A mismatch table per (form, hog) goes to stdout; exit code 0 always (it is a probe, not a test).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../pointdsc_amd/csrc/score_kernel.h"
+
+namespace pdsc {      // the two symbols pdsc_common.h expects from the library's host side
+void set_error(const char*, ...) {}
+int check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -1; }
+}  // namespace pdsc
+
+#define CK(x)                                                                                 \
+    do {                                                                                      \
+        hipError_t e__ = (x);                                                                 \
+        if (e__ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); exit(2); } \
+    } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+void launch_scalar(const float* T, const float* src, const float* tgt, float thr2, int* counts, int N, int S, hipStream_t st);   // pk_f32_repro_noslp.hip
+
+// ---- hand-written packed forms: one thread = one point, one workgroup = 4 seeds (two packed pairs), same grid as score_kernel ----
+template <int OPSEL>
+__global__ __launch_bounds__(256) void score_pk_asm_kernel(const float* __restrict__ seed_trans, const float* __restrict__ src,
+                                                           const float* __restrict__ tgt, float thr2, int* __restrict__ counts, int N, int S) {
+    __shared__ int wsum[4][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, s0 = blockIdx.x * 4;
+    int vz = 0;
+    asm volatile("" : "+v"(vz));
+    // transforms of the two seed pairs, element e of both seeds of a pair side by side: (T_a[e], T_b[e])
+    f2 Tp[2][12];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            Tp[p][e].x = seed_trans[(size_t)min(s0 + 2 * p, S - 1) * 16 + e + vz];
+            Tp[p][e].y = seed_trans[(size_t)min(s0 + 2 * p + 1, S - 1) * 16 + e + vz];
+        }
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = t; i < N; i += 256) {
+        // the point as the compiler's loop holds it: two dwordx3 loads into consecutive registers
+        f2 pxy, pz_, qxy, qz_;
+        pxy.x = src[i * 3]; pxy.y = src[i * 3 + 1]; pz_.x = src[i * 3 + 2]; pz_.y = 0.f;
+        qxy.x = tgt[i * 3]; qxy.y = tgt[i * 3 + 1]; qz_.x = tgt[i * 3 + 2]; qz_.y = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f2 r[3];
+#pragma unroll
+            for (int row = 0; row < 3; ++row) {
+                f2 acc;
+                if constexpr (OPSEL) {
+                    // x = fma(T2, pz, fma(T1, py, T0 * px)) + T3 with px / py / pz taken from (px,py) / (pz,_) by op_sel
+                    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(pxy), "v"(Tp[p][row * 4 + 0]));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(Tp[p][row * 4 + 1]), "v"(pxy));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(Tp[p][row * 4 + 2]), "v"(pz_));
+                    asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc) : "v"(Tp[p][row * 4 + 3]));
+                    if (row == 0) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(qxy));
+                    if (row == 1) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(qxy));
+                    if (row == 2) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(qz_));
+                } else {
+                    const float pe[3] = {pxy.x, pxy.y, pz_.x};
+                    const float qe[3] = {qxy.x, qxy.y, qz_.x};
+                    f2 bx = {pe[0], pe[0]}, by = {pe[1], pe[1]}, bz = {pe[2], pe[2]}, bq = {qe[row], qe[row]};
+                    asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz), "+v"(bq));        // materialise the broadcast pairs: no op_sel below
+                    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(acc) : "v"(bx), "v"(Tp[p][row * 4 + 0]));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(Tp[p][row * 4 + 1]), "v"(by));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(Tp[p][row * 4 + 2]), "v"(bz));
+                    asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc) : "v"(Tp[p][row * 4 + 3]));
+                    asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(bq));
+                }
+                r[row] = acc;
+            }
+            f2 d2;
+            asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(d2) : "v"(r[0]));
+            asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(d2) : "v"(r[1]));
+            asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(d2) : "v"(r[2]));
+            cnt[2 * p] += __popcll(__ballot(d2.x < thr2));
+            cnt[2 * p + 1] += __popcll(__ballot(d2.y < thr2));
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (lane == 0) wsum[wave][s] = cnt[s];
+    __syncthreads();
+    if (t < 4 && s0 + t < S) counts[s0 + t] = wsum[0][t] + wsum[1][t] + wsum[2][t] + wsum[3][t];
+}
+
+// ---- hogs ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hog_mfma(float* out, int iters) {
+    f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (threadIdx.x + e)); b[e] = (__bf16)(0.002f * (threadIdx.x * 3 + e)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][15];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void hog_valu(float* out, int iters) {
+    f2 a = {1.0f + threadIdx.x * 1e-6f, 0.5f}, b = {0.999f, 1.001f}, c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = f2{(float)j, (float)-j};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += c[j].x + c[j].y;
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void hog_mem(const pdsc::f32x4* __restrict__ buf, size_t n4, float* out) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const pdsc::f32x4 v = __builtin_nontemporal_load(buf + i);
+        s += v.x + v.y + v.z + v.w;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void hog_lds(float* out, int iters) {
+    __shared__ float4 sm[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) sm[i] = float4{(float)i, 1.f, 2.f, 3.f};
+    __syncthreads();
+    float s = 0.f;
+    int idx = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        const float4 v = sm[idx & 2047];
+        s += v.x + v.w;
+        idx += 257;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------
+static float frand(unsigned& st) { st = st * 1664525u + 1013904223u; return (st >> 8) * (1.0f / 16777216.0f); }
+
+static void rot(float ax, float ay, float az, float ang, float* R) {
+    const float n = sqrtf(ax * ax + ay * ay + az * az), x = ax / n, y = ay / n, z = az / n, c = cosf(ang), s = sinf(ang), C = 1 - c;
+    const float M[9] = {c + x * x * C, x * y * C - z * s, x * z * C + y * s, y * x * C + z * s, c + y * y * C, y * z * C - x * s,
+                        z * x * C - y * s, z * y * C + x * s, c + z * z * C};
+    memcpy(R, M, sizeof(M));
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 300;
+    const char* libpath = argc > 2 ? argv[2] : nullptr;
+    const char* only = argc > 3 ? argv[3] : nullptr;
+    const int N = 5000, S = 500, LAUNCHES = 6;       // launches of the form per hog launch (each into its own counter slice)
+    unsigned st = 12345u;
+    std::vector<float> src(N * 3), tgt(N * 3), T((size_t)S * 16, 0.f);
+    float Rg[9];
+    rot(0.3f, -0.5f, 0.8f, 0.9f, Rg);
+    const float tg[3] = {0.2f, -0.4f, 0.1f};
+    for (int i = 0; i < N; ++i) {
+        float p[3] = {frand(st) * 3.f, frand(st) * 3.f, frand(st) * 3.f};
+        for (int e = 0; e < 3; ++e) src[i * 3 + e] = p[e];
+        const bool inl = frand(st) < 0.22f;
+        for (int r = 0; r < 3; ++r)
+            tgt[i * 3 + r] = inl ? Rg[r * 3] * p[0] + Rg[r * 3 + 1] * p[1] + Rg[r * 3 + 2] * p[2] + tg[r] + (frand(st) - 0.5f) * 0.06f : frand(st) * 3.f;
+    }
+    for (int s = 0; s < S; ++s) {       // hypotheses around the truth: residuals of the inliers spread across the threshold
+        float dR[9], R[9];
+        rot(frand(st) - 0.5f, frand(st) - 0.5f, frand(st) - 0.5f, frand(st) * 0.03f, dR);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = dR[r * 3] * Rg[c] + dR[r * 3 + 1] * Rg[3 + c] + dR[r * 3 + 2] * Rg[6 + c];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) T[(size_t)s * 16 + r * 4 + c] = R[r * 3 + c];
+            T[(size_t)s * 16 + r * 4 + 3] = tg[r] + (frand(st) - 0.5f) * 0.05f;
+        }
+        T[(size_t)s * 16 + 15] = 1.f;
+    }
+    const float thr2 = pdsc::sqrt_threshold_radicand(0.10f);
+    std::vector<int> want(S, 0);
+    for (int s = 0; s < S; ++s) {
+        const float* t = &T[(size_t)s * 16];
+        for (int i = 0; i < N; ++i) {
+            const float px = src[i * 3], py = src[i * 3 + 1], pz = src[i * 3 + 2];
+            const float x = fmaf(t[2], pz, fmaf(t[1], py, t[0] * px)) + t[3];
+            const float y = fmaf(t[6], pz, fmaf(t[5], py, t[4] * px)) + t[7];
+            const float z = fmaf(t[10], pz, fmaf(t[9], py, t[8] * px)) + t[11];
+            const float dx = x - tgt[i * 3], dy = y - tgt[i * 3 + 1], dz = z - tgt[i * 3 + 2];
+            want[s] += fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < thr2;
+        }
+    }
+    int wmin = want[0], wmax = want[0];
+    for (int v : want) { wmin = v < wmin ? v : wmin; wmax = v > wmax ? v : wmax; }
+    printf("problem: N=%d S=%d, host counts in [%d, %d]; %d reps x %d launches per (form, hog)\n", N, S, wmin, wmax, reps, LAUNCHES);
+
+    float *dsrc, *dtgt, *dT, *dout, *dbig = nullptr;
+    int* dcounts;
+    CK(hipMalloc(&dsrc, src.size() * 4)); CK(hipMalloc(&dtgt, tgt.size() * 4)); CK(hipMalloc(&dT, T.size() * 4));
+    CK(hipMalloc(&dout, 64)); CK(hipMalloc(&dcounts, (size_t)LAUNCHES * S * 4));
+    CK(hipMemcpy(dsrc, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtgt, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dT, T.data(), T.size() * 4, hipMemcpyHostToDevice));
+    const size_t big = (size_t)1 << 30;
+    CK(hipMalloc(&dbig, big)); CK(hipMemset(dbig, 0, big));
+    hipStream_t s_test, s_hog[2];
+    CK(hipStreamCreate(&s_test)); CK(hipStreamCreate(&s_hog[0])); CK(hipStreamCreate(&s_hog[1]));
+
+    // the product's attention launch as a hog (C ABI, random operands)
+    typedef size_t (*bytes2_t)(int, int);
+    typedef size_t (*bytes3_t)(int, int, int);
+    typedef long long (*ld_t)(int);
+    typedef int (*att_t)(const void*, const void*, const unsigned short*, long long, float*, void*, size_t, int, int, int, void*);
+    typedef int (*att32_t)(const float*, const float*, long long, float*, void*, size_t, int, int, int, void*);
+    att32_t att32 = nullptr;
+    float *a32qkv = nullptr, *a32compat = nullptr;
+    void* a32scr = nullptr;
+    size_t a32scr_b = 0;
+    att_t att = nullptr;
+    void *aq = nullptr, *akv = nullptr, *ascr = nullptr, *acompat = nullptr;
+    float* amsg = nullptr;
+    size_t ascr_b = 0;
+    long long ald = 0;
+    const int ABS = 2, AN = 5000;
+    if (libpath) {
+        void* h = dlopen(libpath, RTLD_NOW);
+        if (!h) fprintf(stderr, "dlopen(%s): %s\n", libpath, dlerror());
+        else {
+            att = (att_t)dlsym(h, "pdsc_sc_attention_split_u16");
+            const size_t qb = ((bytes2_t)dlsym(h, "pdsc_split_q_bytes"))(ABS, AN), kb = ((bytes2_t)dlsym(h, "pdsc_split_kv_bytes"))(ABS, AN);
+            ascr_b = ((bytes3_t)dlsym(h, "pdsc_attention_split_scratch_bytes"))(ABS, AN, 0);
+            ald = ((ld_t)dlsym(h, "pdsc_compat_ld"))(AN);
+            CK(hipMalloc(&aq, qb)); CK(hipMalloc(&akv, kb)); CK(hipMalloc(&ascr, ascr_b)); CK(hipMalloc(&amsg, (size_t)ABS * AN * 128 * 4));
+            CK(hipMalloc(&acompat, (size_t)ABS * AN * ald * 2));
+            std::vector<unsigned short> hq(qb / 2), hk(kb / 2), hc((size_t)ABS * AN * ald);
+            for (auto& v : hq) v = (unsigned short)(0x3c00 + (int)(frand(st) * 512));      // bf16 bit patterns of moderate magnitude
+            for (auto& v : hk) v = (unsigned short)(0x3c00 + (int)(frand(st) * 512));
+            for (auto& v : hc) v = frand(st) < 0.1f ? (unsigned short)(frand(st) * 65535) : 0;
+            CK(hipMemcpy(aq, hq.data(), qb, hipMemcpyHostToDevice)); CK(hipMemcpy(akv, hk.data(), kb, hipMemcpyHostToDevice));
+            CK(hipMemcpy(acompat, hc.data(), hc.size() * 2, hipMemcpyHostToDevice));
+            att32 = (att32_t)dlsym(h, "pdsc_sc_attention");
+            a32scr_b = ((bytes3_t)dlsym(h, "pdsc_attention_scratch_bytes"))(ABS, AN, 0);
+            CK(hipMalloc(&a32qkv, (size_t)ABS * AN * 384 * 4)); CK(hipMalloc(&a32compat, (size_t)ABS * AN * ald * 4)); CK(hipMalloc(&a32scr, a32scr_b ? a32scr_b : 16));
+            std::vector<float> hqkv((size_t)ABS * AN * 384), hc32((size_t)ABS * AN * ald);
+            for (auto& v : hqkv) v = frand(st) - 0.5f;
+            for (auto& v : hc32) v = frand(st) < 0.1f ? frand(st) : 0.f;
+            CK(hipMemcpy(a32qkv, hqkv.data(), hqkv.size() * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(a32compat, hc32.data(), hc32.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+
+    const char* forms[] = {"scalar", "slp", "pk_asm", "pk_opsel"};
+    const char* hogs[] = {"none", "mfma", "valu", "mem", "lds", "mfma+mem", "att", "att32"};
+    std::vector<int> got((size_t)LAUNCHES * S);
+    for (int hg = 0; hg < 8; ++hg) {
+        if ((hg == 6 && !att) || (hg == 7 && !att32)) continue;
+        if (only) {      // exact token match in the comma list
+            const size_t L = strlen(hogs[hg]);
+            bool hit = false;
+            for (const char* q = only; (q = strstr(q, hogs[hg])) != nullptr; q += L)
+                if ((q == only || q[-1] == ',') && (q[L] == 0 || q[L] == ',')) { hit = true; break; }
+            if (!hit) continue;
+        }
+        for (int f = 0; f < 4; ++f) {
+            long bad_launches = 0, bad_seeds = 0, bad_odd = 0, short_votes = 0, over_votes = 0, launches = 0;
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, s_test));
+            for (int rep = 0; rep < reps; ++rep) {
+                // hog(s) first (about 1 ms each, 512 workgroups of 256 threads: two per CU, room left for the scoring workgroups)
+                if (hg == 1 || hg == 5) hipLaunchKernelGGL(hog_mfma, dim3(512), dim3(256), 0, s_hog[0], dout, 6000);
+                if (hg == 2) hipLaunchKernelGGL(hog_valu, dim3(512), dim3(256), 0, s_hog[0], dout, 6000);
+                if (hg == 3 || hg == 5) hipLaunchKernelGGL(hog_mem, dim3(1024), dim3(256), 0, s_hog[1], (const pdsc::f32x4*)dbig, big / 16, dout);
+                if (hg == 4) hipLaunchKernelGGL(hog_lds, dim3(512), dim3(256), 0, s_hog[0], dout, 60000);
+                if (hg == 7 && att32(a32qkv, a32compat, ald, amsg, a32scr, a32scr_b, ABS, AN, 0, s_hog[0]) != 0) { fprintf(stderr, "fp32 attention hog failed\n"); att32 = nullptr; break; }
+                if (hg == 6 && att(aq, akv, (const unsigned short*)acompat, ald, amsg, ascr, ascr_b, ABS, AN, 0, s_hog[0]) != 0) { fprintf(stderr, "attention hog failed\n"); att = nullptr; break; }
+                for (int l = 0; l < LAUNCHES; ++l) {
+                    int* c = dcounts + (size_t)l * S;
+                    const dim3 grid((S + 3) / 4, 1);
+                    if (f == 0) launch_scalar(dT, dsrc, dtgt, thr2, c, N, S, s_test);
+                    if (f == 1) hipLaunchKernelGGL((pdsc::score_kernel<0, 1>), grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S, (const int*)nullptr, (float*)nullptr);
+                    if (f == 2) hipLaunchKernelGGL(score_pk_asm_kernel<0>, grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S);
+                    if (f == 3) hipLaunchKernelGGL(score_pk_asm_kernel<1>, grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S);
+                }
+                CK(hipMemcpyAsync(got.data(), dcounts, got.size() * 4, hipMemcpyDeviceToHost, s_test));
+                CK(hipStreamSynchronize(s_test));
+                for (int l = 0; l < LAUNCHES; ++l) {
+                    int nb = 0;
+                    for (int s = 0; s < S; ++s) {
+                        const int d = got[(size_t)l * S + s] - want[s];
+                        if (d) { ++nb; bad_odd += s & 1; if (d < 0) short_votes -= d; else over_votes += d; }
+                    }
+                    bad_launches += nb > 0;
+                    bad_seeds += nb;
+                    ++launches;
+                }
+                CK(hipDeviceSynchronize());
+            }
+            CK(hipEventRecord(e1, s_test));
+            CK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("hog %-9s form %-9s: %ld of %ld launches differ from the host counts; seeds off %ld (odd index %ld), votes short %ld, votes over %ld   [%.0f ms]\n",
+                   hogs[hg], forms[f], bad_launches, launches, bad_seeds, bad_odd, short_votes, over_votes, ms);
+            fflush(stdout);
+        }
+    }
+    return 0;
+}
