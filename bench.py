@@ -167,7 +167,10 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)          # rehearsal: ranks share the visible GPU(s)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # launched by torch.distributed.run with ONE rank (tests/test_gpu_parity.py: the RCCL bring-up -- init with device_id=, barrier,
+    # all_gather -- exercised on the one-GPU box): the process group exists, the data path is the world-1 one
+    solo_pg = world == 1 and args.backend == "nccl" and "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or solo_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -219,7 +222,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or solo_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -331,6 +334,14 @@ def main():
                   "steps": args.steps}
         depth["d"] = in_flight
 
+    rccl_probe = None
+    if solo_pg:
+        # one all_gather of the pose payload through RCCL with world size 1 (gather_results itself short-circuits at world 1)
+        payload = last["res"]["final_trans"].reshape(-1, 16).contiguous()
+        flat = torch.empty_like(payload)
+        dist.all_gather_into_tensor(flat, payload)
+        torch.cuda.synchronize()
+        rccl_probe = {"backend": dist.get_backend(), "world": dist.get_world_size(), "all_gather_bitwise_equal": bool(torch.equal(flat, payload))}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -420,6 +431,8 @@ def main():
     if sustained is not None:
         line["sustained"] = sustained
     line["in_flight"] = depth["d"]
+    if rccl_probe is not None:
+        line["rccl_world1_probe"] = rccl_probe
     line["hip_graphs"] = bool(runners[in_flight].graphs and runners[in_flight]._captured)
     line["tail_streams"] = bool(runners[in_flight].tail_streams)
     if single is not None:
@@ -522,7 +535,7 @@ def main():
                        check.get("timed_result_equals_single_stream_result_bitwise", True)) if dts else None
         line["check"] = check
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or solo_pg:
         dist.destroy_process_group()
     if check is not None and check["ok"] is False:
         # a throughput figure next to outputs that miss the parity contract is not a result: fail the run

@@ -511,6 +511,19 @@ int pdsc_cal_confidence(const float* M, long long ld, const float* leading_eig, 
 int pdsc_eval_stats(const float* trans, const float* gt_trans, const float* pred_labels, const float* gt_labels,
                     float re_thre, float te_thre, float* stats, int bs, int N, void* stream);
 
+/* ---- range probe for layer_gemm = PDSC_LAYER_GEMM_H3 ----------------------------------------------------------------
+ * The H3 arithmetic carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo, so every activation of the
+ * 12-layer chain -- hidden ones included -- must stay below 65504.  This entry runs the ENCODER (compat, layer0, 12 x
+ * {PointCN, q|k|v, attention, fc1, fc2, fc3 + residual}; models/PointDSC.py:48-77) once with the fp32 GEMMs, one launch per
+ * conv, and leaves in absmax[kind] (DEVICE, PDSC_RANGE_NUM_KINDS floats) the largest |value| of each activation kind over
+ * all layers (a NaN anywhere reads back as NaN).  The module calls it on the first forward after packing weights and falls
+ * back to PDSC_LAYER_GEMM_F32 with a warning when a value is out of range.  Same workspace as pdsc_forward_testing. */
+enum pdsc_range_kind { PDSC_RANGE_LAYER0 = 0, PDSC_RANGE_POINTCN = 1, PDSC_RANGE_QKV = 2, PDSC_RANGE_MESSAGE = 3, PDSC_RANGE_FC1 = 4,
+                       PDSC_RANGE_FC2 = 5, PDSC_RANGE_FEATURE = 6, PDSC_RANGE_NUM_KINDS = 8 };
+int pdsc_encoder_range_probe(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                             const float* src_keypts, const float* tgt_keypts, int bs, int N, int num_seeds, float* absmax,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* Named views into the workspace of the last layout computed for (cfg, bs, N, num_seeds): lets the
  * parity tests read intermediates after pdsc_forward_testing.  Returns byte offset or -1. */
 long long pdsc_workspace_offset(const pdsc_config* cfg, int bs, int N, int num_seeds, const char* name);

@@ -83,6 +83,9 @@ def main():
         ref64.load_state_dict(sd, strict=True)
         ref64 = ref64.double()
         torch.set_default_dtype(torch.float32)
+        # N = 20000: the reference's fp64 forward needs ~10 N^2-sized fp64 tensors at once (32 GB + the [N,N,3] temporaries);
+        # the fp32-vs-fp64 stability probe is skipped there and the report says so (the pair is then held to the plain contract)
+        big = w["num_corr"] > 12000
         for i in range(G):
             one = {k: batch[k][i:i + 1] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
             with torch.no_grad():
@@ -93,9 +96,12 @@ def main():
                 ores = res if all_pairs else O.forward_testing(sd, one["corr_pos"], one["src_keypts"], one["tgt_keypts"],
                                                                **{k: kw[k] for k in ORACLE_KEYS})     # (census: reference only)
                 t_or = time.perf_counter() - t0
-                torch.set_default_dtype(torch.float64)
-                res64 = ref64(dict({k_: v_.double() for k_, v_ in one.items()}, testing=True))
-                torch.set_default_dtype(torch.float32)
+                if big:
+                    res64 = {"final_trans": res["final_trans"].double(), "final_labels": res["final_labels"].double()}      # (no fp64 run at this size)
+                else:
+                    torch.set_default_dtype(torch.float64)
+                    res64 = ref64(dict({k_: v_.double() for k_, v_ in one.items()}, testing=True))
+                    torch.set_default_dtype(torch.float32)
             self_dT = float((res["final_trans"].double() - res64["final_trans"]).abs().max())
             self_flips = int((res["final_labels"].double() != res64["final_labels"]).sum())
             stable.append(self_dT < 2e-5 and self_flips == 0)
@@ -106,7 +112,8 @@ def main():
                      oracle_label_flips=int((ores["final_labels"] != res["final_labels"]).sum()),
                      ref_inliers=int(res["final_labels"].sum()), gt_inliers=int(batch["gt_labels"][i].sum()),
                      ref_RE_deg=re, ref_TE_cm=te, ref_seconds=round(t_ref, 2), oracle_seconds=round(t_or, 2),
-                     reference_fp32_vs_fp64_dT=self_dT, reference_fp32_vs_fp64_label_flips=self_flips, stable=stable[-1])
+                     reference_fp32_vs_fp64_dT=None if big else self_dT, reference_fp32_vs_fp64_label_flips=None if big else self_flips,
+                     stable=stable[-1], fp64_probe="skipped (memory)" if big else "reference in fp64")
             rep["pairs"].append(p)
             print(name, json.dumps(p), flush=True)
             if p["oracle_label_flips"] != 0 or p["oracle_dT"] >= (1e-4 if stable[-1] else 1e-3) or re > 1.0:

@@ -198,7 +198,8 @@ def main():
     rm = np.stack([r["refine_margin32"] for r in rows])
     gaps = np.stack([r["knn_gap32"] for r in rows])
     best_gap = np.array([float(r["knn_gap32"][int(r["best32"])]) for r in rows])
-    rep = {"pairs": total, "hypothesis_ties_within_one_vote_fp32": [int(i) for i in tie],
+    rep = {"pairs": total, "pairs_with_a_second_hypothesis_within_one_vote_of_the_winner_fp32": int(len(tie)),
+           "median_number_of_hypotheses_within_one_vote_of_the_winner_fp32": float(np.median((top >= top[:, :1] - 1).sum(axis=1))),
            "knn_boundary_gap_fp32": {"median_over_all_seeds": float(np.median(gaps)), "share_of_seeds_below_2e-5": float((gaps < 2e-5).mean()),
                                      "chosen_seed_gap_below_2e-5": [int(i) for i in np.flatnonzero(best_gap < 2e-5)]},
            "refinement_margin_below_1e-4_fp32": [int(i) for i in np.flatnonzero(np.nanmin(rm, axis=1) < 1e-4)],

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pdsc_cal_confidence_workspace_bytes": (_sz, [_i, _i]),
     "pdsc_cal_confidence": (_i, [_vp, _ll, _vp, _i, _i, _vp, _vp, _sz, _i, _i, _vp]),
     "pdsc_eval_stats": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _vp]),
+    "pdsc_encoder_range_probe": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "pdsc_forward_validation": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _ll, _vp, _sz, _vp]),
     "pdsc_feature_compat": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pdsc_conv_mask_all_pairs": (_i, [_vp, _i, _vp]),

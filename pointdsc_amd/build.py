@@ -30,8 +30,17 @@ EXP_OBJ_DIR = PKG / "csrc" / "_obj_exp"
 ARCH = "gfx950"
 # -ffp-contract=off: the kernels spell out every fused multiply-add (fmaf) themselves, so the arithmetic
 # that decides thresholds is exactly what the source says (see DESIGN.md "numerics").
+# -fno-slp-vectorize, EVERY translation unit (r04): the SLP vectoriser pairs adjacent scalar fp32 operations into v_pk_*_f32
+# with op_sel operand selects; in r03 that form of the hypothesis-scoring kernel lost votes while kernels of other forwards were
+# co-resident, and tools/pk_f32_repro.hip (no PointDSC forward: the scoring loop beside the attention launch) shows wrong lanes
+# in packed op_sel code too (profiles/r04_pk_f32_repro*.txt).  The cause below the ISA is not established, so no compiler-paired
+# packed fp32 is shipped at all; the only packed fp32 left is the hand-written float2 math of compat.hip (its results are covered
+# bit for bit by the in-flight exactness probes and tests).  `--slp` builds the old flags as libpointdsc_hip_slp.so for A/B runs.
+NO_SLP = ["-fno-slp-vectorize"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"] + os.environ.get("PDSC_HIPCC_EXTRA", "").split()     # e.g. -DPDSC_LAYER_DIAG (diagnostic kernels)
+SLP_LIB = PKG / "libpointdsc_hip_slp.so"
+SLP_OBJ_DIR = PKG / "csrc" / "_obj_slp"
 
 
 def _hipcc() -> str:
@@ -41,9 +50,8 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-# extra flags of single sources.  score.hip: no SLP vectorisation -- the packed-fp32 form of the inlier test miscounted votes
-# while other kernels were co-resident (csrc/score.hip, pointdsc_amd/pipeline.py, profiles/r03_ab_probe.txt)
-PER_FILE_FLAGS = {"score.hip": ["-fno-slp-vectorize"]}
+# extra flags of single sources.  score_slp.hip (experiments builds): the r03 reproducer, deliberately WITH SLP vectorisation
+PER_FILE_FLAGS = {"score_slp.hip": ["-fslp-vectorize"]}
 
 
 def _sources():
@@ -61,9 +69,9 @@ def _digest(flags=None) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> Path:
-    flags = FLAGS + (["-DPDSC_EXPERIMENTS"] if experiments else [])
-    lib, obj_dir = (EXP_LIB, EXP_OBJ_DIR) if experiments else (LIB, OBJ_DIR)
+def build(force: bool = False, verbose: bool = True, experiments: bool = False, slp: bool = False) -> Path:
+    flags = FLAGS + ([] if slp else NO_SLP) + (["-DPDSC_EXPERIMENTS"] if experiments else [])
+    lib, obj_dir = (SLP_LIB, SLP_OBJ_DIR) if slp else ((EXP_LIB, EXP_OBJ_DIR) if experiments else (LIB, OBJ_DIR))
     stamp = obj_dir / "sources.sha256"
     digest = _digest(flags)
     if not force and lib.exists() and stamp.exists() and stamp.read_text().strip() == digest:
@@ -98,4 +106,4 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv, slp="--slp" in sys.argv))

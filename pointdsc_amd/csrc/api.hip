@@ -61,6 +61,26 @@ __global__ void fill_u32_kernel(unsigned int* p, unsigned int value, size_t coun
 __global__ void copy_u32_kernel(unsigned int* __restrict__ dst, const unsigned int* __restrict__ src, size_t count) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// slot := max(slot, max_i |x[i]|) on the bit patterns (non-negative floats order like unsigned integers; NaN patterns sort above inf,
+// so a NaN anywhere shows as "out of range")
+__global__ void absmax_kernel(const float* __restrict__ x, size_t count, unsigned int* __restrict__ slot) {
+    unsigned int m = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned int u = __float_as_uint(x[i]) & 0x7fffffffu;
+        m = u > m ? u : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(slot, m);
+}
+static int launch_absmax(const float* x, size_t count, unsigned int* slot, hipStream_t st) {
+    const size_t blocks = (count + 1023) / 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, count, slot);
+    return check_launch("absmax");
+}
 int launch_copy_u32(unsigned int* dst, const unsigned int* src, size_t count, hipStream_t st) {
     if (count == 0) return PDSC_OK;
     const size_t blocks = (count + 255) / 256;
@@ -323,7 +343,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                        const float* src, const float* tgt, int bs, int N, int num_seeds,
                        float* final_trans, float* final_labels, float* Mout, long long ldM, void* workspace,
                        size_t workspace_bytes, void* stream, const int* nvalid = nullptr, const int* svalid = nullptr, int n_min = 0,
-                       void* tail_stream = nullptr, void* ev_fork = nullptr, void* ev_join = nullptr) {
+                       void* tail_stream = nullptr, void* ev_fork = nullptr, void* ev_join = nullptr, unsigned int* probe = nullptr) {
     if (!config_ok(cfg)) return PDSC_ERR_ARG;
     PDSC_REQUIRE(!tail_stream || (ev_fork && ev_join && tail_stream != stream),
                  "pdsc_forward_testing_streams: a tail stream (different from the main stream) needs the fork and join events");
@@ -391,7 +411,10 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                          att_bytes, bs, N, nsplit, PDSC_PARTIALS_ROWS, nvalid, hst);
     };
     PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
-    const int fused = env_int("PDSC_FUSED_LAYERS", 1);          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
+    // probe != NULL (pdsc_encoder_range_probe): one launch per conv, every intermediate in the workspace, |max| of each kind recorded
+    const int fused = probe ? 0 : env_int("PDSC_FUSED_LAYERS", 1);          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
+    auto P = [&](int kind, const float* x, size_t count) { return probe ? launch_absmax(x, count, probe + kind, hst) : PDSC_OK; };
+    PDSC_TRY(P(PDSC_RANGE_LAYER0, featA, (size_t)M * C));
     if (fused && cfg->num_layers > 0 && split) {
         // split precision: head of layer 0, then per layer attention (partials left un-merged when the keys are split)
         // + ONE launch for the merge, the tail of layer i and the head of layer i+1
@@ -494,16 +517,23 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     } else
     for (int i = 0; i < cfg->num_layers; ++i) {
         PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_PCN_W, i), W(PDSC_W_PCN_B, i), nullptr, 0, featB, C, M, C, C, 1, stream));
+        PDSC_TRY(P(PDSC_RANGE_POINTCN, featB, (size_t)M * C));
         PDSC_TRY(pdsc_linear(featB, C, W(PDSC_W_QKV_W, i), W(PDSC_W_QKV_B, i), nullptr, 0, qkv, 3 * C, M, C, 3 * C, 0, stream));
+        PDSC_TRY(P(PDSC_RANGE_QKV, qkv, (size_t)M * 3 * C));
         if (split) {
             PDSC_TRY(pdsc_pack_qkv_split(qkv, q_split, kv_tiles, bs, N, stream));
             PDSC_TRY(attention_split(msg, 0));
         } else
             PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+        PDSC_TRY(P(PDSC_RANGE_MESSAGE, msg, (size_t)M * C));
         PDSC_TRY(pdsc_linear(msg, C, W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), nullptr, 0, t64a, C / 2, M, C, C / 2, 1, stream));
+        PDSC_TRY(P(PDSC_RANGE_FC1, t64a, (size_t)M * (C / 2)));
         PDSC_TRY(pdsc_linear(t64a, C / 2, W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i), nullptr, 0, t64b, C / 2, M, C / 2, C / 2, 1, stream));
+        PDSC_TRY(P(PDSC_RANGE_FC2, t64b, (size_t)M * (C / 2)));
         PDSC_TRY(pdsc_linear(t64b, C / 2, W(PDSC_W_FC3_W, i), W(PDSC_W_FC3_B, i), featB, C, featA, C, M, C / 2, C, 0, stream));
+        PDSC_TRY(P(PDSC_RANGE_FEATURE, featA, (size_t)M * C));
     }
+    if (probe) return PDSC_OK;
     // pdsc_forward_testing_streams: everything after the encoder -- a strictly sequential chain of ~15 small, latency-bound
     // launches -- goes to the caller's second (high-priority) stream: with several forwards in flight its workgroups are then
     // dispatched ahead of the queued workgroups of another forward's attention launch instead of behind them.
@@ -591,6 +621,18 @@ extern "C" int pdsc_forward_testing_streams(const pdsc_config* cfg, const float*
     PDSC_REQUIRE(tail_stream && fork_event && join_event, "pdsc_forward_testing_streams: tail stream and both events are required");
     return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, final_trans, final_labels, nullptr, 0,
                        workspace, workspace_bytes, stream, num_corr, num_seeds_per_pair, n_min, tail_stream, fork_event, join_event);
+}
+
+// Range probe for layer_gemm = PDSC_LAYER_GEMM_H3 (fp16 hi/lo operands: every activation of the chain must stay below 65504): the
+// encoder once with the fp32 GEMMs, one launch per conv, and the largest |value| of every activation kind over all layers.
+extern "C" int pdsc_encoder_range_probe(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,
+                                        const float* src, const float* tgt, int bs, int N, int num_seeds, float* absmax,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    PDSC_REQUIRE(absmax, "pdsc_encoder_range_probe: absmax [PDSC_RANGE_NUM_KINDS] (device) required");
+    PDSC_TRY(launch_fill_u32((unsigned int*)absmax, 0u, PDSC_RANGE_NUM_KINDS, (hipStream_t)stream));
+    float dummy_T = 0.f;         // (outputs of the tail are not produced in probe mode; the pointers only pass the null checks)
+    return run_forward(0, cfg, wpack, wsplit, corr_pos, src, tgt, bs, N, num_seeds, &dummy_T, &dummy_T, nullptr, 0, workspace,
+                       workspace_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (unsigned int*)absmax);
 }
 
 extern "C" int pdsc_forward_validation(const pdsc_config* cfg, const float* wpack, const void* wsplit, const float* corr_pos,

@@ -243,7 +243,13 @@ __device__ __forceinline__ void compat_fast_tile(const float* __restrict__ pts, 
         tx[cp] = f32x2{b0[0], b1[0]}; ty[cp] = f32x2{b0[1], b1[1]}; tz[cp] = f32x2{b0[2], b1[2]};
     }
     unsigned tr[8][4];                            // mirrored tile: chunk of column m = rows (2rp, 2rp+1) packed in word rp
-    const f32x2 one2 = {1.0f, 1.0f}, ninv2 = {ninv, ninv}, zero2 = {0.f, 0.f};
+    // r04: NO operand selects on the packed fp32 instructions.  v_pk_*_f32 with a non-default op_sel / op_sel_hi (a scalar or an
+    // inline constant broadcast into both halves, which is what `f32x2{x, x} - v` compiles to) returned wrong lanes whenever the
+    // wave shared a CU with the split attention kernel (tools/pk_f32_repro.hip, profiles/r04_pk_f32_repro*.txt: 16-24 % of the
+    // launches; never with default selects).  Every broadcast therefore lives in a real register PAIR (materialised through an
+    // empty asm, so the compiler cannot fold it back into an operand select): constants once per lane, the row point once per row.
+    f32x2 one2 = {1.0f, 1.0f}, ninv2 = {ninv, ninv}, zero2 = {0.f, 0.f};
+    asm volatile("" : "+v"(one2), "+v"(ninv2), "+v"(zero2));
     const int colpos = j0 + 32 * (cj >> 2) + 8 * (cj & 3);                           // tile-order position of this lane's column chunk
     const int rowpos = i0 + 32 * (ri >> 2) + 8 * (ri & 3);
 #pragma unroll
@@ -254,14 +260,22 @@ __device__ __forceinline__ void compat_fast_tile(const float* __restrict__ pts, 
         const f32x4 ps1 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(r0 + 1));
         const f32x4 pt1 = *reinterpret_cast<const f32x4*>(pts + cf_point_slot(r0 + 1) + 4);
         unsigned d0[4], d1[4];
+        f32x2 bs[2][3], bt[2][3];                 // the two row points, every coordinate in both halves of a register pair
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                bs[rr][e] = f32x2{(rr ? ps1 : ps0)[e], (rr ? ps1 : ps0)[e]};
+                bt[rr][e] = f32x2{(rr ? pt1 : pt0)[e], (rr ? pt1 : pt0)[e]};
+                asm volatile("" : "+v"(bs[rr][e]), "+v"(bt[rr][e]));
+            }
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp) {
             f32x2 o[2];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const f32x4 ps = rr ? ps1 : ps0, pt = rr ? pt1 : pt0;
-                const f32x2 dx = f32x2{ps[0], ps[0]} - sx[cp], dy = f32x2{ps[1], ps[1]} - sy[cp], dz = f32x2{ps[2], ps[2]} - sz[cp];
-                const f32x2 ex = f32x2{pt[0], pt[0]} - tx[cp], ey = f32x2{pt[1], pt[1]} - ty[cp], ez = f32x2{pt[2], pt[2]} - tz[cp];
+                const f32x2 dx = bs[rr][0] - sx[cp], dy = bs[rr][1] - sy[cp], dz = bs[rr][2] - sz[cp];
+                const f32x2 ex = bt[rr][0] - tx[cp], ey = bt[rr][1] - ty[cp], ez = bt[rr][2] - tz[cp];
                 const f32x2 a = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
                 const f32x2 b = __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
                 const f32x2 ds = {__builtin_amdgcn_sqrtf(a[0]), __builtin_amdgcn_sqrtf(a[1])};

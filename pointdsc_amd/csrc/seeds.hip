@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
     __syncthreads();
     const int i0 = blockIdx.x * NMS2_ROWS + t, i1 = i0 + 256;
     const int r0 = min(i0, N - 1), r1 = min(i1, N - 1);
-    const f32x2 mx = {s[r0 * 3], s[r1 * 3]}, my = {s[r0 * 3 + 1], s[r1 * 3 + 1]}, mz = {s[r0 * 3 + 2], s[r1 * 3 + 2]};
+    // (scalar fp32 on purpose: packed fp32 with broadcast operand selects is not used anywhere in this library, pointdsc_amd/build.py)
+    const float mx0 = s[r0 * 3], my0 = s[r0 * 3 + 1], mz0 = s[r0 * 3 + 2], mx1 = s[r1 * 3], my1 = s[r1 * 3 + 1], mz1 = s[r1 * 3 + 2];
     const float c0 = c[r0], c1 = c[r1];
     bool ok0 = true, ok1 = true;
     const int n = j_end - j_begin;
@@ -68,11 +69,10 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
         const int jn = min(64, n - j0);
         for (int jj = 0; jj < jn; ++jj) {
             const float4 o = rec[j0 + jj];              // same address in every lane: LDS broadcast
-            const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-            const f32x2 dx = mx - ox, dy = my - oy, dz = mz - oz;
-            const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));   // norm3's radicand
-            ok0 = ok0 && ((c0 >= o.w) || (d2[0] >= radius2));
-            ok1 = ok1 && ((c1 >= o.w) || (d2[1] >= radius2));
+            const float dx0 = mx0 - o.x, dy0 = my0 - o.y, dz0 = mz0 - o.z, dx1 = mx1 - o.x, dy1 = my1 - o.y, dz1 = mz1 - o.z;
+            const float d20 = fmaf(dz0, dz0, fmaf(dy0, dy0, dx0 * dx0)), d21 = fmaf(dz1, dz1, fmaf(dy1, dy1, dx1 * dx1));   // norm3's radicand
+            ok0 = ok0 && ((c0 >= o.w) || (d20 >= radius2));
+            ok1 = ok1 && ((c1 >= o.w) || (d21 >= radius2));
         }
     }
     if (!ok0 && i0 < N) keys[(size_t)b * N + i0] = c0 * 0.0f;       // -0.0 for suppressed negatives, like torch

@@ -115,7 +115,8 @@ class PointDSC(nn.Module):
                 nn.init.constant_(m.bias, 0)
         # Not a reference constructor argument (the signature stays the reference's): arithmetic of the two
         # attention contractions.  "bf16x3" = split-precision bf16 MFMA (default; features within 5e-6 of fp32),
-        # "fp32" = exact fp32 MFMA, "bf16x3_all" = the point-wise GEMMs in split precision too (features within 2e-5).
+        # "fp32" = exact fp32 MFMA.  (Experiments builds of the library also take "bf16x3_all": the point-wise GEMMs in split
+        # precision too, features within 2e-5 -- an A/B record, rejected by the product library.)
         # Module attributes only -- neither the module nor the library reads the environment.  Set before calling forward.
         self.attention_precision = "bf16x3"
         # storage of the N x N spatial-consistency matrix between its build and the attention launches (split-precision
@@ -134,6 +135,7 @@ class PointDSC(nn.Module):
         self._wpack_key = None
         self._workspace: Optional[torch.Tensor] = None
         self._h3_range_checked = False
+        self.last_range_probe = None            # {activation kind: largest |value|} of the last pdsc_encoder_range_probe
         self._tail: Dict[int, tuple] = {}       # workspace slot -> (high-priority tail stream, fork event, join event): pipeline.InFlight(tail_streams=True)
         self._workspaces: Dict[int, torch.Tensor] = {}      # one per in-flight slot (pointdsc_amd.pipeline.InFlight); slot 0 = the plain call
         self._ws_slot = 0
@@ -143,7 +145,10 @@ class PointDSC(nn.Module):
         # reference post_refinement picks its threshold by exact equality with 0.10 (:415-418)
         refine_thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
         if self.attention_precision not in ATTENTION_PRECISIONS:
-            raise ValueError(f"attention_precision must be one of {sorted(ATTENTION_PRECISIONS)}, got {self.attention_precision!r}")
+            raise ValueError(f"attention_precision must be one of ['bf16x3', 'fp32'], got {self.attention_precision!r}")
+        if self.attention_precision == "bf16x3_all" and not _lib.load().pdsc_experiments_enabled():
+            raise ValueError('attention_precision "bf16x3_all" (all-split layer GEMMs, an A/B record) exists in experiments builds of the '
+                             "library only (python -m pointdsc_amd.build --experiments); the product accepts 'bf16x3' and 'fp32'")
         if self.compat_format not in COMPAT_FORMATS:
             raise ValueError(f"compat_format must be one of {sorted(COMPAT_FORMATS)}, got {self.compat_format!r}")
         if self.layer_gemm not in LAYER_GEMMS:
@@ -379,6 +384,11 @@ class PointDSC(nn.Module):
                     final_labels[idx, :ng] = r["final_labels"]
                 return {"final_trans": final_trans, "final_labels": final_labels, "M": None}
         num_seeds = int(n * self.ratio)                       # python double arithmetic, as the reference (:174)
+        if self.layer_gemm == "h3" and self.attention_precision != "fp32" and self.num_layers > 0:
+            self.packed_weights(dev)                           # (re)packs if needed and resets the flag below
+            if not self._h3_range_checked and self.layer_gemm == "h3":
+                self._h3_range_checked = True
+                self._h3_range_probe(corr_pos, src_keypts, tgt_keypts)      # first forward after packing: may switch to "f32"
         cfg = self._config()
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
@@ -422,18 +432,44 @@ class PointDSC(nn.Module):
                 rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
                 what = "pdsc_forward_validation"
         _lib.check(rc, what)
-        if self.layer_gemm == "h3" and not self._h3_range_checked and self.attention_precision != "fp32" and self.num_layers > 0:
-            # first forward after (re)packing the weights: the final features must be finite and far from the fp16 limit (one
-            # device->host sync, once per packing); otherwise this call and all later ones use the fp32 GEMMs
-            self._h3_range_checked = True
-            fmax = float(self.workspace_view("featA", bs, n)[: bs * n * 128].abs().max()) if counts is None else \
-                float(torch.nan_to_num(self.workspace_view("featA", bs, n)[: bs * n * 128].reshape(bs, n, 128)[:, : min(counts)], nan=float("inf")).abs().max())
-            if not fmax < 3.0e4:
-                warnings.warn(f"pointdsc_amd: activations reach {fmax:.3g}, outside the fp16 range of layer_gemm='h3'; "
-                              "re-running with layer_gemm='f32' (kept for this module)", RuntimeWarning)
-                self.layer_gemm = "f32"
-                return self._run(corr_pos, src_keypts, tgt_keypts, testing, counts)
         return {"final_trans": final_trans, "final_labels": final_labels, "M": M}
+
+    RANGE_KINDS = ("layer0", "PointCN", "q|k|v", "message", "fc_message hidden 1", "fc_message hidden 2", "feature")
+
+    def _h3_range_probe(self, corr_pos, src_keypts, tgt_keypts) -> None:
+        """layer_gemm = "h3" carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo: EVERY activation of the chain,
+        hidden ones included, must stay below 65504.  Once per weight packing, before the first forward: the encoder with the fp32
+        GEMMs, one launch per conv, and the largest |value| of every activation kind over all layers (pdsc_encoder_range_probe;
+        one device -> host copy of 8 floats).  Out of range (or NaN): warn and keep layer_gemm = "f32" for this module.
+        A heuristic, not a proof: it sees the first input only -- a later input with much larger activations is not re-checked
+        (set model.layer_gemm = "f32" yourself for checkpoints whose activations approach 1e4)."""
+        lib = _lib.load()
+        dev = corr_pos.device
+        bs, n = corr_pos.shape[0], corr_pos.shape[1]
+        num_seeds = max(int(n * self.ratio), 1)
+        cfg = self._config()
+        with torch.cuda.device(dev):
+            wpack = self.packed_weights(dev)
+            if self.layer_gemm != "h3":              # (the weight check at packing already fell back)
+                return
+            wsplit = self.split_weights(dev)
+            nbytes = int(lib.pdsc_workspace_bytes(C.byref(cfg), bs, n, num_seeds))
+            if nbytes == 0:
+                return                               # (the forward itself reports the unsupported size)
+            ws = self._get_workspace(nbytes, dev)
+            absmax = torch.zeros(8, device=dev, dtype=torch.float32)
+            rc = lib.pdsc_encoder_range_probe(C.byref(cfg), C.c_void_p(wpack.data_ptr()), C.c_void_p(wsplit.data_ptr()),
+                                              C.c_void_p(corr_pos.data_ptr()), C.c_void_p(src_keypts.data_ptr()),
+                                              C.c_void_p(tgt_keypts.data_ptr()), bs, n, num_seeds, C.c_void_p(absmax.data_ptr()),
+                                              C.c_void_p(ws.data_ptr()), nbytes, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pdsc_encoder_range_probe")
+        vals = absmax[: len(self.RANGE_KINDS)].tolist()
+        self.last_range_probe = dict(zip(self.RANGE_KINDS, vals))
+        bad = [(k, v) for k, v in zip(self.RANGE_KINDS, vals) if not v < 3.0e4]
+        if bad:
+            warnings.warn("pointdsc_amd: activations reach " + ", ".join(f"{v:.3g} ({k})" for k, v in bad) + ", outside the fp16 range of "
+                          "layer_gemm='h3'; using layer_gemm='f32' (kept for this module)", RuntimeWarning)
+            self.layer_gemm = "f32"
 
     def workspace_view(self, name: str, bs: int, n: int, dtype=torch.float32) -> torch.Tensor:
         """Intermediate of the LAST forward (parity tests): flat view into the workspace from `name` on."""

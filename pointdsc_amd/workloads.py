@@ -47,6 +47,16 @@ WORKLOADS: Dict[str, dict] = {
     "lomatch_n10000_b8": dict(baseline_config=4, num_corr=10000, global_batch=8, model=BASE_MODEL, wseed=7,
                               logit_shift=None, pair=dict(inlier_ratio=0.15, noise=0.01, scale=3.0), seed0=4000,
                               label="3DLoMatch-like synthetic correspondences (BASELINE.json configs[4])"),
+    # the reference's real KITTI evaluation size: evaluation/test_KITTI.py:120 (num_node=12000), :166-170 (sigma_d 1.2, threshold 0.6)
+    "kitti_n12000_b4": dict(baseline_config=None, num_corr=12000, global_batch=4, model=KITTI_MODEL, wseed=8,
+                            logit_shift=None, logit_sign=-1.0, pair=dict(inlier_ratio=0.25, noise=0.1, scale=60.0), seed0=5000,
+                            label="KITTI-like synthetic correspondences at the reference's evaluation size (evaluation/test_KITTI.py:120: "
+                                  "N=12000, sigma_d=1.2 m, inlier_threshold=0.6 m)"),
+    # the reference's multiway registration feeds 20000 correspondences per pair (multiway/test_multi_ate.py:245)
+    "multiway_n20000_b1": dict(baseline_config=None, num_corr=20000, global_batch=1, model=BASE_MODEL, wseed=7,
+                               logit_shift=None, pair=dict(inlier_ratio=0.15, noise=0.01, scale=3.0), seed0=6000,
+                               label="3DMatch-like synthetic correspondences at the multiway evaluation size "
+                                     "(multiway/test_multi_ate.py:245: N=20000)"),
 }
 DEFAULT = "n5000_b32"
 

@@ -1214,7 +1214,9 @@ def _bench_model(name):
 @pytest.mark.parametrize("name,bs", [("n1000_b1", 1),
                                      ("n5000_b32", 4), ("n5000_b32", 8), ("n5000_b32", 16), ("n5000_b32", 32),
                                      ("kitti_n5000_b16", 2), ("kitti_n5000_b16", 4), ("kitti_n5000_b16", 8), ("kitti_n5000_b16", 16),
-                                     ("lomatch_n10000_b8", 1), ("lomatch_n10000_b8", 2), ("lomatch_n10000_b8", 4), ("lomatch_n10000_b8", 8)])
+                                     ("lomatch_n10000_b8", 1), ("lomatch_n10000_b8", 2), ("lomatch_n10000_b8", 4), ("lomatch_n10000_b8", 8),
+                                     # the reference's real evaluation sizes (evaluation/test_KITTI.py:120, multiway/test_multi_ate.py:245)
+                                     ("kitti_n12000_b4", 4), ("kitti_n12000_b4", 1), ("multiway_n20000_b1", 1)])
 def test_bench_workload_matches_reference_golden(name, bs):
     """THE TIMED PATH: the first bs pairs of a bench workload (bs = the per-GPU share on 8/4/2/1 GPUs; bs = global batch
     is exactly what `bench.py --config name` times on one GPU, same pairs, same weights, same launch plans) against
@@ -1236,12 +1238,25 @@ def test_bench_workload_matches_reference_golden(name, bs):
     assert flips == 0, f"{flips} label flips vs the reference"
     assert bool((dT < 1e-4).all()), dT.tolist()            # all golden pairs of the bench workloads are stable in the reference
     # ... and EVERY pair of the batch against the census fixture (reference fp32 and fp64 outputs of the same pairs)
+    if not (GOLDEN / f"census_{name}.npz").exists():       # (the large-N workloads have the golden pairs only)
+        return
     cfx = _census_fixture(name)
     ok, d32, dbest, f32, which = _census_judge(res["final_trans"], res["final_labels"], cfx, n)
-    ref_self = np.abs(cfx["ref32_final_trans"][:bs].astype(np.float64) - cfx["ref64_final_trans"][:bs]).max(axis=(1, 2))
-    ill = (ref_self >= 1e-4) | (cfx["ref32_final_labels_bits"][:bs] != cfx["ref64_final_labels_bits"][:bs]).any(axis=1)
-    edge = [i for i in np.flatnonzero(~ok.numpy()).tolist() if not ill[i]]      # (see test_parity_census)
-    assert len(edge) <= 1 and all(float(d32[i]) < 2e-4 * w["pair"]["scale"] and int(f32[i]) <= 2 for i in edge), [(i, float(d32[i]), int(f32[i])) for i in edge]
+    # a pair outside the fp32 contract needs a recorded discrete cause (test_parity_census; tools/parity_census.py:explain)
+    mod = _census_module()
+    ixp = GOLDEN / f"census_internals_{name}.npz"
+    strict = (d32 < 1e-4) & (f32 == 0)
+    if not bool(strict.all()):
+        ix = np.load(ixp, allow_pickle=False)
+        dec = mod.decisions(model, bs, n)
+        ref_self = np.abs(cfx["ref32_final_trans"][:bs].astype(np.float64) - cfx["ref64_final_trans"][:bs]).max(axis=(1, 2))
+        ill = (ref_self >= 1e-4) | (cfx["ref32_final_labels_bits"][:bs] != cfx["ref64_final_labels_bits"][:bs]).any(axis=1)
+        l32 = np.unpackbits(cfx["ref32_final_labels_bits"][:bs], axis=1)[:, :n]
+        for i in np.flatnonzero(~strict.numpy()).tolist():
+            flipped = np.flatnonzero((res["final_labels"][i].cpu().numpy() > 0) != (l32[i] > 0))
+            okx, why = mod.explain(i, {k: v[i] for k, v in dec.items()}, ix, {k: batch[k][i] for k in ("src_keypts", "tgt_keypts")},
+                                   float(w["model"]["inlier_threshold"]), float(w["pair"]["scale"]), flipped if float(d32[i]) < 1e-4 else None)
+            assert okx or ill[i], (i, float(d32[i]), int(f32[i]), why)
     # every pair of the batch, golden or not, must register (well-conditioned workload) and be a rigid motion
     T = res["final_trans"].cpu().double()
     assert (T[:, :3, :3] @ T[:, :3, :3].transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5
@@ -1270,49 +1285,46 @@ def _census_judge(trans, labels, fx, n, first=0):
     return mod.judge(trans, labels, fx, n, first)
 
 
+def _census_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("parity_census", ROOT / "tools" / "parity_census.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 @pytest.mark.parametrize("gemm", ["h3", "f32"])
 @pytest.mark.parametrize("name,step", [("n5000_b32", 32), ("n5000_b32", 4), ("kitti_n5000_b16", 16), ("kitti_n5000_b16", 2),
                                        ("lomatch_n10000_b8", 8), ("lomatch_n10000_b8", 1), ("n1000_b1", 1), ("n1000_b1", 16)])
 def test_parity_census(name, step, gemm):
-    """Parity census (r03): 256 seeded pairs per workload family (64 at N = 10 000), pair i = the bench workload's pair i,
-    run in batches of the bench's global batch and of its 8-GPU share, with both layer-GEMM arithmetics: EVERY pair must
-    meet the contract against the unmodified reference (oracle/make_census_goldens.py: its fp32 output, or its fp64 output
-    where the reference itself lands on another hypothesis) -- no 1e-3 escape, no seed selection."""
+    """Parity census: 256 seeded pairs per workload family (64 at N = 10 000), pair i = the bench workload's pair i, run in batches
+    of the bench's global batch and of its 8-GPU share, with both layer-GEMM arithmetics.  Every pair must meet BASELINE.json's
+    contract against the unmodified reference's fp32 output (labels bit-exact, R/t within 1e-4).  A pair outside it passes ONLY
+    with a recorded discrete cause, checked against what the reference itself decided on that pair
+    (tests/golden/census_internals_<name>.npz, oracle/make_census_internals.py; rules in tools/parity_census.py:explain):
+      * the reference does not reproduce itself there (its own fp32 and fp64 runs differ in pose >= 1e-4 or in the label mask), or
+      * hypothesis tie: another hypothesis chosen, within one vote of the winner in the reference's votes AND in this run's, or
+      * refinement: same hypothesis, the inlier-count sequence leaves the reference's by exactly one vote, or
+      * kNN tie: the seed's 40-neighbour set differs and the reference recorded that seed's top-k boundary gap at round-off level, or
+      * label edge: flipped labels sit within 8 ulps of the threshold under the reference's hypothesis.
+    No allowance in number or size: one pair without such a record fails the test.  The records of the excused pairs are printed
+    (and committed under profiles/ by tools/parity_census.py)."""
     model, _ = _bench_model(name)
     fx = _census_fixture(name)
-    n = workloads.WORKLOADS[name]["num_corr"]
-    total = fx["ref32_final_trans"].shape[0]
-    model.layer_gemm = gemm
-    T, L = [], []
+    chk = sum(float(workloads.batch(name, 0, 1)[k][0].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts"))
+    assert abs(chk - float(fx["input_checksum"][0])) < 1e-6, "synthetic inputs differ from the fixture's"
+    mod = _census_module()
     try:
-        for first in range(0, total, step):
-            batch = workloads.batch(name, first, min(step, total - first))
-            if first == 0:
-                chk = sum(float(batch[k][0].double().sum()) for k in ("corr_pos", "src_keypts", "tgt_keypts"))
-                assert abs(chk - float(fx["input_checksum"][0])) < 1e-6, "synthetic inputs differ from the fixture's"
-            res = _forward(model, batch)
-            T.append(res["final_trans"].cpu())
-            L.append(res["final_labels"].cpu())
+        rep, _m = mod.run_family(name, [step], layer_gemm=gemm, model=model)
     finally:
         model.layer_gemm = LAYER_GEMM_DEFAULT
-    ok, d32, dbest, f32, which = _census_judge(torch.cat(T), torch.cat(L), fx, n)
-    bad = np.flatnonzero(~ok.numpy()).tolist()
-    # pairs on which the reference does not reproduce ITS OWN pose between fp32 and fp64 (>= 1e-4: the hypothesis ranking sits on
-    # a tie that round-off decides, models/PointDSC.py:325-335) have no well-defined target; everywhere else the contract holds
-    # pair by pair, except for the measured tolerance edge: a few pairs per 256 whose near-tie falls the other way under this
-    # implementation's round-off although the reference's two runs happened to agree (DESIGN.md section 6) -- bounded here in
-    # number (1.5 %) and size (5e-4, labels within 2 flips), and listed by tools/parity_census.py under profiles/.
-    ref_self = np.abs(fx["ref32_final_trans"].astype(np.float64) - fx["ref64_final_trans"]).max(axis=(1, 2))
-    ill = (ref_self >= 1e-4) | (fx["ref32_final_labels_bits"] != fx["ref64_final_labels_bits"]).any(axis=1)     # pose or mask
-    edge = [i for i in bad if not ill[i]]
-    print(f"{name} x{step} {gemm}: median dT {float(dbest.median()):.1e} max {float(dbest.max()):.1e}; matched on the fp64 reference: "
-          f"{np.flatnonzero(which.numpy() == 1).tolist()}; outside the contract: {bad} of which the reference itself is ill-posed on "
-          f"{[i for i in bad if ill[i]]}; tolerance edge: {[(i, float(d32[i]), int(f32[i])) for i in edge]}")
-    assert len(edge) <= max(1, int(np.ceil(0.015 * total))), edge
-    # size of an edge case: the pose moves with the handful of correspondences that sit on the inlier threshold, i.e. with the
-    # scene scale (3 m: < 6e-4 observed 1.6e-4; KITTI-like 60 m: < 1.2e-2 observed 6.5e-4)
-    scale = workloads.WORKLOADS[name]["pair"]["scale"]
-    assert all(float(d32[i]) < 2e-4 * scale and int(f32[i]) <= 2 for i in edge), [(i, float(d32[i]), int(f32[i])) for i in edge]
+    r = rep[step]
+    assert r["unexcused"] is not None, f"tests/golden/census_internals_{name}.npz is missing"
+    print(f"{name} x{step} {gemm}: median dT {r['median_dT']:.1e}; outside the fp32 contract {r['outside_fp32_contract']}; "
+          f"reference not self-consistent on {r['reference_not_self_consistent']}")
+    for d in r["outside_fp32_contract_detail"]:
+        print("   ", json.dumps(d))
+    assert r["unexcused"] == [], [d for d in r["outside_fp32_contract_detail"] if d["pair"] in r["unexcused"]]
 
 
 @pytest.mark.parametrize("fmt", ["f32", "u16"])
@@ -1814,6 +1826,53 @@ def test_ragged_batch_padded_tensors_and_count_list():
     assert torch.equal(u["final_trans"], r["final_trans"]) and torch.equal(u["final_labels"], r["final_labels"])
 
 
+def test_ragged_batch_with_pairs_of_at_most_k_rows():
+    """The reference clamps the neighbour count per pair, k = min(k, num_corr - 1) (models/PointDSC.py:250); one launch has one k.
+    A batch that mixes ordinary pairs with pairs of no more than k = 40 correspondences therefore runs those as their own calls
+    (model._ragged_groups): every pair's result is still that of its own call -- bit for bit for the short ones, which ARE their own
+    call -- and the C entry point refuses such a batch instead of reading neighbour lists it never selected."""
+    import ctypes as C
+    model, _ = _bench_model("n5000_b32")
+    sizes = (100, 30, 257, 41, 40)
+    pairs = _ragged_pairs(sizes, 31, inlier_ratio=0.5)
+    with torch.no_grad():
+        got = model(_as_lists(pairs))
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(got["final_trans"]).all())
+    for i, p in enumerate(pairs):
+        one = _forward(model, p)
+        assert got["final_labels"][i].shape == (sizes[i],)
+        if sizes[i] <= 40:
+            assert torch.equal(got["final_trans"][i], one["final_trans"][0]) and torch.equal(got["final_labels"][i], one["final_labels"][0])
+        else:
+            assert int((got["final_labels"][i] != one["final_labels"][0]).sum()) == 0
+            assert float((got["final_trans"][i] - one["final_trans"][0]).abs().max()) < 1e-4
+    # the padded-tensor form of the same batch
+    n_max = max(sizes)
+    data = {"testing": True, "num_corr": list(sizes)}
+    for k, wdt in (("corr_pos", 6), ("src_keypts", 3), ("tgt_keypts", 3)):
+        t = torch.zeros(len(sizes), n_max, wdt)
+        for i, p in enumerate(pairs):
+            t[i, : sizes[i]] = p[k][0]
+        data[k] = g(t)
+    with torch.no_grad():
+        pad = model(data)
+    assert torch.equal(pad["final_trans"], got["final_trans"])
+    # C ABI: n_min <= k is refused
+    lib = _lib.load()
+    cfg = model._config()
+    bs, n, S = 2, 100, 10
+    z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=DEV, dtype=dt)
+    cnt, sds = torch.tensor([100, 30], device=DEV, dtype=torch.int32), torch.tensor([10, 3], device=DEV, dtype=torch.int32)
+    nb = int(lib.pdsc_workspace_bytes(C.byref(cfg), bs, n, S))
+    ws = torch.empty(nb, device=DEV, dtype=torch.uint8)
+    T, L = z(bs, 4, 4), z(bs, n)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.pdsc_forward_testing_ragged(C.byref(cfg), P(model.packed_weights()), P(model.split_weights()), P(z(bs, n, 6)), P(z(bs, n, 3)),
+                                         P(z(bs, n, 3)), bs, n, S, P(cnt), P(sds), 30, P(T), P(L), P(ws), nb, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and "clamps k per pair" in _lib.last_error()
+
+
 def test_ragged_batch_rejections():
     model, _ = _bench_model("n5000_b32")
     pairs = _ragged_pairs((300, 400), 3)
@@ -1932,22 +1991,37 @@ def test_forwards_in_flight_stay_exact_under_load(mode):
 
 def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():
     """layer_gemm = "h3" carries the operands of the fc_message / PointCN GEMMs as fp16 hi + lo (|x| < 65504).  A checkpoint whose
-    folded weights or activations leave that range must not produce inf / NaN silently: the module checks the packed weights
-    and, on the first forward after packing, the final features, warns and continues with the fp32 GEMMs."""
+    folded weights or activations -- HIDDEN ones included -- leave that range must not produce inf / NaN silently: the module
+    checks the packed weights and, before the first forward after packing, every activation kind of every layer
+    (pdsc_encoder_range_probe), warns and continues with the fp32 GEMMs."""
     kw = dict(KW, num_layers=2)
     pair = synthetic.make_pair(400, inlier_ratio=0.4, seed=3)
-    for scale_key, scale in (("encoder.layer0.weight", 3.0e5), ("encoder.blocks.PointCN_layer_1.0.weight", 1.0e6)):
+    # (5e4: the folded weights stay below the weight check's 3e4, the first hidden activation of fc_message does not)
+    hidden_only = {"encoder.blocks.NonLocal_layer_0.fc_message.0.weight": 5.0e4, "encoder.blocks.NonLocal_layer_0.fc_message.0.bias": 5.0e4,
+                   "encoder.blocks.NonLocal_layer_0.fc_message.3.weight": 2.0e-5}
+    for scales, kind in (({"encoder.layer0.weight": 3.0e5}, None), ({"encoder.blocks.PointCN_layer_1.0.weight": 1.0e6}, None),
+                         (hidden_only, "fc_message hidden 1")):
         model = PointDSC(**kw)
         sd = synthetic.make_state_dict(model.state_dict(), seed=2)
-        sd[scale_key] = sd[scale_key] * scale
+        for key, scale in scales.items():
+            sd[key] = sd[key] * scale
         model.load_state_dict(sd)
         model = model.eval().to(DEV)
         assert model.layer_gemm == "h3"
         with pytest.warns(RuntimeWarning, match="fp16 range"):
             res = _forward(model, pair)
         assert model.layer_gemm == "f32" and bool(torch.isfinite(res["final_trans"]).all())
+        if kind is not None:
+            # only a hidden activation leaves the range: the final features (all the r03 guard looked at) stay small
+            probe = model.last_range_probe
+            assert probe[kind] > 65504.0 and probe["feature"] < 3.0e4 and probe["message"] < 3.0e4, probe
         again = _forward(model, pair)
         assert bool(torch.isfinite(again["final_trans"]).all())
+    # ... and a well-scaled checkpoint stays on H3, its probe inside the range
+    model, _ = _bench_model("n5000_b32")
+    model.invalidate_packed_weights()
+    _forward(model, workloads.batch("n5000_b32", 0, 1))
+    assert model.layer_gemm == "h3" and max(model.last_range_probe.values()) < 3.0e4, model.last_range_probe
 
 
 @pytest.mark.parametrize("gemm,fmt", [("h3", "u16"), ("f32", "f32")])

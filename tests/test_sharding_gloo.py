@@ -159,3 +159,23 @@ def test_eight_rank_bench_rehearsal_on_one_gpu(config, expect_per_rank):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 8 and line["config"]["pairs_per_gpu"] == expect_per_rank and line["scaling"] == "strong"
     assert line["value"] > 0 and line["check"]["ok"] is not False and line["in_flight"] == 2
+
+
+@pytest.mark.gpu
+def test_one_rank_bench_through_rccl():
+    """`bench.py --gpus 1` launched the way the driver launches the N > 1 runs (torch.distributed.run, --backend nccl = RCCL) with ONE
+    rank: the RCCL bring-up the multi-GPU runs depend on -- init_process_group(device_id=...), the barriers of the timing fence and
+    an all_gather of the pose payload -- runs on the one-GPU box (world sizes > 1 need the 8-GPU node, tools/scale_run.sh)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--backend", "nccl",
+           "--config", "n5000_b32", "--pairs-per-gpu", "4", "--no-cpu-baseline", "--sustain-seconds", "0", "--settle-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["check"]["ok"] is not False
+    assert line["rccl_world1_probe"] == {"backend": "nccl", "world": 1, "all_gather_bitwise_equal": True}

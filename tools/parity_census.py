@@ -63,11 +63,15 @@ def set_hash(idx) -> int:
     return h
 
 
-# A seed's neighbour set is "decided by round-off" when the reference's own gap between the last neighbour kept and the first
-# one left out (distances 2 - 2<f_i,f_j> of unit features, models/common.py:60-68) is below this: 4 x the 5e-6 to which this
-# implementation's features follow the reference's fp32 features (the reference's own fp32 and fp64
-# features differ by ~1e-6).  The recorded gap of every excused pair is printed and stored, not just compared.
-KNN_TIE_GAP = 2e-5
+# A seed's neighbour set is "decided by round-off" when the reference's own gap between the last neighbour kept and the first one
+# left out (distances 2 - 2<f_i,f_j> of unit features, models/common.py:60-68) is below this.  2e-6 = 8 quanta of that fp32
+# expression near its operand 2.0 (2^-22 each), ~3 sigma of the rounding noise of a 128-term fp32 dot product of unit vectors
+# (sqrt(128) * 2^-24 = 6.7e-7): below it the reference's OWN ranking depends on its summation order (its CPU and CUDA paths, or its
+# fp32 and fp64 runs, already disagree there).  The recorded gap of every excused pair is printed and stored, not just compared
+# (measured on the census: excused pairs sit at 0 ... 1.2e-6; the median gap over ALL seeds of these seeded-weight workloads is
+# 4.8e-7 at N = 5000 -- the random-init feature space is nearly collapsed, which is why neighbour sets, and through them the
+# per-seed hypotheses, are round-off-level arbitrary in the reference too).
+KNN_TIE_GAP = 2e-6
 
 
 def knn_tie(dec, ix, i: int, corr: int):
@@ -142,16 +146,17 @@ def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None)
     return False, f"same hypothesis, same refinement sequence, neighbour set {'equal' if differs is not None else 'not recorded'}: no recorded discrete cause"
 
 
-def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0, attention_precision=None):
+def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0, attention_precision=None, model=None):
     fx = np.load(ROOT / "tests" / "golden" / f"census_{name}.npz", allow_pickle=False)
     ixp = ROOT / "tests" / "golden" / f"census_internals_{name}.npz"
     ix = np.load(ixp, allow_pickle=False) if ixp.exists() else None
     w = workloads.WORKLOADS[name]
     n = w["num_corr"]
     total = fx["ref32_final_trans"].shape[0] if pairs <= 0 else min(pairs, fx["ref32_final_trans"].shape[0])
-    model = PointDSC(**w["model"])
-    model.load_state_dict(workloads.state_dict(name, model.state_dict()))
-    model = model.eval().cuda()
+    if model is None:
+        model = PointDSC(**w["model"])
+        model.load_state_dict(workloads.state_dict(name, model.state_dict()))
+        model = model.eval().cuda()
     if compat_format:
         model.compat_format = compat_format
     if layer_gemm:

@@ -12,9 +12,12 @@
 //     slp      score_kernel<0,1> built with default flags: the compiler's packed form (the r03 failure)
 //     pk_asm   hand-written v_pk_*_f32, operands broadcast into register pairs first: packed math, NO op_sel
 //     pk_opsel hand-written v_pk_*_f32 reading the loaded point registers through op_sel / op_sel_hi: the compiler's operand form
+//     pk_opsel_mov  the same op_sel forms on VALU-written copies of the point (v_mov first): op_sel without a VMEM-written source
 // Hogs: none | mfma (bf16 32x32x16 chains, the matrix pipe + power) | valu (packed fma chains) | mem (HBM stream) | lds (ds_read_b128)
 //       | att (the product's own split-precision attention launch -- LDS-DMA staging, s_setprio -- on random operands, through the C ABI of
-//       libpointdsc_hip.so, if the path is given) | att32 (the exact-fp32 attention launch: fp32 MFMA, ordinary LDS staging).
+//       libpointdsc_hip.so, if the path is given) | att32 (the exact-fp32 attention launch: fp32 MFMA, ordinary LDS staging)
+//       | perm (v_permlane32_swap chains) | exp (v_exp_f32 chains) | ldsdma (buffer_load ... lds streams) | bar (s_barrier + LDS traffic) | cvt (v_cvt_pk_bf16_f32):
+//       the ingredients of the split attention kernel one at a time.
 // A mismatch table per (form, hog) goes to stdout; exit code 0 always (it is a probe, not a test).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -65,6 +68,15 @@ __global__ __launch_bounds__(256) void score_pk_asm_kernel(const float* __restri
         f2 pxy, pz_, qxy, qz_;
         pxy.x = src[i * 3]; pxy.y = src[i * 3 + 1]; pz_.x = src[i * 3 + 2]; pz_.y = 0.f;
         qxy.x = tgt[i * 3]; qxy.y = tgt[i * 3 + 1]; qz_.x = tgt[i * 3 + 2]; qz_.y = 0.f;
+        if constexpr (OPSEL == 2) {
+            // copies written by the VALU: the packed instructions below then never read a register a VMEM load wrote
+            f2 a, b, c, d;
+            asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                         : "=&v"(a.x), "=&v"(a.y), "=&v"(b.x), "=&v"(b.y) : "v"(pxy.x), "v"(pxy.y), "v"(pz_.x), "v"(pz_.y));
+            asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                         : "=&v"(c.x), "=&v"(c.y), "=&v"(d.x), "=&v"(d.y) : "v"(qxy.x), "v"(qxy.y), "v"(qz_.x), "v"(qz_.y));
+            pxy = a; pz_ = b; qxy = c; qz_ = d;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             f2 r[3];
@@ -157,6 +169,72 @@ __global__ __launch_bounds__(256) void hog_lds(float* out, int iters) {
         const float4 v = sm[idx & 2047];
         s += v.x + v.w;
         idx += 257;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void hog_perm(float* out, int iters) {       // v_permlane32_swap chains (the attention kernel's half_max / chunk_for_store)
+    unsigned a = threadIdx.x * 2654435761u, b = threadIdx.x ^ 0x9e3779b9u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            a = r[0] + 1u; b = r[1] ^ a;
+        }
+    }
+    if (a == 0x12345u && b == 0x54321u) out[0] = 1.f;
+}
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void hog_cvt(float* out, int iters) {        // v_cvt_pk_bf16_f32 chains (the attention kernel's P hi/lo split)
+    f2 x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = f2{0.001f * (threadIdx.x + j), 1.5f + j};
+    unsigned acc = 0u;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf16x2v h = __builtin_convertvector(x[j], bf16x2v);
+            const unsigned u = __builtin_bit_cast(unsigned, h);
+            acc ^= u;
+            x[j].x = __builtin_bit_cast(float, u << 16) * 1.0001f;
+            x[j].y = __builtin_bit_cast(float, u & 0xffff0000u) * 0.9999f;
+        }
+    if (acc == 0x12345u) out[0] = 1.f;
+}
+__global__ __launch_bounds__(256) void hog_exp(float* out, int iters) {        // transcendental unit
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = -0.001f * (threadIdx.x + j);
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_exp2f(x[j]) - 1.0f;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void hog_ldsdma(const float* __restrict__ buf, size_t bytes, float* out, int iters) {     // buffer_load ... lds (LDS-DMA)
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][4096];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+    int off = (blockIdx.x * 4 + wave) * 4096;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage[wave] + j * 1024), 16, lane * 16, off + j * 1024, 0, 0);
+        off = (off + 1048576) & 0x3fffffff;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (stage[wave][lane] == 77 && iters < 0) out[0] = 1.f;
+}
+__global__ __launch_bounds__(256) void hog_bar(float* out, int iters) {        // barriers + ds_read/ds_write traffic
+    __shared__ float sm[1024];
+    float s = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        sm[(threadIdx.x + it) & 1023] = s + it;
+        __syncthreads();
+        s += sm[(threadIdx.x * 7 + it) & 1023];
+        __syncthreads();
     }
     if (s == 123.456f) out[0] = s;
 }
@@ -271,10 +349,10 @@ int main(int argc, char** argv) {
         }
     }
 
-    const char* forms[] = {"scalar", "slp", "pk_asm", "pk_opsel"};
-    const char* hogs[] = {"none", "mfma", "valu", "mem", "lds", "mfma+mem", "att", "att32"};
+    const char* forms[] = {"scalar", "slp", "pk_asm", "pk_opsel", "pk_opsel_mov"};
+    const char* hogs[] = {"none", "mfma", "valu", "mem", "lds", "mfma+mem", "att", "att32", "perm", "exp", "ldsdma", "bar", "cvt"};
     std::vector<int> got((size_t)LAUNCHES * S);
-    for (int hg = 0; hg < 8; ++hg) {
+    for (int hg = 0; hg < 13; ++hg) {
         if ((hg == 6 && !att) || (hg == 7 && !att32)) continue;
         if (only) {      // exact token match in the comma list
             const size_t L = strlen(hogs[hg]);
@@ -283,7 +361,7 @@ int main(int argc, char** argv) {
                 if ((q == only || q[-1] == ',') && (q[L] == 0 || q[L] == ',')) { hit = true; break; }
             if (!hit) continue;
         }
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < 5; ++f) {
             long bad_launches = 0, bad_seeds = 0, bad_odd = 0, short_votes = 0, over_votes = 0, launches = 0;
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -295,6 +373,11 @@ int main(int argc, char** argv) {
                 if (hg == 2) hipLaunchKernelGGL(hog_valu, dim3(512), dim3(256), 0, s_hog[0], dout, 6000);
                 if (hg == 3 || hg == 5) hipLaunchKernelGGL(hog_mem, dim3(1024), dim3(256), 0, s_hog[1], (const pdsc::f32x4*)dbig, big / 16, dout);
                 if (hg == 4) hipLaunchKernelGGL(hog_lds, dim3(512), dim3(256), 0, s_hog[0], dout, 60000);
+                if (hg == 8) hipLaunchKernelGGL(hog_perm, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 9) hipLaunchKernelGGL(hog_exp, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 10) hipLaunchKernelGGL(hog_ldsdma, dim3(512), dim3(256), 0, s_hog[0], (const float*)dbig, big, dout, 40);
+                if (hg == 12) hipLaunchKernelGGL(hog_cvt, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 11) hipLaunchKernelGGL(hog_bar, dim3(512), dim3(256), 0, s_hog[0], dout, 1500);
                 if (hg == 7 && att32(a32qkv, a32compat, ald, amsg, a32scr, a32scr_b, ABS, AN, 0, s_hog[0]) != 0) { fprintf(stderr, "fp32 attention hog failed\n"); att32 = nullptr; break; }
                 if (hg == 6 && att(aq, akv, (const unsigned short*)acompat, ald, amsg, ascr, ascr_b, ABS, AN, 0, s_hog[0]) != 0) { fprintf(stderr, "attention hog failed\n"); att = nullptr; break; }
                 for (int l = 0; l < LAUNCHES; ++l) {
@@ -304,6 +387,7 @@ int main(int argc, char** argv) {
                     if (f == 1) hipLaunchKernelGGL((pdsc::score_kernel<0, 1>), grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S, (const int*)nullptr, (float*)nullptr);
                     if (f == 2) hipLaunchKernelGGL(score_pk_asm_kernel<0>, grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S);
                     if (f == 3) hipLaunchKernelGGL(score_pk_asm_kernel<1>, grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S);
+                    if (f == 4) hipLaunchKernelGGL(score_pk_asm_kernel<2>, grid, dim3(256), 0, s_test, dT, dsrc, dtgt, thr2, c, N, S);
                 }
                 CK(hipMemcpyAsync(got.data(), dcounts, got.size() * 4, hipMemcpyDeviceToHost, s_test));
                 CK(hipStreamSynchronize(s_test));
