@@ -490,7 +490,7 @@ def main():
         # 32 intra-op threads is the fastest setting measured on the 256-core GPU box (16: 0.42, 32: 0.59, 64: 0.33,
         # 128: 0.19 pairs/s; 256 threads did not finish 3 pairs in 240 s), so that is what the baseline gets
         cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
-        n_cpu = args.cpu_pairs or {1000: 64, 5000: 6, 10000: 2}.get(N, 4)
+        n_cpu = args.cpu_pairs or {1000: 64, 5000: 6, 10000: 2}.get(N, 1 if N > 10000 else 4)
         n_chk = 0 if args.no_check else min(B, args.check_pairs if N <= 5000 else 1)
         log(f"CPU baseline: {n_cpu} pair(s), {cores} threads (cap {args.cpu_timeout:.0f}s); exact oracle on {n_chk} pair(s) for the check")
         cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-worker", "--config", args.config,

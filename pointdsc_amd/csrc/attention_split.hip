@@ -272,12 +272,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const int csw = C16 ? (l31 >> 2) & 3 : ((wave * 32 + l31) >> 1) & 7;
     constexpr float C16_INV = 1.0f / 65535.0f;      // 65535 * fl(1/65535) == 1.0f exactly (and 0 stays 0)
     // unorm16 -> f32 of the 4 keys of group g (registers 4g..4g+3): words 2(g&1), 2(g&1)+1 of 16-B chunk 2h + (g>>1)
+    // (two values per v_pk_mul_f32, the scale in a real register pair: packed fp32 with DEFAULT operand selects only -- the
+    //  broadcast-select form is not used anywhere in this library, pointdsc_amd/build.py; the pairing is worth 1-2 % of the launch)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 c16_inv2 = {C16_INV, C16_INV};
+    asm volatile("" : "+v"(c16_inv2));
     auto c16_group = [&](const unsigned (&w)[8], int g, float (&cc)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned word = w[2 * g + (e >> 1)];
-            cc[e] = (float)((e & 1) ? (word >> 16) : (word & 0xffffu)) * C16_INV;
-        }
+        const unsigned w0 = w[2 * g], w1 = w[2 * g + 1];
+        const f32x2 a = f32x2{(float)(w0 & 0xffffu), (float)(w0 >> 16)} * c16_inv2;
+        const f32x2 b = f32x2{(float)(w1 & 0xffffu), (float)(w1 >> 16)} * c16_inv2;
+        cc[0] = a[0]; cc[1] = a[1]; cc[2] = b[0]; cc[3] = b[1];
     };
     auto c16_load = [&](const unsigned char* crow, int half, unsigned (&w)[8]) {   // half 0: groups 0,1; half 1: groups 2,3
         const u32x4 v = *reinterpret_cast<const u32x4*>(crow + (((2 * h + half) ^ csw) << 4));
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         //  wasted work that nothing reads -- cheaper than a second code path, which makes the register allocator keep
         //  copies of the 64 accumulator registers.)
         float psum = 0.f;
-        bf16x8 ph[2], pl[2];
+        u32x4 phw[2], plw[2];                    // P hi / lo as packed bf16 pairs: word w of operand j = keys (2w, 2w+1) of its 8
         {
             const unsigned char* K = Ks + (st ^ 1) * SPL_K_BYTES;
             // fragments one step ahead of their MFMAs, and the steps pinned in source order: with the chunk-major image every
@@ -422,14 +426,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
                 if (j < DMA_SLOTS) dma_slot(kt, st, j);
-#pragma unroll
-                for (int r = 2 * j; r < 2 * j + 2; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(tl[r]);
-                    psum += p;
-                    __bf16 hi, lo;
-                    split_bf16(p, hi, lo);
-                    ph[r >> 3][r & 7] = hi;
-                    pl[r >> 3][r & 7] = lo;
+                {
+                    // p values 2j, 2j+1 = one 32-bit word of the P operands: split as a PAIR (split_layout.h split_bf16 arithmetic:
+                    // hi = bf16(p), lo = bf16(p - hi), round to nearest even) -- one v_cvt_pk_bf16_f32 per plane and pair, where the
+                    // element-wise form converted every hi twice (16 of the loop's ~130 vector instructions per tile)
+                    const float p0 = __builtin_amdgcn_exp2f(tl[2 * j]), p1 = __builtin_amdgcn_exp2f(tl[2 * j + 1]);
+                    psum += p0;
+                    psum += p1;
+                    typedef float pf2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 pb2 __attribute__((ext_vector_type(2)));
+                    const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(pf2{p0, p1}, pb2));
+                    const float h0 = __builtin_bit_cast(float, hw << 16), h1 = __builtin_bit_cast(float, hw & 0xffff0000u);
+                    const unsigned lw = __builtin_bit_cast(unsigned, __builtin_convertvector(pf2{p0 - h0, p1 - h1}, pb2));
+                    phw[j >> 2][j & 3] = hw;
+                    plw[j >> 2][j & 3] = lw;
                 }
                 fh = nh; fl = nl;
                 __builtin_amdgcn_sched_barrier(0);
@@ -455,9 +465,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                     nvh = *reinterpret_cast<const bf16x8*>(V + vo);
                     nvl = *reinterpret_cast<const bf16x8*>(V + SPL_V_PLANE + vo);
                 }
-                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[j], o[c], 0, 0, 0);
-                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[j], o[c], 0, 0, 0);
-                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[j], o[c], 0, 0, 0);
+                const bf16x8 phj = __builtin_bit_cast(bf16x8, phw[j]), plj = __builtin_bit_cast(bf16x8, plw[j]);
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, phj, o[c], 0, 0, 0);
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, plj, o[c], 0, 0, 0);
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, phj, o[c], 0, 0, 0);
                 if (8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
                 if (C16) {
                     if (u == 0) c16_load(Cn, 0, cw);

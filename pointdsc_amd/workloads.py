@@ -66,6 +66,8 @@ DEFAULT = "n5000_b32"
 MEASURED_LOGIT_SHIFT: Dict[str, float] = {
     "kitti_n5000_b16": -1.8915,
     "lomatch_n10000_b8": 0.4779,
+    "kitti_n12000_b4": -1.8683,
+    "multiway_n20000_b1": 0.4761,
 }
 
 

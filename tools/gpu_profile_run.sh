@@ -26,7 +26,7 @@ if [ -z "$QUICK" ]; then
   cp profiles/traffic.json "$OUT/${TAG}_traffic.json"
   cd "$ROOT"
 fi
-for c in $CONFIGS; do
+for c in $CONFIGS kitti_n12000_b4 multiway_n20000_b1; do      # (the last two: the reference's real evaluation sizes, r04)
   timeout 400 python bench.py --config $c > "$OUT/${TAG}_bench_$c.log" 2>&1; tail -1 "$OUT/${TAG}_bench_$c.log" > "$OUT/${TAG}_bench_line_$c.json"
 done
 SHARES="n5000_b32:16 n5000_b32:8 n5000_b32:4 kitti_n5000_b16:8 kitti_n5000_b16:4 kitti_n5000_b16:2 lomatch_n10000_b8:4 lomatch_n10000_b8:2 lomatch_n10000_b8:1"
@@ -36,7 +36,9 @@ if [ -z "$QUICK" ]; then
     timeout 300 python bench.py --config $c --global-batch $B --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_${c}_${B}pairs.json"
   done
   timeout 900 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
-  timeout 600 python tools/parity_census.py --only n5000_b32 --batches 32,4 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
+  timeout 900 python tools/parity_census.py --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
+  timeout 300 tools/pk_f32_repro.bin 5000 pointdsc_amd/libpointdsc_hip.so none,att,att32,mfma > "$OUT/${TAG}_pk_f32_repro.txt" 2>&1
+  timeout 200 python tools/attention_power.py --seconds 3 > "$OUT/${TAG}_attention_power.txt" 2>&1
 fi
 cd /tmp
 for s in n5000_b32:32 n1000_b1:1 kitti_n5000_b16:16 lomatch_n10000_b8:8 n5000_b32:4 kitti_n5000_b16:2 lomatch_n10000_b8:1; do
