@@ -36,7 +36,17 @@ def sysfs_sources():
         p = os.path.join(hw, "freq1_input")
         if os.path.exists(p) and "sclk" not in srcs:
             srcs["sclk"] = p
+        p = os.path.join(hw, "energy1_input")                  # accumulated microjoules, if the driver exposes it: exact mean power
+        if os.path.exists(p) and "energy" not in srcs:
+            srcs["energy"] = p
     return srcs
+
+
+def read_energy_uj(srcs):
+    try:
+        return int(open(srcs["energy"]).read()) if "energy" in srcs else None
+    except Exception:       # noqa: BLE001
+        return None
 
 
 class Sampler(threading.Thread):
@@ -82,6 +92,7 @@ def arm(name, launch, seconds, flops_exec, mfma_per_launch):
         launch()
     torch.cuda.synchronize()
     smp = Sampler()
+    e_start = read_energy_uj(smp.srcs)
     smp.start()
     t0 = time.perf_counter()
     n = 0
@@ -91,6 +102,7 @@ def arm(name, launch, seconds, flops_exec, mfma_per_launch):
         n += 50
         torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    e_end = read_energy_uj(smp.srcs)
     smp.stop_flag = True
     smp.join()
     s = [x for x in smp.samples if x[0] - t0 > 0.3 * seconds and x[1] == x[1]]       # drop the ramp
@@ -102,7 +114,9 @@ def arm(name, launch, seconds, flops_exec, mfma_per_launch):
     rec = {"arm": name, "launches_per_s": round(rate, 1), "ms_per_launch": round(1e3 / rate, 4), "executed_tflops": round(flops_exec * rate / 1e12, 1),
            "mean_power_w": round(mean_pw, 1), "max_power_w": round(max(pw), 1) if pw else None, "mean_sclk_mhz": round(mean_ck, 0),
            "joule_per_launch": round(mean_pw / rate, 4), "nanojoule_per_executed_mfma": round(mean_pw / rate / mfma_per_launch * 1e9, 2),
-           "samples": len(s), "sampler": smp.mode}
+           "samples": len(s), "sampler": smp.mode,
+           "power_first_last_w": [round(pw[0], 1), round(pw[-1], 1)] if pw else None,
+           "energy_counter_mean_power_w": round((e_end - e_start) * 1e-6 / el, 1) if (e_start is not None and e_end is not None) else None}
     print(json.dumps(rec), flush=True)
     return rec
 
