@@ -172,6 +172,11 @@ int pdsc_spatial_compat_u16(const float* src_keypts, const float* tgt_keypts, co
 /* Self-test hook for the two hand-rolled exact primitives of the compat kernel (correctly rounded sqrt, division
  * by a loop-invariant): sqrt_out[i] = sqrt(x[i]), div_out[i] = x[i] / divisor, both must equal the IEEE results. */
 int pdsc_selftest_exact_math(const float* x, float divisor, float* sqrt_out, float* div_out, long long n, void* stream);
+/* Test infrastructure: launches `workgroups` x 256 threads of a synthetic kernel that interleaves bf16 MFMAs with ordinary vector
+ * work for `iters` loop iterations (2500 ~ 1 ms) -- the co-resident neighbour beside which packed fp32 instructions with operand
+ * selects return wrong lanes (tools/pk_f32_repro.hip "mix").  The library ships no such instruction; the GPU
+ * tests keep this neighbour on the chip while they check the entry points bit for bit.  sink: >= 1 float, never written. */
+int pdsc_selftest_mfma_valu_neighbour(float* sink, int workgroups, int iters, void* stream);
 
 /* ---- a-2  point-wise layers --------------------------------------------------------------------
  * replaces every Conv1d(kernel_size=1)[+BatchNorm1d(eval)][+ReLU] of models/PointDSC.py:12-23,54-61,107-113.

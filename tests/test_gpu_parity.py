@@ -1994,10 +1994,14 @@ def test_forwards_in_flight_stay_exact_under_load(mode):
 
 def test_other_entry_points_stay_exact_beside_attention_launches():
     """The r04 reproducer (tools/pk_f32_repro.hip) showed packed fp32 with operand selects returning wrong lanes whenever a wave
-    shares a CU with the split attention kernel; the library ships none any more (test_library_ships_no_packed_fp32_with_operand_
+    shares a CU with a wave that interleaves MFMAs with vector work -- the r03 attention kernel, or 100 % of the launches beside the
+    synthetic "mix" neighbour; the library ships no such instruction any more (test_library_ships_no_packed_fp32_with_operand_
     selects).  This is the behavioural side: the entry points outside the testing forward -- the compat builds (hand-written packed
-    math), the NMS keys, the SM baseline, the validation forward, hypothesis scoring -- run 150 times each while attention launches
-    of two pairs of N = 5000 keep the chip busy on another stream; every result is bit-identical to the unloaded call."""
+    math with default selects), the NMS keys, the SM baseline, the validation forward, hypothesis scoring -- run 150 times each
+    while that synthetic neighbour (pdsc_selftest_mfma_valu_neighbour) AND attention launches of two pairs of N = 5000 keep the chip
+    busy on other streams; every result is bit-identical to the unloaded call.  In experiments builds the r03 scoring kernel
+    (compiler-paired packed fp32, PDSC_SCORE_SLP=1) serves as the positive control: beside the same neighbour it must miscount."""
+    import ctypes as C
     from pointdsc_amd import baselines
     model, _ = _bench_model("n5000_b32")
     n, bs = 5000, 2
@@ -2005,8 +2009,8 @@ def test_other_entry_points_stay_exact_beside_attention_launches():
     src, tgt, corr = g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(batch["corr_pos"])
     sig = torch.tensor([0.1], device=DEV)
     conf = torch.randn(bs, n, generator=torch.Generator().manual_seed(5)).to(DEV)
-    seed_trans = batch["gt_trans"].repeat_interleave(8, 0).reshape(bs, 8, 4, 4).clone()
-    seed_trans[:, :, :3, 3] += 0.01 * torch.randn(bs, 8, 3, generator=torch.Generator().manual_seed(6))
+    seed_trans = batch["gt_trans"].repeat_interleave(64, 0).reshape(bs, 64, 4, 4).clone()
+    seed_trans[:, :, :3, 3] += 0.01 * torch.randn(bs, 64, 3, generator=torch.Generator().manual_seed(6))
     seed_trans = g(seed_trans)
     small = workloads.batch("n1000_b1", 7, 1)
     sdata = {k: g(small[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}      # validation forward: no 'testing' key
@@ -2025,16 +2029,36 @@ def test_other_entry_points_stay_exact_beside_attention_launches():
         c16 = ops.spatial_compat_u16(src, tgt, sig)
         qkv = (torch.randn(bs * n, 384, generator=torch.Generator().manual_seed(0)) * 0.3).to(DEV)
         qs, kv = ops.pack_qkv_split(qkv, bs, n)
-        side = torch.cuda.Stream()
-        bad = {k: 0 for k in calls}
-        for rep in range(150):
+        side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+        sink = torch.zeros(4, device=DEV)
+        lib = _lib.load()
+
+        def load_the_chip():
             with torch.cuda.stream(side):
                 for _ in range(3):
                     ops.sc_attention_split(qs, kv, c16, bs, n)
+            _lib.check(lib.pdsc_selftest_mfma_valu_neighbour(C.c_void_p(sink.data_ptr()), 512, 5000, side2.cuda_stream), "neighbour")
+
+        bad = {k: 0 for k in calls}
+        for rep in range(150):
+            load_the_chip()
             for k, f in calls.items():
                 bad[k] += not torch.equal(f(), want[k])
             torch.cuda.synchronize()
-    assert not any(bad.values()), bad
+        assert not any(bad.values()), bad
+        if EXPERIMENTS:
+            # positive control: the compiler-paired scoring kernel of r03 loses votes beside the same neighbour
+            import os
+            os.environ["PDSC_SCORE_SLP"] = "1"
+            try:
+                wrong = 0
+                for rep in range(50):
+                    load_the_chip()
+                    wrong += not torch.equal(calls["score_hypotheses"](), want["score_hypotheses"])
+                    torch.cuda.synchronize()
+            finally:
+                os.environ.pop("PDSC_SCORE_SLP", None)
+            assert wrong > 0, "the r03 packed-fp32 scoring kernel did not miscount beside the synthetic neighbour"
 
 
 def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():

@@ -179,3 +179,24 @@ def test_one_rank_bench_through_rccl():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["check"]["ok"] is not False
     assert line["rccl_world1_probe"] == {"backend": "nccl", "world": 1, "all_gather_bitwise_equal": True}
+
+
+@pytest.mark.gpu
+def test_bench_check_judges_a_census_pair_outside_the_contract_by_its_recorded_cause():
+    """bench.py's parity check on the one KITTI census pair that leaves BASELINE.json's contract at its 8-GPU share (pair 60 in
+    batches of 2: 6.4e-4 against the reference's fp32 pose): the line must list it under `pairs_outside_fp32_contract` with the
+    recorded cause (the chosen seed's neighbour set sits on a top-k tie the reference itself recorded at 1.5e-6) and stay `ok` --
+    and the judged result (last forward of the timed region, two forwards in flight) equals the single-stream one bit for bit."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, str(root / "bench.py"), "--config", "kitti_n5000_b16", "--global-batch", "2", "--first-pair", "60", "--steps", "4",
+           "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0", "--settle-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    chk = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["check"]
+    assert chk["ok"] is True and chk["timed_result_equals_single_stream_result_bitwise"] is True and chk["pairs_failing_vs_reference"] == []
+    for p in chk["pairs_outside_fp32_contract"]:
+        assert p["excused"] and p["pair"] in (60, 61) and ("knn-tie" in p["why"] or p["why"].startswith(("tie", "refinement", "label-edge"))), p

@@ -16,7 +16,7 @@
 // Hogs: none | mfma (bf16 32x32x16 chains, the matrix pipe + power) | valu (packed fma chains) | mem (HBM stream) | lds (ds_read_b128)
 //       | att (the product's own split-precision attention launch -- LDS-DMA staging, s_setprio -- on random operands, through the C ABI of
 //       libpointdsc_hip.so, if the path is given) | att32 (the exact-fp32 attention launch: fp32 MFMA, ordinary LDS staging)
-//       | perm (v_permlane32_swap chains) | exp (v_exp_f32 chains) | ldsdma (buffer_load ... lds streams) | bar (s_barrier + LDS traffic) | cvt (v_cvt_pk_bf16_f32):
+//       | perm (v_permlane32_swap chains) | exp (v_exp_f32 chains) | ldsdma (buffer_load ... lds streams) | bar (s_barrier + LDS traffic) | cvt (v_cvt_pk_bf16_f32) | cvt_s (the same with an SGPR source) | mix (MFMA + v_exp + SGPR-source conversion + LDS reads in one loop) and mix-<x> (the mix without ingredient x; mix_vcvt: the conversion with VGPR sources only):
 //       the ingredients of the split attention kernel one at a time.
 // A mismatch table per (form, hog) goes to stdout; exit code 0 always (it is a probe, not a test).
 #include <dlfcn.h>
@@ -201,6 +201,62 @@ __global__ __launch_bounds__(256) void hog_cvt(float* out, int iters) {        /
         }
     if (acc == 0x12345u) out[0] = 1.f;
 }
+// v_cvt_pk_bf16_f32 with an SGPR as its second source: the form the element-wise P split of the attention loop compiled to before
+// r04's pairwise split (`v_cvt_pk_bf16_f32 v149, v199, s0`, 16 per tile) -- the library whose attention launch triggers the miscount
+// has it, the one that does not has not
+__global__ __launch_bounds__(256) void hog_cvt_s(float* out, int iters) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = 0.001f * (threadIdx.x + j) + 1.0f;
+    unsigned acc = 0u;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned u;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, s0" : "=v"(u) : "v"(x[j]));
+            acc ^= u;
+            x[j] = __builtin_bit_cast(float, u << 16) * 1.0001f;
+        }
+    if (acc == 0x12345u) out[0] = 1.f;
+}
+// the attention loop's mix in one synthetic kernel: bf16 MFMA chains with v_exp, SGPR-operand conversions, shifts and LDS reads between them.
+// Template switches take one ingredient out at a time (CVT: 0 none, 1 both sources VGPRs, 2 second source an SGPR).
+template <bool MFMA, bool EXP, int CVT, bool LDS>
+__global__ __launch_bounds__(256) void hog_mix(float* out, int iters) {
+    __shared__ float4 sm[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) sm[i] = float4{(float)i, 1.f, 2.f, 3.f};
+    __syncthreads();
+    f16v acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (threadIdx.x + e)); b[e] = (__bf16)(0.002f * (threadIdx.x * 3 + e)); }
+    float x = -0.01f * threadIdx.x, s = 0.f;
+    unsigned w = 0u;
+    int idx = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (MFMA) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            float p = x * 0.999f;
+            if (EXP) p = __builtin_amdgcn_exp2f(x);
+            unsigned u = __builtin_bit_cast(unsigned, p) >> 16;
+            if (CVT == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, s0" : "=v"(u) : "v"(p));
+            if (CVT == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u) : "v"(p));
+            w ^= u;
+            x = p - __builtin_bit_cast(float, u << 16) - 0.5f;
+            if (LDS) {
+                const float4 v = sm[idx & 1023];
+                s += v.x;
+                idx += 17;
+            }
+        }
+    }
+    if (s + acc[0][0] + acc[1][3] == 123.456f && w == 7u) out[0] = s;
+}
 __global__ __launch_bounds__(256) void hog_exp(float* out, int iters) {        // transcendental unit
     float x[8];
 #pragma unroll
@@ -350,9 +406,9 @@ int main(int argc, char** argv) {
     }
 
     const char* forms[] = {"scalar", "slp", "pk_asm", "pk_opsel", "pk_opsel_mov"};
-    const char* hogs[] = {"none", "mfma", "valu", "mem", "lds", "mfma+mem", "att", "att32", "perm", "exp", "ldsdma", "bar", "cvt"};
+    const char* hogs[] = {"none", "mfma", "valu", "mem", "lds", "mfma+mem", "att", "att32", "perm", "exp", "ldsdma", "bar", "cvt", "cvt_s", "mix", "mix-mfma", "mix-exp", "mix-cvt", "mix_vcvt", "mix-lds"};
     std::vector<int> got((size_t)LAUNCHES * S);
-    for (int hg = 0; hg < 13; ++hg) {
+    for (int hg = 0; hg < 20; ++hg) {
         if ((hg == 6 && !att) || (hg == 7 && !att32)) continue;
         if (only) {      // exact token match in the comma list
             const size_t L = strlen(hogs[hg]);
@@ -376,6 +432,13 @@ int main(int argc, char** argv) {
                 if (hg == 8) hipLaunchKernelGGL(hog_perm, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
                 if (hg == 9) hipLaunchKernelGGL(hog_exp, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
                 if (hg == 10) hipLaunchKernelGGL(hog_ldsdma, dim3(512), dim3(256), 0, s_hog[0], (const float*)dbig, big, dout, 40);
+                if (hg == 13) hipLaunchKernelGGL(hog_cvt_s, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 14) hipLaunchKernelGGL((hog_mix<true, true, 2, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 15) hipLaunchKernelGGL((hog_mix<false, true, 2, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 16) hipLaunchKernelGGL((hog_mix<true, false, 2, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 17) hipLaunchKernelGGL((hog_mix<true, true, 0, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 18) hipLaunchKernelGGL((hog_mix<true, true, 1, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (hg == 19) hipLaunchKernelGGL((hog_mix<true, true, 2, false>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
                 if (hg == 12) hipLaunchKernelGGL(hog_cvt, dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
                 if (hg == 11) hipLaunchKernelGGL(hog_bar, dim3(512), dim3(256), 0, s_hog[0], dout, 1500);
                 if (hg == 7 && att32(a32qkv, a32compat, ald, amsg, a32scr, a32scr_b, ABS, AN, 0, s_hog[0]) != 0) { fprintf(stderr, "fp32 attention hog failed\n"); att32 = nullptr; break; }
