@@ -31,11 +31,12 @@ ARCH = "gfx950"
 # -ffp-contract=off: the kernels spell out every fused multiply-add (fmaf) themselves, so the arithmetic
 # that decides thresholds is exactly what the source says (see DESIGN.md "numerics").
 # -fno-slp-vectorize, EVERY translation unit (r04): the SLP vectoriser pairs adjacent scalar fp32 operations into v_pk_*_f32
-# with op_sel operand selects; in r03 that form of the hypothesis-scoring kernel lost votes while kernels of other forwards were
-# co-resident, and tools/pk_f32_repro.hip (no PointDSC forward: the scoring loop beside the attention launch) shows wrong lanes
-# in packed op_sel code too (profiles/r04_pk_f32_repro*.txt).  The cause below the ISA is not established, so no compiler-paired
-# packed fp32 is shipped at all; the only packed fp32 left is the hand-written float2 math of compat.hip (its results are covered
-# bit for bit by the in-flight exactness probes and tests).  `--slp` builds the old flags as libpointdsc_hip_slp.so for A/B runs.
+# with op_sel / op_sel_hi operand selects, and packed fp32 WITH such a select returns wrong lanes whenever a co-resident wave
+# interleaves MFMAs with vector work: 100 % of the launches beside a synthetic neighbour, 14-25 % beside the r03 attention kernel
+# (tools/pk_f32_repro.hip, no PointDSC forward; profiles/r04_*pk_f32_repro*.txt) -- scalar fp32 and packed fp32 with default selects:
+# never.  The mechanism below the ISA is not established, so no instruction of that form is shipped at all: no compiler pairing
+# anywhere, the hand-written float2 math of compat.hip keeps its broadcasts in register pairs, and tools/isa_audit.py checks the
+# built code objects in the CPU test suite.  `--slp` builds the old flags as libpointdsc_hip_slp.so for A/B runs.
 NO_SLP = ["-fno-slp-vectorize"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"] + os.environ.get("PDSC_HIPCC_EXTRA", "").split()     # e.g. -DPDSC_LAYER_DIAG (diagnostic kernels)
