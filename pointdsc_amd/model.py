@@ -388,7 +388,7 @@ class PointDSC(nn.Module):
             self.packed_weights(dev)                           # (re)packs if needed and resets the flag below
             if not self._h3_range_checked and self.layer_gemm == "h3":
                 self._h3_range_checked = True
-                self._h3_range_probe(corr_pos, src_keypts, tgt_keypts)      # first forward after packing: may switch to "f32"
+                self._h3_range_probe(corr_pos, src_keypts, tgt_keypts, counts)      # first forward after packing: may switch to "f32"
         cfg = self._config()
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
@@ -436,7 +436,7 @@ class PointDSC(nn.Module):
 
     RANGE_KINDS = ("layer0", "PointCN", "q|k|v", "message", "fc_message hidden 1", "fc_message hidden 2", "feature")
 
-    def _h3_range_probe(self, corr_pos, src_keypts, tgt_keypts) -> None:
+    def _h3_range_probe(self, corr_pos, src_keypts, tgt_keypts, counts=None) -> None:
         """layer_gemm = "h3" carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo: EVERY activation of the chain,
         hidden ones included, must stay below 65504.  Once per weight packing, before the first forward: the encoder with the fp32
         GEMMs, one launch per conv, and the largest |value| of every activation kind over all layers (pdsc_encoder_range_probe;
@@ -448,6 +448,11 @@ class PointDSC(nn.Module):
         bs, n = corr_pos.shape[0], corr_pos.shape[1]
         num_seeds = max(int(n * self.ratio), 1)
         cfg = self._config()
+        if counts is not None:
+            # ragged batch: the probe runs the padded layout as a uniform batch, so the padding rows (any values, NaN included, by
+            # contract) are replaced by zeros in copies -- nothing of the probe may depend on them
+            keep = (torch.arange(n, device=dev)[None, :] < torch.tensor(counts, device=dev)[:, None])[:, :, None]
+            corr_pos, src_keypts, tgt_keypts = (torch.where(keep, t, torch.zeros_like(t)) for t in (corr_pos, src_keypts, tgt_keypts))
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
             if self.layer_gemm != "h3":              # (the weight check at packing already fell back)

@@ -1809,8 +1809,12 @@ def test_ragged_batch_padded_tensors_and_count_list():
         for i, p in enumerate(pairs):
             t[i, : sizes[i]] = p[k][0]
         data[k] = g(t)
-    with torch.no_grad():
+    model.invalidate_packed_weights()          # the call below is then the FIRST forward after packing: the H3 range probe runs on this
+    import warnings as _w                       # ragged batch and must not see the NaN padding (it would fall back to the fp32 GEMMs)
+    with torch.no_grad(), _w.catch_warnings():
+        _w.simplefilter("error", RuntimeWarning)
         a = model(data)
+        assert model.layer_gemm == "h3" and max(model.last_range_probe.values()) < 3.0e4
         b = model(_as_lists(pairs))
     torch.cuda.synchronize()
     assert a["final_labels"].shape == (len(sizes), n_max) and bool(torch.isfinite(a["final_trans"]).all())

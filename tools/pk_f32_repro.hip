@@ -120,6 +120,80 @@ __global__ __launch_bounds__(256) void score_pk_asm_kernel(const float* __restri
     if (t < 4 && s0 + t < S) counts[s0 + t] = wsum[0][t] + wsum[1][t] + wsum[2][t] + wsum[3][t];
 }
 
+// ---- what do the wrong lanes compute?  Operands chosen so that every possible mis-selection gives a distinct product: a = (1, 2), b = (10, 100).
+//   r0 = v_pk_mul_f32 a, b op_sel_hi:[0,1]   right: (1*10, 1*100) = (10, 100);  select dropped -> hi = 2*100 = 200
+//   r1 = v_pk_mul_f32 a, b op_sel:[1,0]      right: (2*10, 2*100) = (20, 200);  select dropped -> lo = 1*10  = 10
+//   r2 = v_pk_mul_f32 a, b                   (default selects)                  always (10, 200)
+// Every thread repeats the three instructions `iters` times on fresh copies and counts the outcomes that differ from the right ones:
+// tally[0..5] = wrong r0.lo, r0.hi, r1.lo, r1.hi, r2.lo, r2.hi;  tally[6 + k] = how often the wrong value was the "select dropped" one
+__global__ __launch_bounds__(256) void select_probe_kernel(unsigned long long* __restrict__ tally, int iters) {
+    unsigned bad[6] = {0, 0, 0, 0, 0, 0}, dropped[2] = {0, 0};
+    for (int it = 0; it < iters; ++it) {
+        f2 a = {1.0f, 2.0f}, b = {10.0f, 100.0f}, r0, r1, r2;
+        asm volatile("" : "+v"(a), "+v"(b));
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r0) : "v"(a), "v"(b));
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r1) : "v"(a), "v"(b));
+        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r2) : "v"(a), "v"(b));
+        bad[0] += r0.x != 10.0f; bad[1] += r0.y != 100.0f; bad[2] += r1.x != 20.0f; bad[3] += r1.y != 200.0f;
+        bad[4] += r2.x != 10.0f; bad[5] += r2.y != 200.0f;
+        dropped[0] += r0.y == 200.0f; dropped[1] += r1.x == 10.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (bad[k]) atomicAdd(&tally[k], (unsigned long long)bad[k]);
+    if (dropped[0]) atomicAdd(&tally[6], (unsigned long long)dropped[0]);
+    if (dropped[1]) atomicAdd(&tally[7], (unsigned long long)dropped[1]);
+}
+
+// ... and the victim's actual dependent chain (mul -> fma -> fma -> add -> add with the same operand-select forms), on small integer
+// operands so that every mis-selection gives a distinct exact value:  px,py = 1,2  pz = 3  qx = 0.5;  T0 = (10,20) T1 = (100,200)
+// T2 = (1000,2000) T3 = (5,7):  right = (10 + 200 + 3000 + 5 - 0.5, 20 + 400 + 6000 + 7 - 0.5) = (3214.5, 6426.5).
+// wrong[0] = number of wrong results; wrong[1 + 2k], wrong[2 + 2k] = the k-th wrong (lo, hi) pair as float bits (first 31 kept)
+// the same chain keeping a copy of the accumulator pair after every instruction: on a wrong end result the five intermediate pairs of
+// the first cases are stored -- which instruction of the chain went wrong, and how
+__global__ __launch_bounds__(256) void chain_trace_kernel(unsigned* __restrict__ wrong, float* __restrict__ trace, int iters) {
+    for (int it = 0; it < iters; ++it) {
+        f2 pxy = {1.0f, 2.0f}, pz_ = {3.0f, 0.0f}, qxy = {0.5f, 0.25f}, T0 = {10.f, 20.f}, T1 = {100.f, 200.f}, T2 = {1000.f, 2000.f}, T3 = {5.f, 7.f}, a1, a2, a3, a4, a5;
+        asm volatile("" : "+v"(pxy), "+v"(pz_), "+v"(qxy), "+v"(T0), "+v"(T1), "+v"(T2), "+v"(T3));
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(a1) : "v"(pxy), "v"(T0));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(a2) : "v"(T1), "v"(pxy), "v"(a1));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(a3) : "v"(T2), "v"(pz_), "v"(a2));
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a4) : "v"(T3), "v"(a3));
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a5) : "v"(a4), "v"(qxy));
+        if (a5.x != 3214.5f || a5.y != 6426.5f) {
+            const unsigned k = atomicAdd(&wrong[0], 1u);
+            if (k < 4) {
+                float* t = trace + k * 10;
+                t[0] = a1.x; t[1] = a1.y; t[2] = a2.x; t[3] = a2.y; t[4] = a3.x; t[5] = a3.y; t[6] = a4.x; t[7] = a4.y; t[8] = a5.x; t[9] = a5.y;
+            }
+        }
+    }
+}
+
+// NOPS: wait states (s_nop NOPS-1) placed between the dependent packed instructions: 0 = none (back to back, as the compiler emits them)
+template <int NOPS>
+__global__ __launch_bounds__(256) void chain_probe_kernel(unsigned* __restrict__ wrong, int iters) {
+    for (int it = 0; it < iters; ++it) {
+        f2 pxy = {1.0f, 2.0f}, pz_ = {3.0f, 0.0f}, qxy = {0.5f, 0.25f}, T0 = {10.f, 20.f}, T1 = {100.f, 200.f}, T2 = {1000.f, 2000.f}, T3 = {5.f, 7.f}, acc;
+        asm volatile("" : "+v"(pxy), "+v"(pz_), "+v"(qxy), "+v"(T0), "+v"(T1), "+v"(T2), "+v"(T3));
+#define PK_GAP() do { if constexpr (NOPS > 0) asm volatile("s_nop %0" :: "n"(NOPS - 1)); } while (0)
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(pxy), "v"(T0));
+        PK_GAP();
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(T1), "v"(pxy));
+        PK_GAP();
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(T2), "v"(pz_));
+        PK_GAP();
+        asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc) : "v"(T3));
+        PK_GAP();
+        asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(acc) : "v"(qxy));
+#undef PK_GAP
+        if (acc.x != 3214.5f || acc.y != 6426.5f) {
+            const unsigned k = atomicAdd(&wrong[0], 1u);
+            if (k < 31) { wrong[1 + 2 * k] = __builtin_bit_cast(unsigned, acc.x); wrong[2 + 2 * k] = __builtin_bit_cast(unsigned, acc.y); }
+        }
+    }
+}
+
 // ---- hogs ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hog_mfma(float* out, int iters) {
     f16v acc[4];
@@ -405,6 +479,76 @@ int main(int argc, char** argv) {
         }
     }
 
+    {   // select probe: alone, beside the pure MFMA loop, beside the mix neighbour
+        unsigned long long* dtally;
+        CK(hipMalloc(&dtally, 8 * sizeof(unsigned long long)));
+        const char* names[3] = {"alone", "beside the pure MFMA loop", "beside the mix neighbour (MFMA interleaved with vector work)"};
+        for (int mode = 0; mode < 3 && (!only || strstr(only, "probe")); ++mode) {
+            CK(hipMemset(dtally, 0, 8 * sizeof(unsigned long long)));
+            const int P_REPS = 200, P_WG = 512, P_IT = 2000;
+            for (int rep = 0; rep < P_REPS; ++rep) {
+                if (mode == 1) hipLaunchKernelGGL(hog_mfma, dim3(512), dim3(256), 0, s_hog[0], dout, 6000);
+                if (mode == 2) hipLaunchKernelGGL((hog_mix<true, true, 2, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                hipLaunchKernelGGL(select_probe_kernel, dim3(P_WG), dim3(256), 0, s_test, dtally, P_IT);
+                CK(hipDeviceSynchronize());
+            }
+            unsigned long long t[8];
+            CK(hipMemcpy(t, dtally, sizeof(t), hipMemcpyDeviceToHost));
+            const double tot = (double)P_REPS * P_WG * 256 * P_IT;
+            printf("select probe %-62s: of %.3g evaluations per form -- op_sel_hi:[0,1]: lo wrong %llu, hi wrong %llu (of which = the value with the select DROPPED: %llu); "
+                   "op_sel:[1,0]: lo wrong %llu (select dropped: %llu), hi wrong %llu; default selects: lo wrong %llu, hi wrong %llu\n",
+                   names[mode], tot, t[0], t[1], t[6], t[2], t[7], t[3], t[4], t[5]);
+            fflush(stdout);
+        }
+        CK(hipFree(dtally));
+        unsigned* dwrong;
+        CK(hipMalloc(&dwrong, 64 * sizeof(unsigned)));
+        for (int nops = 0; nops <= 3; ++nops)
+        for (int mode = 0; mode < 3 && (!only || strstr(only, "probe")); ++mode) {
+            if (nops > 0 && mode != 2) continue;
+            const int gap = nops == 0 ? 0 : nops == 1 ? 1 : nops == 2 ? 2 : 8;
+            CK(hipMemset(dwrong, 0, 64 * sizeof(unsigned)));
+            const int P_REPS = 200, P_WG = 512, P_IT = 2000;
+            for (int rep = 0; rep < P_REPS; ++rep) {
+                if (mode == 1) hipLaunchKernelGGL(hog_mfma, dim3(512), dim3(256), 0, s_hog[0], dout, 6000);
+                if (mode == 2) hipLaunchKernelGGL((hog_mix<true, true, 2, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                if (gap == 0) hipLaunchKernelGGL(chain_probe_kernel<0>, dim3(P_WG), dim3(256), 0, s_test, dwrong, P_IT);
+                if (gap == 1) hipLaunchKernelGGL(chain_probe_kernel<1>, dim3(P_WG), dim3(256), 0, s_test, dwrong, P_IT);
+                if (gap == 2) hipLaunchKernelGGL(chain_probe_kernel<2>, dim3(P_WG), dim3(256), 0, s_test, dwrong, P_IT);
+                if (gap == 8) hipLaunchKernelGGL(chain_probe_kernel<8>, dim3(P_WG), dim3(256), 0, s_test, dwrong, P_IT);
+                CK(hipDeviceSynchronize());
+            }
+            unsigned w[64];
+            CK(hipMemcpy(w, dwrong, sizeof(w), hipMemcpyDeviceToHost));
+            printf("chain probe, %d wait state(s) between the dependent packed instructions, %-62s: %u wrong results of %.3g; first wrong (lo, hi) pairs [right: (3214.5, 6426.5)]:",
+                   gap, names[mode], w[0], (double)P_REPS * P_WG * 256 * P_IT);
+            for (unsigned k = 0; k < (w[0] < 8 ? w[0] : 8); ++k) printf(" (%g, %g)", __builtin_bit_cast(float, w[1 + 2 * k]), __builtin_bit_cast(float, w[2 + 2 * k]));
+            printf("\n");
+            fflush(stdout);
+        }
+        {   // which instruction of the chain goes wrong
+            float* dtrace;
+            CK(hipMalloc(&dtrace, 40 * sizeof(float)));
+            CK(hipMemset(dtrace, 0, 40 * sizeof(float)));
+            CK(hipMemset(dwrong, 0, 64 * sizeof(unsigned)));
+            for (int rep = 0; rep < 200 && (!only || strstr(only, "probe")); ++rep) {
+                hipLaunchKernelGGL((hog_mix<true, true, 2, true>), dim3(512), dim3(256), 0, s_hog[0], dout, 2500);
+                hipLaunchKernelGGL(chain_trace_kernel, dim3(512), dim3(256), 0, s_test, dwrong, dtrace, 2000);
+                CK(hipDeviceSynchronize());
+            }
+            unsigned w0;
+            float tr[40];
+            CK(hipMemcpy(&w0, dwrong, 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(tr, dtrace, sizeof(tr), hipMemcpyDeviceToHost));
+            printf("chain trace (every intermediate in its own register pair) beside the mix neighbour: %u wrong end results; right intermediates: "
+                   "mul (10, 20) -> fma (210, 420) -> fma (3210, 6420) -> add (3215, 6427) -> add (3214.5, 6426.5)\n", w0);
+            for (unsigned k = 0; k < (w0 < 4 ? w0 : 4); ++k)
+                printf("    wrong case %u: mul (%g, %g) -> fma (%g, %g) -> fma (%g, %g) -> add (%g, %g) -> add (%g, %g)\n", k, tr[k * 10], tr[k * 10 + 1], tr[k * 10 + 2],
+                       tr[k * 10 + 3], tr[k * 10 + 4], tr[k * 10 + 5], tr[k * 10 + 6], tr[k * 10 + 7], tr[k * 10 + 8], tr[k * 10 + 9]);
+            CK(hipFree(dtrace));
+        }
+        CK(hipFree(dwrong));
+    }
     const char* forms[] = {"scalar", "slp", "pk_asm", "pk_opsel", "pk_opsel_mov"};
     const char* hogs[] = {"none", "mfma", "valu", "mem", "lds", "mfma+mem", "att", "att32", "perm", "exp", "ldsdma", "bar", "cvt", "cvt_s", "mix", "mix-mfma", "mix-exp", "mix-cvt", "mix_vcvt", "mix-lds"};
     std::vector<int> got((size_t)LAUNCHES * S);
