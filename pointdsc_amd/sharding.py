@@ -25,7 +25,9 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_results(local_trans: torch.Tensor, local_labels: Optional[torch.Tensor], total: int,
                    group=None) -> Dict[str, Optional[torch.Tensor]]:
     """all_gather the per-rank shards back into [total,4,4] (+ [total,N] labels) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    # no process group: nothing to gather.  A process group of ONE rank still takes the collective path below (a 64-byte all_gather
+    # with itself): that is how the RCCL code path is exercised on a one-GPU box (tests/test_sharding_gloo.py).
+    if not (dist.is_available() and dist.is_initialized()):
         return {"final_trans": local_trans, "final_labels": local_labels}
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     cap = -(-total // world)                       # shards are padded to the largest shard

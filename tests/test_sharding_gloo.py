@@ -164,8 +164,10 @@ def test_eight_rank_bench_rehearsal_on_one_gpu(config, expect_per_rank):
 @pytest.mark.gpu
 def test_one_rank_bench_through_rccl():
     """`bench.py --gpus 1` launched the way the driver launches the N > 1 runs (torch.distributed.run, --backend nccl = RCCL) with ONE
-    rank: the RCCL bring-up the multi-GPU runs depend on -- init_process_group(device_id=...), the barriers of the timing fence and
-    an all_gather of the pose payload -- runs on the one-GPU box (world sizes > 1 need the 8-GPU node, tools/scale_run.sh)."""
+    rank: the RCCL bring-up the multi-GPU runs depend on -- init_process_group(device_id=...), the barriers of the timing fence, the
+    pose all_gather behind EVERY forward on the forward's own stream (sharding.gather_results takes the collective path whenever a
+    process group exists, also with one rank) and one more all_gather of the payload compared bitwise -- runs on the one-GPU box
+    (world sizes > 1 need the 8-GPU node, tools/scale_run.sh)."""
     import json
     import subprocess
     import sys
