@@ -318,6 +318,15 @@ int pdsc_attention_trace(long long* device_buffer);
  * stage boundaries of layer_fused_kernel (tools/layer_trace.py); NULL switches it off. */
 int pdsc_layer_trace(long long* device_buffer);
 
+/* ---- a-4  first two layers of the confidence head in one launch ------------------------------------------------
+ * replaces classification.0 .. classification.3 (models/PointDSC.py:107-111, called at :171):
+ *   h2[m][0:32] = relu(W2 relu(W1 feat[m][0:128] + b1) + b2),  W1 [32][128], W2 [32][32] row-major fp32.
+ * Exact fp32 MFMA; every output element goes through the same fma chain as
+ *   pdsc_linear(feat, 128, W1, b1, ..., relu) followed by pdsc_linear(h1, 32, W2, b2, ..., relu)   -- bit-identical --
+ * without the [M][32] hidden layer going through HBM.  pdsc_forward_* calls this since r04. */
+int pdsc_classifier_hidden(const float* feat, const float* W1, const float* b1, const float* W2, const float* b2, float* h2,
+                           int M, void* stream);
+
 /* ---- a-4  L2 normalisation + last classifier layer --------------------------------------------
  * replaces F.normalize (models/PointDSC.py:156) and classification.4 (:112,171).
  *   normed[m][:] = feat[m][:] / max(||feat[m]||_2, 1e-12);  conf[m] = <h2[m][0:32], w3> + b3 */

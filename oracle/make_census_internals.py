@@ -201,7 +201,9 @@ def main():
     rep = {"pairs": total, "pairs_with_a_second_hypothesis_within_one_vote_of_the_winner_fp32": int(len(tie)),
            "median_number_of_hypotheses_within_one_vote_of_the_winner_fp32": float(np.median((top >= top[:, :1] - 1).sum(axis=1))),
            "knn_boundary_gap_fp32": {"median_over_all_seeds": float(np.median(gaps)), "share_of_seeds_below_2e-5": float((gaps < 2e-5).mean()),
-                                     "chosen_seed_gap_below_2e-5": [int(i) for i in np.flatnonzero(best_gap < 2e-5)]},
+                                     "share_of_seeds_below_2e-6": float((gaps < 2e-6).mean()),
+                                     "pairs_whose_chosen_seed_gap_is_below_2e-5": int((best_gap < 2e-5).sum()),
+                                     "pairs_whose_chosen_seed_gap_is_below_2e-6": int((best_gap < 2e-6).sum())},
            "refinement_margin_below_1e-4_fp32": [int(i) for i in np.flatnonzero(np.nanmin(rm, axis=1) < 1e-4)],
            "refinement_iterations_fp32": {str(k): int(v) for k, v in zip(*np.unique([(r["refine_counts32"] >= 0).sum() for r in rows], return_counts=True))}}
     p = GOLDEN / "CENSUS_PINNING.json"

@@ -52,6 +52,7 @@ SIGNATURES = {
     "pdsc_spatial_compat_u16": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pdsc_selftest_exact_math": (_i, [_vp, _f, _vp, _vp, _ll, _vp]),
     "pdsc_selftest_mfma_valu_neighbour": (_i, [_vp, _i, _i, _vp]),
+    "pdsc_classifier_hidden": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pdsc_linear": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pdsc_layer0": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pdsc_layer_fused": (_i, [_vp] * 16 + [_i, _vp]),

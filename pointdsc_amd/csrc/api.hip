@@ -546,8 +546,12 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         hst = (hipStream_t)tail_stream;
     }
     // Step 2.1 (:156,:171,:174): normalise, confidence head, NMS seeds
-    PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), nullptr, 0, h1, 32, M, C, 32, 1, stream));
-    PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
+    if (env_int("PDSC_CLS_FUSED", 1))       // (A/B knob, experiments builds: 0 = the two pdsc_linear launches of r01-r03; same bits)
+        PDSC_TRY(launch_classifier_hidden(featA, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), h2, M, hst));
+    else {
+        PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), nullptr, 0, h1, 32, M, C, 32, 1, stream));
+        PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
+    }
     PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
     if (mode == 0) {
         PDSC_TRY(launch_nms_keys_grid(src, conf, cfg->nms_radius, keys, ws + L.find("nms_ws"), pdsc_nms_workspace_bytes(bs, N), bs, N, nvalid, hst));

@@ -149,6 +149,108 @@ __global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ c
     }
 }
 
+// ---- a-4, first two layers of the confidence head in ONE launch (r04): h2 = relu(W2 relu(W1 x + b1) + b2), x [M][128] -> h2 [M][32]
+//      reference: classification.0 .. classification.3 (models/PointDSC.py:107-111, :171).
+// The forward used to issue two pdsc_linear launches for this (64 x 64 output tiles of which half is padding at Nout = 32, W staged
+// again by each of the 2500 workgroups, the [M][32] hidden layer through HBM, no overlap of loads and MFMAs: 2 x 47 us at 32 pairs).
+// Here a persistent workgroup keeps W1, W2 and the biases in LDS, walks 128-row tiles with the next tile's loads in flight under
+// the MFMAs, and chains the two GEMMs in registers: the operand roles are swapped (A = W, B = x: accumulator lane = point, register
+// r = output channel (r&3) + 8(r>>2) + 4h), so relu(h1 + b1) IS the B operand of the second GEMM (k-slot (4q+e, h) <-> channel
+// 8q + 4h + e, the convention of this file).  Same instruction (v_mfma_f32_32x32x2_f32), same k order, a*b = b*a per product: every
+// output element goes through the fma chain of the two pdsc_linear launches, bit for bit (test_classifier_hidden_equals_two_linears).
+constexpr int CH_ROWS = 128, CH_K = PDSC_CHANNELS, CH_H = 32;
+constexpr int CH_XLD = CH_K + 4, CH_W2LD = CH_H + 4;
+struct ClassifierLds {
+    float W1[CH_H * CH_XLD];
+    float W2[CH_H * CH_W2LD];
+    float b1[CH_H], b2[CH_H];
+    float X[CH_ROWS * CH_XLD];
+};
+
+__global__ __launch_bounds__(256) void classifier_hidden_kernel(const float* __restrict__ X, const float* __restrict__ W1,
+                                                               const float* __restrict__ b1, const float* __restrict__ W2,
+                                                               const float* __restrict__ b2, float* __restrict__ H2, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ClassifierLds& sh = *reinterpret_cast<ClassifierLds*>(lds_raw);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int num_tiles = ceil_div_dev(M, CH_ROWS);
+    for (int idx = t; idx < CH_H * (CH_K / 4); idx += 256) {
+        const int row = idx / (CH_K / 4), c = idx - row * (CH_K / 4);
+        *reinterpret_cast<f32x4*>(sh.W1 + row * CH_XLD + 4 * c) = *reinterpret_cast<const f32x4*>(W1 + (size_t)row * CH_K + 4 * c);
+    }
+    for (int idx = t; idx < CH_H * (CH_H / 4); idx += 256) {
+        const int row = idx / (CH_H / 4), c = idx - row * (CH_H / 4);
+        *reinterpret_cast<f32x4*>(sh.W2 + row * CH_W2LD + 4 * c) = *reinterpret_cast<const f32x4*>(W2 + (size_t)row * CH_H + 4 * c);
+    }
+    if (t < CH_H) { sh.b1[t] = b1[t]; sh.b2[t] = b2[t]; }
+    f32x4 stage[16];                              // this thread's share of a 128 x 128 tile: rows (t >> 5) + 8 i, columns 4 (t & 31) ..
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = tile * CH_ROWS + (t >> 5) + 8 * i;
+            stage[i] = m < M ? *reinterpret_cast<const f32x4*>(X + (size_t)m * CH_K + 4 * (t & 31)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < num_tiles) load_tile(tile);
+    for (; tile < num_tiles; tile += gridDim.x) {
+        __syncthreads();                          // the previous tile's readers are done (first pass: the weights are staged)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(sh.X + ((t >> 5) + 8 * i) * CH_XLD + 4 * (t & 31)) = stage[i];
+        __syncthreads();
+        if (tile + gridDim.x < num_tiles) load_tile(tile + gridDim.x);       // in flight under the MFMAs below
+        // GEMM 1: acc[r] = sum_k W1[chan(r)][k] x[point][k], lane = point wave * 32 + l31
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* wa = sh.W1 + l31 * CH_XLD + 4 * h;
+        const float* xb = sh.X + (wave * 32 + l31) * CH_XLD + 4 * h;
+#pragma unroll
+        for (int q = 0; q < CH_K / 8; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(wa + 8 * q);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(xb + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+        // bias + relu: register r = channel (r&3) + 8(r>>2) + 4h; as B operand of GEMM 2: x[q][e] = h1[4q + e]
+        f32x4 h1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h1[q][e] = fmaxf(acc[4 * q + e] + sh.b1[e + 8 * q + 4 * h], 0.f);
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        const float* wa2 = sh.W2 + l31 * CH_W2LD + 4 * h;
+#pragma unroll
+        for (int q = 0; q < CH_H / 8; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(wa2 + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], h1[q][e], acc2, 0, 0, 0);
+        }
+        const int m = tile * CH_ROWS + wave * 32 + l31;
+        if (m < M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc2[4 * g + e] + sh.b2[e + 8 * g + 4 * h], 0.f);
+                *reinterpret_cast<f32x4*>(H2 + (size_t)m * CH_H + 8 * g + 4 * h) = o;
+            }
+        }
+    }
+}
+
+int launch_classifier_hidden(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, float* H2, int M,
+                             hipStream_t st) {
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&classifier_hidden_kernel), sizeof(ClassifierLds), "pdsc_classifier_hidden(dynamic LDS)");
+    if (rc != PDSC_OK) return rc;
+    const int tiles = ceil_div(M, CH_ROWS);
+    const int grid = tiles < 256 ? tiles : 256;        // one persistent workgroup per CU (89 KiB of LDS each)
+    hipLaunchKernelGGL(classifier_hidden_kernel, dim3(grid), dim3(256), sizeof(ClassifierLds), st, X, W1, b1, W2, b2, H2, M);
+    return check_launch("pdsc_classifier_hidden");
+}
+
 static size_t linear_lds_bytes(int NT, int K) { return (size_t)(LIN_BM + 64 * NT) * (K + 4) * sizeof(float); }
 
 template <int NT, int MODE>
@@ -327,4 +429,10 @@ extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, c
     else
         hipLaunchKernelGGL(pdsc::layer0_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, corr_pos, in_dim, W0, b0, feat, M);
     return pdsc::check_launch("pdsc_layer0");
+}
+
+extern "C" int pdsc_classifier_hidden(const float* feat, const float* W1, const float* b1, const float* W2, const float* b2, float* h2,
+                                      int M, void* stream) {
+    PDSC_REQUIRE(feat && W1 && b1 && W2 && b2 && h2 && M > 0, "pdsc_classifier_hidden: bad argument");
+    return pdsc::launch_classifier_hidden(feat, W1, b1, W2, b2, h2, M, (hipStream_t)stream);
 }

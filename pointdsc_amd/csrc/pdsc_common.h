@@ -32,6 +32,9 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 // scoring kernel's atomicAdds that follow it on the same stream; a kernel node is)
 int launch_fill_u32(unsigned int* p, unsigned int value, size_t count, hipStream_t st);
 int launch_copy_u32(unsigned int* dst, const unsigned int* src, size_t count, hipStream_t st);      // dst[i] = src[i], likewise a kernel
+// linear.hip: the first two layers of the confidence head in one launch (bit-identical to two pdsc_linear launches)
+int launch_classifier_hidden(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, float* H2, int M,
+                             hipStream_t st);
 
 // opt-in event timing of the roofline kernels (api.hip); no-ops unless pdsc_profile_enable() was called
 void profile_mark_begin(int kind, hipStream_t st);

@@ -112,6 +112,19 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 @_on_device
+def classifier_hidden(feat: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """feat [M,128] -> h2 [M,32] = relu(w2 relu(w1 feat + b1) + b2) in one launch (pdsc_classifier_hidden): bit-identical to
+    linear(linear(feat, w1, b1, relu=True), w2, b2, relu=True)."""
+    lib = _lib.load()
+    x = _chk(feat, "feat")
+    w1, b1, w2, b2 = _chk(w1, "w1"), _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2")
+    assert x.shape[1] == 128 and w1.shape == (32, 128) and w2.shape == (32, 32) and b1.shape == (32,) and b2.shape == (32,)
+    h2 = torch.empty(x.shape[0], 32, device=x.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_classifier_hidden(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(h2), x.shape[0], _stream()), "pdsc_classifier_hidden")
+    return h2
+
+
+@_on_device
 def layer0(corr_pos: torch.Tensor, w0_padded: torch.Tensor, b0: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _chk(corr_pos, "corr_pos").reshape(-1, corr_pos.shape[-1])

@@ -1295,9 +1295,11 @@ def _census_module():
 
 @pytest.mark.parametrize("gemm", ["h3", "f32"])
 @pytest.mark.parametrize("name,step", [("n5000_b32", 32), ("n5000_b32", 4), ("kitti_n5000_b16", 16), ("kitti_n5000_b16", 2),
-                                       ("lomatch_n10000_b8", 8), ("lomatch_n10000_b8", 1), ("n1000_b1", 1), ("n1000_b1", 16)])
+                                       ("lomatch_n10000_b8", 8), ("lomatch_n10000_b8", 1), ("n1000_b1", 1), ("n1000_b1", 16),
+                                       # 32 pairs at the reference's real KITTI evaluation size (evaluation/test_KITTI.py:120)
+                                       ("kitti_n12000_b4", 4), ("kitti_n12000_b4", 1)])
 def test_parity_census(name, step, gemm):
-    """Parity census: 256 seeded pairs per workload family (64 at N = 10 000), pair i = the bench workload's pair i, run in batches
+    """Parity census: 256 seeded pairs per workload family (64 at N = 10 000, 32 at N = 12 000), pair i = the bench workload's pair i, run in batches
     of the bench's global batch and of its 8-GPU share, with both layer-GEMM arithmetics.  Every pair must meet BASELINE.json's
     contract against the unmodified reference's fp32 output (labels bit-exact, R/t within 1e-4).  A pair outside it passes ONLY
     with a recorded discrete cause, checked against what the reference itself decided on that pair
@@ -1576,6 +1578,21 @@ def test_inner_product_matching_matches_the_3dlomatch_callers_lines(name):
         want = torch.argmax(torch.einsum("ac,bc->ab", s, t), dim=-1).numpy()
         got = correspondences.match_descriptors(g(s), g(t), metric="ip").cpu().numpy()
         assert np.array_equal(got, want), (with_nan, got, want)
+
+
+@pytest.mark.parametrize("m", [1, 31, 128, 129, 1000, 5000 * 3 + 17, 160000])
+def test_classifier_hidden_equals_two_linears(m):
+    """pdsc_classifier_hidden (r04: classification.0 .. classification.3, models/PointDSC.py:107-111, in one launch with the hidden
+    layer kept in registers) against the two pdsc_linear launches it replaces in the forward: the same MFMA instruction, the same k
+    order, operand roles swapped (a*b = b*a) -- bit-identical, whatever the row count (tiles of 128, persistent workgroups)."""
+    gen = torch.Generator().manual_seed(m)
+    feat = g(torch.randn(m, 128, generator=gen) * 0.7)
+    w1, b1 = g(torch.randn(32, 128, generator=gen) * 0.15), g(torch.randn(32, generator=gen) * 0.1)
+    w2, b2 = g(torch.randn(32, 32, generator=gen) * 0.3), g(torch.randn(32, generator=gen) * 0.1)
+    want = ops.linear(ops.linear(feat, w1, b1, relu=True), w2, b2, relu=True)
+    got = ops.classifier_hidden(feat, w1, b1, w2, b2)
+    assert got.shape == (m, 32) and torch.equal(got, want)
+    assert float((want > 0).float().mean()) > 0.2           # (the comparison is not about all-zero rows)
 
 
 def test_match_descriptors_ties_and_ragged_sizes():
