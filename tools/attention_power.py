@@ -26,9 +26,48 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
+_CHOSEN_HWMON = None      # set by calibrate(): the hwmon directory of the GPU this process actually loads
+
+
+def all_hwmons():
+    out = []
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        for name in ("power1_average", "power1_input"):
+            if os.path.exists(os.path.join(hw, name)):
+                out.append((hw, os.path.join(hw, name)))
+                break
+    return out
+
+
+def calibrate(launch):
+    """A box may expose several GPUs in sysfs while this process sees one: pick the hwmon whose power moves most between idle and
+    one second of the launch loop (and print every candidate's figures, so that the choice can be checked)."""
+    global _CHOSEN_HWMON
+    import torch
+    cands = all_hwmons()
+    if not cands:
+        return
+    rd = lambda p: int(open(p).read()) * 1e-6
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    idle = [rd(p) for _, p in cands]
+    t0 = time.perf_counter()
+    peak = list(idle)
+    while time.perf_counter() - t0 < 1.5:
+        for _ in range(20):
+            launch()
+        peak = [max(a, rd(p)) for a, (_, p) in zip(peak, cands)]
+        torch.cuda.synchronize()
+    deltas = [b - a for a, b in zip(idle, peak)]
+    k = max(range(len(cands)), key=lambda i: deltas[i])
+    _CHOSEN_HWMON = cands[k][0]
+    print(json.dumps({"calibration": [{"hwmon": hw, "idle_w": round(a, 1), "peak_under_load_w": round(b, 1)} for (hw, _), a, b in zip(cands, idle, peak)],
+                      "chosen": _CHOSEN_HWMON}), flush=True)
+
+
 def sysfs_sources():
     srcs = {}
-    for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+    for hw in ([_CHOSEN_HWMON] if _CHOSEN_HWMON else glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
         for name in ("power1_average", "power1_input"):
             p = os.path.join(hw, name)
             if os.path.exists(p) and "power" not in srcs:
@@ -146,6 +185,8 @@ def main():
     for label, scale in (("random", 0.3), ("zeros", 0.0)):
         qkv = (torch.randn(bs * n, 384, generator=gen) * scale).to(dev)
         qs, kv = ops.pack_qkv_split(qkv, bs, n)
+        if _CHOSEN_HWMON is None:
+            calibrate(lambda: ops.sc_attention_split(qs, kv, c16, bs, n))
         out.append(arm(f"split kernel, unorm16 matrix, {label} operands", lambda: ops.sc_attention_split(qs, kv, c16, bs, n), a.seconds, flops_exec, mfma))
         if a.wide:
             os.environ["PDSC_ATT_WIDE"] = "0"
