@@ -26,6 +26,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                      against the CPU oracle run in the cpu_baseline leg;
   sustained       -- the same step repeated for >= --sustain-seconds after the timed region (the K timed steps of
                      the default invocation last a fraction of a second on a power-managed chip);
+  power           -- socket power / shader clock of rank 0's GPU sampled from its hwmon during the sustained leg, the
+                     board's cap, joules per pair: at frac_of_cap ~ 1 the step is bounded by the board's power budget
+                     (tools/forward_power.py is the stand-alone record; null where no sensor is readable);
   cpu_baseline    -- the reference's CPU path timed on this host's cores on a bounded sample of the same workload
                      (rank 0, N=1 only): the unmodified reference when /root/reference is importable (kind
                      "reference"), else the CPU oracle in its timing mode (kind "port").
@@ -39,7 +42,9 @@ import ctypes as C
 import json
 import math
 import os
+import glob
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -62,6 +67,75 @@ def log(msg):
 
 
 _T0 = time.perf_counter()
+
+
+class PowerSampler(threading.Thread):
+    """Socket power and shader clock of this rank's GPU, read from the amdgpu hwmon files every 50 ms while a leg runs.
+
+    A box may expose more GPUs in sysfs than the process sees: the sensor is the one whose PCI address equals the device's
+    (torch's pci_*_id properties against the /sys/class/drm/card*/device link); failing that, with one rank on the box, the
+    sensor with the highest mean reading (the loaded GPU).  Everything here is best effort: no sensor -> `power` is null."""
+
+    def __init__(self, device_index: int, period: float = 0.05):
+        super().__init__(daemon=True)
+        self.period, self.stop_flag = period, False
+        self.sensors = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(hw, name)):
+                    self.sensors.append({"dir": hw, "power": os.path.join(hw, name), "pw": [], "ck": []})
+                    break
+        self.want_pci = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            self.want_pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        except Exception:       # noqa: BLE001
+            pass
+
+    @staticmethod
+    def _read(path):
+        try:
+            return int(open(path).read())
+        except Exception:       # noqa: BLE001
+            return None
+
+    def run(self):
+        while not self.stop_flag:
+            for sn in self.sensors:
+                v = self._read(sn["power"])
+                if v is not None:
+                    sn["pw"].append(v * 1e-6)
+                c = self._read(os.path.join(sn["dir"], "freq1_input"))
+                if c is not None:
+                    sn["ck"].append(c * 1e-6)
+            time.sleep(self.period)
+
+    def finish(self, seconds: float, pairs: int, solo: bool):
+        self.stop_flag = True
+        self.join()
+        live = [sn for sn in self.sensors if sn["pw"]]
+        if not live:
+            return None
+        chosen, how = None, None
+        if self.want_pci:
+            for sn in live:
+                try:
+                    if os.path.basename(os.path.realpath(os.path.join(sn["dir"], "..", ".."))).lower().startswith(self.want_pci):
+                        chosen, how = sn, "pci address"
+                except Exception:       # noqa: BLE001
+                    pass
+        if chosen is None and solo:
+            chosen, how = max(live, key=lambda sn: sum(sn["pw"]) / len(sn["pw"])), "highest mean reading on the box"
+        if chosen is None:
+            return None
+        pw = chosen["pw"][len(chosen["pw"]) // 4:]                  # drop the first quarter: the sensor averages over a window
+        ck = chosen["ck"][len(chosen["ck"]) // 4:]
+        cap = self._read(os.path.join(chosen["dir"], "power1_cap"))
+        mean = sum(pw) / len(pw)
+        return {"leg": "sustained", "mean_w": round(mean, 1), "max_w": round(max(pw), 1), "cap_w": None if cap is None else round(cap * 1e-6, 1),
+                "frac_of_cap": None if not cap else round(mean / (cap * 1e-6), 4), "mean_sclk_mhz": round(sum(ck) / len(ck), 0) if ck else None,
+                "joule_per_pair": round(mean * seconds / pairs, 4), "samples": len(pw), "sensor": chosen["dir"], "sensor_matched_by": how,
+                "note": "this rank's GPU only; value x joule_per_pair = mean_w: at frac_of_cap ~ 1 the step is bounded by the board's power, not by a kernel's schedule"}
 
 
 def cpu_baseline_worker(config: str, pairs: int, threads: int, check_pairs: int, force_port: bool = False) -> None:
@@ -312,14 +386,28 @@ def main():
 
     # ---- sustained leg: the same step for >= sustain_seconds (same step count on every rank) ----
     sustained = None
+    power = None
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, min(2000, int(math.ceil(args.sustain_seconds / max(elapsed / args.steps, 1e-6)))))
         fence()
+        sampler = None
+        if rank == 0:
+            try:
+                sampler = PowerSampler(dev.index if hasattr(dev, "index") and dev.index is not None else 0)
+                sampler.start()
+            except Exception as e:  # noqa: BLE001
+                log(f"power sampler not started: {e!r}")
+                sampler = None
         t0 = time.perf_counter()
         for _ in range(n_sus):
             out = step()
         fence()
         sus = time.perf_counter() - t0
+        if sampler is not None:
+            try:
+                power = sampler.finish(sus, B * n_sus, solo=(world == 1))
+            except Exception as e:  # noqa: BLE001
+                log(f"power sampler failed: {e!r}")
         if world > 1:
             t = torch.tensor([sus], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -446,6 +534,7 @@ def main():
     }
     if sustained is not None:
         line["sustained"] = sustained
+    line["power"] = power
     line["in_flight"] = depth["d"]
     if rccl_probe is not None:
         line["rccl_world1_probe"] = rccl_probe
