@@ -25,6 +25,7 @@ struct AttSplitArgs {
     float* part_ml;              // [bs][nsplit][Npad][2]
     int N, Npad, nsplit, num_tiles, nq, bs;
     int prio_mode;               // A/B knob PDSC_ATT_PRIO: 1 = s_setprio 1 for the younger half of the waves, 2 = for the older half
+    int compute_all_waves;       // A/B knob PDSC_ATT_ALL_WAVES (experiments builds): 1 = waves without a valid query compute anyway (r01-r03)
     int compat_nt;               // A/B knob PDSC_ATT_COMPAT_NT: stream the compat slices with the non-temporal policy
     int items;                   // persistent form: number of (pair, key split, query block) items (= the one-item form's grid)
     int part_frag;               // key-split partials in point-fragment order (split_layout.h: PF), straight from the accumulators

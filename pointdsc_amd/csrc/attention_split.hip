@@ -208,6 +208,30 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                                                      coff[u], kt * (SPL_BK * (int)CEL), 0, 0);
     };
 
+    // A wave whose 32 queries ALL lie past the pair's last row has nothing to compute: its accumulators would hold copies of
+    // query N-1 in rows no consumer reads (the layer kernels walk ceil(N / 32) tiles, the combine kernel N rows).  N = 5000: waves
+    // 5-7 of every pair's last query block = 1.9 % of all waves; N = 10 000: 2.2 %.  Such a wave keeps its share of the K / V
+    // loads and every barrier of the protocol below, and skips the matrix and vector work (and its own compat rows): the launch
+    // runs at the board's power limit, so MFMAs not executed are time, not only energy.  Wave-uniform, decided
+    // once; the waves that compute run exactly the code they ran before.
+    if (!PS && !TRACE && !a.compute_all_waves && q_first + wave * 32 >= N) {
+        dma_k(kt0);
+        if (kt0 + 1 < kt1) dma_k(kt0 + 1);
+        dma_v(kt0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                             // the first tile's barrier
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int st = (kt - kt0) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                         // every wave is past iteration kt - 1: stages st (K) / st ^ 1 (V) are free
+#pragma unroll
+            for (int slot = NCS; slot < DMA_SLOTS; ++slot) dma_slot(kt, st, slot);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(a.nsplit != 1 && a.part_frag)) __syncthreads();        // the row-order epilogue's barrier
+        return;
+    }
+
     // prologue: K, compat of the first two tiles and V of the first in flight, then this lane's Q fragments
     f32x4 ccur[4], cnext[4];                     // CREG: compat of the tile whose logits are formed next / the one after
     dma_k(kt0); dma_c(kt0);
@@ -772,6 +796,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     a.trace = g_att_trace;
     a.nvalid = nvalid;
     a.prio_mode = env_int("PDSC_ATT_PRIO", 0);
+    a.compute_all_waves = env_int("PDSC_ATT_ALL_WAVES", 0);
     a.compat_nt = c16 ? 0 : 1;                 // (the wide variant still takes it as an argument)
     PDSC_REQUIRE(partial_layout == PDSC_PARTIALS_ROWS || partial_layout == PDSC_PARTIALS_PF, "pdsc_sc_attention_split: partial_layout=%d", partial_layout);
     PDSC_REQUIRE(partial_layout == PDSC_PARTIALS_ROWS || (!msg && nsplit > 1), "pdsc_sc_attention_split: point-fragment partials are not merged here (msg must be NULL, key split > 1)");
