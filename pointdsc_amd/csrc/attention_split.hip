@@ -79,7 +79,9 @@ constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
 // item's last tiles fetch the NEXT item's first K / compat / V tiles (today they fetch tiles nobody reads), so the
 // prologue's HBM round trip and the first tile's wait (5 % of a workgroup's life, tools/attention_trace.py) sit behind the
 // previous item's last tiles.  Point-fragment partials only: that epilogue needs no LDS, the stages stay live across items.
-template <int NW, int CM = 0, bool TRACE = false, bool PS = false>
+// PEEL: the split's last tile runs as peeled tail code (see tile_iteration); false = the r01-r03 straight-line loop (A/B record,
+// experiments builds: PDSC_ATT_PEEL=0)
+template <int NW, int CM = 0, bool TRACE = false, bool PS = false, bool PEEL = true>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
     constexpr bool C16 = CM == 1, CREG = CM == 2;
     static_assert(!PS || (!CREG && !TRACE), "the persistent form exists for the LDS-staged compat formats, untraced");
@@ -224,8 +226,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             const int st = (kt - kt0) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                         // every wave is past iteration kt - 1: stages st (K) / st ^ 1 (V) are free
+            if (kt + 1 < kt1) {                                     // (the last iteration has nothing left to fetch)
 #pragma unroll
-            for (int slot = NCS; slot < DMA_SLOTS; ++slot) dma_slot(kt, st, slot);
+                for (int slot = NCS; slot < DMA_SLOTS; ++slot) dma_slot(kt, st, slot);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(a.nsplit != 1 && a.part_frag)) __syncthreads();        // the row-order epilogue's barrier
@@ -390,9 +394,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     PDSC_TRACE_STAMP(1)                          // 1: first tile (wait + QK + logits)
     if (a.prio_mode == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);       // static priority, no per-segment flips
     if (a.prio_mode == 2 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
-    for (int kt = kt0; kt < kt1; ++kt) {
+    // One iteration of the tile loop.  LAST (one-item form only): the split's last tile has no successor -- no QK^T of a tile
+    // kt + 1, no logits, no run-ahead loads: r01-r03 ran the same straight-line body there and threw the 24 MFMAs away (0.6 % of a
+    // launch's MFMAs at 32 pairs of N = 5000, 1-2.4 % with the finer key splits of 1-4 pairs); peeled AFTER the loop the tail is
+    // straight-line code of its own, the accumulators flow loop -> tail -> epilogue and nothing is copied.
+    auto tile_iteration = [&](const int kt, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
         const int st = (PS ? u0 + kt - kt0 : kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
-        const bool has_next = kt + 1 < kt1;
+        const bool has_next = !LAST && kt + 1 < kt1;
         if constexpr (PS) {
             // what this iteration's run-ahead loads address: this item's tiles kt + 2 (K, compat) / kt + 1 (V), or, past its
             // end, the next item's first tiles.  The compat offsets of the lanes follow the next item's row count from the
@@ -437,19 +446,24 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             // fragments one step ahead of their MFMAs, and the steps pinned in source order: with the chunk-major image every
             // read is `base + immediate`, and left to itself the scheduler hoists all sixteen to the top of the iteration and
             // clusters the MFMAs behind them (measured: +7 % per launch)
-            bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff);
-            bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff);
+            bf16x8 fh = {}, fl = {};
+            if constexpr (!LAST) {
+                fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff);
+                fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 bf16x8 nh = fh, nl = fl;
-                if (j + 1 < 8) {
-                    nh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * (j + 1));
-                    nl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * (j + 1));
+                if constexpr (!LAST) {
+                    if (j + 1 < 8) {
+                        nh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * (j + 1));
+                        nl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * (j + 1));
+                    }
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
+                    if (j < DMA_SLOTS) dma_slot(kt, st, j);
                 }
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
-                if (j < DMA_SLOTS) dma_slot(kt, st, j);
                 {
                     // p values 2j, 2j+1 = one 32-bit word of the P operands: split as a PAIR (split_layout.h split_bf16 arithmetic:
                     // hi = bf16(p), lo = bf16(p - hi), round to nearest even) -- one v_cvt_pk_bf16_f32 per plane and pair, where the
@@ -493,8 +507,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, phj, o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, plj, o[c], 0, 0, 0);
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, phj, o[c], 0, 0, 0);
-                if (8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
-                if (C16) {
+                if (!LAST && 8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
+                if (LAST) {
+                    // (no tile kt + 1: no logits to form)
+                } else if (C16) {
                     if (u == 0) c16_load(Cn, 0, cw);
                     if (u == 4) c16_load(Cn, 1, cw);
                     if (u & 1) {
@@ -545,6 +561,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             }
         }
         PDSC_TRACE_STAMP(7)
+    };
+    if constexpr (PS || !PEEL) {
+        for (int kt = kt0; kt < kt1; ++kt) tile_iteration(kt, std::false_type{});
+    } else {
+        for (int kt = kt0; kt + 1 < kt1; ++kt) tile_iteration(kt, std::false_type{});
+        tile_iteration(kt1 - 1, std::true_type{});
     }
 
     if constexpr (!PS) break;
@@ -866,6 +888,15 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     if (trace && c16) PDSC_ATT_LAUNCH(8, 1, true);
     else if (trace) PDSC_ATT_LAUNCH(8, 0, true);
     else
+#endif
+#ifdef PDSC_EXPERIMENTS
+    if (nw == 8 && c16 && env_int("PDSC_ATT_PEEL", 1) == 0) {
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<8, 1, false, false, false>), lds_bytes, "pdsc_sc_attention_split(dynamic LDS)");
+        if (rc != PDSC_OK) return rc;
+        profile_mark_begin(PDSC_PROF_ATTENTION, st);
+        hipLaunchKernelGGL((sc_attention_split_kernel<8, 1, false, false, false>), dim3(grid), dim3(512), lds_bytes, st, a);
+        profile_mark_end(PDSC_PROF_ATTENTION, st);
+    } else
 #endif
     if (nw == 8 && c16) PDSC_ATT_LAUNCH(8, 1, false);
 #ifdef PDSC_EXPERIMENTS

@@ -15,15 +15,17 @@ def L(name):
 
 
 def bench_table():
-    out = ["| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of bf16 peak | fused layer launch, frac of 8 TB/s | compat build, frac of 8 TB/s | reference CPU path | check: max dT vs reference / oracle |",
-           "|---|---|---|---|---|---|---|---|---|---|"]
+    out = ["| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of bf16 peak | fused layer launch, frac of 8 TB/s | compat build, frac of 8 TB/s | socket power in the sustained leg (share of the cap), J per pair | reference CPU path | check: max dT vs reference / oracle |",
+           "|---|---|---|---|---|---|---|---|---|---|---|"]
     names = [("n5000_b32", "configs[2], headline"), ("n1000_b1", "configs[1]"), ("kitti_n5000_b16", "configs[3]"), ("lomatch_n10000_b8", "configs[4]"),
              ("kitti_n12000_b4", "the reference's KITTI evaluation size"), ("multiway_n20000_b1", "the reference's multiway size")]
     for n, lab in names:
         l = L(n); r = l["roofline"]; rl = l["roofline_layer"]; rc = l["roofline_compat"]; c = l["check"]; cb = l.get("cpu_baseline", {})
+        pw = l.get("power")
+        pws = "n/a" if not pw else f"{pw['mean_w']:.0f} W ({100 * pw['frac_of_cap']:.0f} %), {pw['joule_per_pair']:.2f} J"
         out.append(f"| `{n}` ({lab}) | **{l['value']:.0f}** ({l['in_flight']} in flight) | {l['single_stream']['value']:.0f} | {l['sustained']['value']:.0f} | "
                    f"{l['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms, {r['executed_frac']:.3f} | {rl['avg_launch_ms']:.3f} ms, {rl['frac']:.3f} | "
-                   f"{rc['avg_launch_ms']:.3f} ms, {rc['frac']:.3f} | {cb.get('value')} ({cb.get('kind')}, {cb.get('cores')} thr) | "
+                   f"{rc['avg_launch_ms']:.3f} ms, {rc['frac']:.3f} | {pws} | {cb.get('value')} ({cb.get('kind')}, {cb.get('cores')} thr) | "
                    f"{c.get('max_abs_dT_vs_reference'):.1e} / {c.get('max_abs_dT_vs_oracle'):.1e} ({'ok' if c['ok'] else 'FAIL'}) |")
     return "\n".join(out)
 
