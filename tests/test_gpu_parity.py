@@ -751,6 +751,46 @@ def test_point_fragment_hand_offs_reproduce_the_row_order_chain(n, bs, nsplit):
     assert torch.equal(ops.pf_to_rows(fb_h, bs, ops.pf_rows(n))[:, :n].reshape(m, 128), fb_hr) and torch.equal(qs_h, qs_hr) and torch.equal(kv_h, kv_hr)
 
 
+@pytest.mark.parametrize("layout", ["pf", "rows"])
+@pytest.mark.parametrize("n,bs,nsplit", [(5000, 5, 2), (4100, 3, 3), (2053, 4, 1), (1000, 2, 4), (288, 3, 2)])
+def test_attention_without_wasted_work_writes_the_same_partials(n, bs, nsplit, layout, monkeypatch):
+    """(experiments builds only)  Two r04 savings of the split-precision attention launch, against the r01-r03 behaviour kept
+    behind A/B knobs: waves whose 32 queries all lie past the pair's last row skip their arithmetic (PDSC_ATT_ALL_WAVES=1: they
+    compute), and the key split's last tile runs as peeled tail code without the QK^T of the tile after it (PDSC_ATT_PEEL=0:
+    straight-line loop).  Neither touches anything a consumer reads: partials (rows below the pair's last 32-row tile) and (m, l)
+    (rows below N) agree bit for bit, in both hand-off orders, with whole idle waves (n = 5000: 3 of 8, n = 2053: 7 of 8, n = 288:
+    7 of 8 in the second block), the four-wavefront kernel of small launches and the unsplit path (merged rows)."""
+    if not _lib.load().pdsc_experiments_enabled():
+        pytest.skip("the r01-r03 behaviour is an A/B record: experiments builds only")
+    gen = torch.Generator().manual_seed(700 + n)
+    batch = synthetic.make_batch(bs, n, seed=13 + n)
+    compat = ops.spatial_compat_u16(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    qkv = torch.cat([torch.randn(bs * n, 128, generator=gen) * 0.3 * QSCALE, torch.randn(bs * n, 128, generator=gen) * 0.3,
+                     torch.randn(bs * n, 128, generator=gen)], dim=-1)
+    qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+    npad = (n + 255) // 256 * 256
+    cut = bs * nsplit * npad * 128
+
+    def run():
+        if nsplit == 1:
+            return ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=1).clone(), None
+        t = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit, merge=False, layout=layout)[0].view(torch.float32)
+        o = t[:cut].reshape(bs * nsplit, npad, 128)
+        o = (ops.pf_to_rows(t[:cut], bs * nsplit, npad) if layout == "pf" else o)[:, : (n + 31) // 32 * 32 if layout == "pf" else n]
+        return o.clone(), t[cut:cut + bs * nsplit * npad * 2].reshape(bs * nsplit, npad, 2)[:, :n].clone()
+
+    monkeypatch.setenv("PDSC_ATT_ALL_WAVES", "1")
+    monkeypatch.setenv("PDSC_ATT_PEEL", "0")
+    want = run()
+    for env in ({"PDSC_ATT_ALL_WAVES": "0", "PDSC_ATT_PEEL": "0"}, {"PDSC_ATT_ALL_WAVES": "1", "PDSC_ATT_PEEL": "1"},
+                {"PDSC_ATT_ALL_WAVES": "0", "PDSC_ATT_PEEL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        assert torch.equal(got[0], want[0]), env
+        assert want[1] is None or torch.equal(got[1], want[1]), env
+
+
 @pytest.mark.parametrize("fmt", ["f32", "u16"])
 @pytest.mark.parametrize("n,bs,nsplit", [(5000, 13, 2), (4100, 16, 2), (2053, 32, 2)])
 def test_persistent_attention_writes_the_same_partials(n, bs, nsplit, fmt, monkeypatch):
@@ -1297,9 +1337,11 @@ def _census_module():
 @pytest.mark.parametrize("name,step", [("n5000_b32", 32), ("n5000_b32", 4), ("kitti_n5000_b16", 16), ("kitti_n5000_b16", 2),
                                        ("lomatch_n10000_b8", 8), ("lomatch_n10000_b8", 1), ("n1000_b1", 1), ("n1000_b1", 16),
                                        # 32 pairs at the reference's real KITTI evaluation size (evaluation/test_KITTI.py:120)
-                                       ("kitti_n12000_b4", 4), ("kitti_n12000_b4", 1)])
+                                       ("kitti_n12000_b4", 4), ("kitti_n12000_b4", 1),
+                                       # 16 pairs at the reference's multiway size (multiway/test_multi_ate.py:245)
+                                       ("multiway_n20000_b1", 1), ("multiway_n20000_b1", 4)])
 def test_parity_census(name, step, gemm):
-    """Parity census: 256 seeded pairs per workload family (64 at N = 10 000, 32 at N = 12 000), pair i = the bench workload's pair i, run in batches
+    """Parity census: 256 seeded pairs per workload family (64 at N = 10 000, 32 at N = 12 000, 16 at N = 20 000), pair i = the bench workload's pair i, run in batches
     of the bench's global batch and of its 8-GPU share, with both layer-GEMM arithmetics.  Every pair must meet BASELINE.json's
     contract against the unmodified reference's fp32 output (labels bit-exact, R/t within 1e-4).  A pair outside it passes ONLY
     with a recorded discrete cause, checked against what the reference itself decided on that pair

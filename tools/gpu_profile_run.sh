@@ -38,7 +38,9 @@ if [ -z "$QUICK" ]; then
   timeout 900 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
   timeout 900 python tools/parity_census.py --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
   timeout 300 tools/pk_f32_repro.bin 5000 pointdsc_amd/libpointdsc_hip.so none,att,att32,mfma > "$OUT/${TAG}_pk_f32_repro.txt" 2>&1
-  timeout 300 python tools/attention_power.py --seconds 8 > "$OUT/${TAG}_attention_power.txt" 2>&1
+  timeout 300 python tools/attention_power.py --seconds 5 > "$OUT/${TAG}_attention_power.txt" 2>&1
+  timeout 300 python tools/forward_power.py --seconds 4 > "$OUT/${TAG}_forward_power.txt" 2>&1
+  timeout 200 python tools/forward_power.py --seconds 3 --pairs 4 > "$OUT/${TAG}_forward_power_4pairs.txt" 2>&1
 fi
 cd /tmp
 for s in n5000_b32:32 n1000_b1:1 kitti_n5000_b16:16 lomatch_n10000_b8:8 n5000_b32:4 kitti_n5000_b16:2 lomatch_n10000_b8:1; do
