@@ -204,7 +204,7 @@ def parse():
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="extra measured leg after the timed region (0 = off)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="forwards in flight: consecutive steps alternate between this many HIP streams (pointdsc_amd/pipeline.py); "
-                         "1 = every step on the current stream; 0 = 2, or 4 captured hipGraphs when a step is one small problem (<= 4096 "
+                         "1 = every step on the current stream; 0 = 2, or 6 captured hipGraphs (zero-copy replays) when a step is one small problem (<= 4096 "
                          "correspondences: its ~45 launches are latency- and host-bound).  The single-stream rate is measured and reported either way")
     ap.add_argument("--tail-streams", choices=["on", "off"], default="on",
                     help="with forwards in flight: enqueue each forward's latency-bound tail on a high-priority companion stream "
@@ -212,6 +212,9 @@ def parse():
                          "pairs of N=5000, -6 %% at 4 pairs, -13 %% for one pair of N=10000; not used on the hipGraph path)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay each in-flight slot's forward as a captured hipGraph (auto: only when a step is one small problem)")
+    ap.add_argument("--zero-copy", choices=["auto", "off"], default="auto",
+                    help="with --graphs: capture each slot's graph on the resident input tensors and hand out the graph's own output "
+                         "tensors (pipeline.InFlight(zero_copy=True): no staging copies / clones around a replay); off = copies as in r03")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed load before the timed region so that it does not sit on the clock ramp (0 = exactly W warm-up steps)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed on the CPU baseline (0 = sized for ~10-20 s)")
@@ -281,10 +284,15 @@ def main():
 
     from pointdsc_amd.pipeline import InFlight
     small = B * N <= 4096                      # one small problem per step: its ~45 launches are latency- and host-bound
-    in_flight = args.in_flight if args.in_flight > 0 else (4 if small else 2)
+    # small steps are host / queue bound: depth sweep r04 (profiles/r04_w_inflight_depth_n1000.txt; sustained pairs/s at depth
+    # 2 / 3 / 4 / 5 / 6 / 8: 4650 / 6530 / 4730 / 5630 / 6520 / 5990; timed K = 20 region 2550 / 2890 / 3490 / 4770 / 5160 / 4940)
+    in_flight = args.in_flight if args.in_flight > 0 else (6 if small else 2)
     use_graphs = in_flight > 1 and (args.graphs == "on" or (args.graphs == "auto" and small))
     use_tail = args.tail_streams == "on"
-    runners = {d: InFlight(model, depth=d, graphs=use_graphs and d > 1, tail_streams=use_tail) for d in sorted({1, in_flight})}
+    # captured forwards read the bench's resident input tensors in place and hand out the graphs' own output tensors
+    zero_copy = use_graphs and args.zero_copy != "off"
+    runners = {d: InFlight(model, depth=d, graphs=use_graphs and d > 1, tail_streams=use_tail, zero_copy=zero_copy and d > 1)
+               for d in sorted({1, in_flight})}
     depth = {"d": in_flight}
 
     def gather(res):
@@ -540,6 +548,7 @@ def main():
         line["rccl_world1_probe"] = rccl_probe
     line["hip_graphs"] = bool(runners[in_flight].graphs and runners[in_flight]._captured)
     line["tail_streams"] = bool(runners[in_flight].tail_streams)
+    line["zero_copy_graphs"] = bool(runners[in_flight].zero_copy and line["hip_graphs"])
     if single is not None:
         line["single_stream"] = single
     traffic_file = ROOT / "profiles" / "traffic.json"      # PMC-derived HBM bytes per launch, if collected

@@ -31,6 +31,11 @@ sync, no allocation) and replays it: the ~45 launches of a forward cost the host
 launch-bound -- one pair of N=1000: 0.243 ms per forward with three eager forwards in flight, 0.149 ms with four captured ones
 (profiles/r03_e_graph_probe.txt); at 32 pairs of N=5000 it changes nothing.  Inputs are copied into per-slot static tensors,
 outputs are returned as copies; ragged batches and the validation forward take the eager path.
+``zero_copy=True`` (with graphs; r04) drops that staging: a slot's graph is captured ON the caller's fp32 input tensors and its own
+output tensors are handed out -- for callers that keep feeding the same buffers (a serving loop with pre-allocated inputs; other
+buffers are captured as a further graph, up to 4 per slot) and read a result before its slot runs again (``depth`` calls later).
+Five small launches and two allocations less per forward: the host's share of a captured N = 1000 forward, where the host is the
+bound (bench.py n1000_b1, profiles/r04_v_*).
 Exactness under concurrency (r03; tools/inflight_race_probe.py, tools/inflight_diverge_probe.py, profiles/r03_*_probe.txt): with
 several forwards sharing the chip -- above all three replayed graphs of 2-3 pairs of N=5000 -- up to 35 % of the forwards first
 came back with a pose off by 1e-4 ... 6e-4 (labels equal).  Both causes sat in the hypothesis scoring stage and are fixed in
@@ -53,11 +58,17 @@ import torch
 
 
 class InFlight:
-    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False, tail_streams: bool = True):
+    def __init__(self, model, depth: int = 2, device=None, graphs: bool = False, tail_streams: bool = True, zero_copy: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
         self.depth = depth
+        # graphs only: capture each slot's graph ON the caller's input tensors (fp32, contiguous) and hand out the graph's own
+        # output tensors -- no staging copies in, no clones out: 5 small launches and two allocations less per forward, which is
+        # most of the host's share of a captured N = 1000 forward.  Contract: the caller keeps feeding the same input buffers (new
+        # contents in place are fine once the previous forward on them has finished; other buffers are captured as a further
+        # graph, up to 4 per slot) and a result is valid until the same slot runs again, `depth` calls later.
+        self.zero_copy = bool(zero_copy) and bool(graphs) and depth > 1
         dev = device if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("pointdsc_amd has no CPU path: move the model to the GPU first")
@@ -84,7 +95,7 @@ class InFlight:
             torch.cuda.synchronize(dev)
         self._i = 0
         self.graphs = bool(graphs) and depth > 1
-        self._captured = {}                     # slot -> (key, graph, static inputs, static outputs)
+        self._captured = {}                     # slot -> {key: (key, graph, static inputs, static outputs)}
         self._ensure_weights()
 
     def _ensure_weights(self) -> None:
@@ -139,11 +150,16 @@ class InFlight:
         corr = data.get("corr_pos")
         if not (torch.is_tensor(corr) and "testing" in data and data.get("num_corr") is None):
             return None
-        key = (tuple(corr.shape), m.attention_precision, m.compat_format, m.layer_gemm, m._wpack_key)
-        cap = self._captured.get(slot)
-        if cap is None or cap[0] != key:
+        names = ("corr_pos", "src_keypts", "tgt_keypts")
+        zc = self.zero_copy and all(torch.is_tensor(data.get(k)) and data[k].dtype == torch.float32 and data[k].is_contiguous() for k in names)
+        key = (tuple(corr.shape), m.attention_precision, m.compat_format, m.layer_gemm, m._wpack_key,
+               tuple(data[k].data_ptr() for k in names) if zc else None)
+        caps = self._captured.setdefault(slot, {})
+        cap = caps.get(key)
+        if cap is None:
             try:
-                static = {k: data[k].detach().to(torch.float32).contiguous().clone() for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+                # zero-copy: the graph reads the caller's tensors (kept referenced here, so their memory stays theirs)
+                static = {k: (data[k].detach() if zc else data[k].detach().to(torch.float32).contiguous().clone()) for k in names}
                 static["testing"] = True
                 m._ws_slot = self._slots[slot]
                 try:
@@ -156,16 +172,21 @@ class InFlight:
                 finally:
                     m._ws_slot = 0
                 cap = (key, g, static, out)
-                self._captured[slot] = cap
+                if len(caps) >= 4 or any(k[:5] != key[:5] for k in caps):      # other shape / arithmetic / weights: the old graphs are dead
+                    caps.clear()
+                caps[key] = cap
             except Exception as e:        # noqa: BLE001  (capture is an optimisation: fall back to the eager path for good)
                 warnings.warn(f"pointdsc_amd.InFlight: hipGraph capture failed ({e!r}); continuing without graphs", RuntimeWarning)
                 self.graphs = False
                 return None
         _, g, static, out = cap
-        for k in ("corr_pos", "src_keypts", "tgt_keypts"):
-            if data[k].data_ptr() != static[k].data_ptr():
-                static[k].copy_(data[k], non_blocking=True)
+        if not zc:
+            for k in names:
+                if data[k].data_ptr() != static[k].data_ptr():
+                    static[k].copy_(data[k], non_blocking=True)
         g.replay()
+        if zc:
+            return {"final_trans": out["final_trans"], "final_labels": out["final_labels"], "M": None}
         return {"final_trans": out["final_trans"].clone(), "final_labels": out["final_labels"].clone(), "M": None}
 
     def synchronize(self) -> None:

@@ -2030,6 +2030,45 @@ def test_replayed_hipgraph_forwards_reproduce_the_plain_calls():
     gr.close()
 
 
+def test_zero_copy_hipgraph_forwards_reproduce_the_plain_calls():
+    """InFlight(graphs=True, zero_copy=True): each slot's graph is captured on the CALLER's input tensors and the graph's own output
+    tensors are handed out (no staging copies, no clones).  Two input buffer sets alternate (two graphs per slot), their contents
+    are overwritten in place between uses with other pairs, and every result -- read before its slot runs again -- is bit-identical
+    to the plain call on the same pair; a third buffer set of another shape falls back to a fresh capture."""
+    from pointdsc_amd.pipeline import InFlight
+    model, _ = _bench_model("n1000_b1")
+    pairs = [workloads.batch("n1000_b1", i, 1) for i in range(6)]
+    plain = [_forward(model, b) for b in pairs]
+    names = ("corr_pos", "src_keypts", "tgt_keypts")
+    bufs = [{k: g(pairs[0][k]).clone() for k in names} for _ in range(2)]
+    for b in bufs:
+        b["testing"] = True
+    depth = 3
+    gr = InFlight(model, depth=depth, graphs=True, zero_copy=True)
+    pending, bad = [], []
+    for i in range(120):
+        buf = bufs[i % 2]
+        if len(pending) >= 2:                       # the previous forward on THIS buffer set has finished before it is overwritten,
+            j, r = pending.pop(0)                   # and its result is read before its slot runs again (depth = 3 > 2 pending)
+            r["ready"].synchronize()
+            if not (torch.equal(r["final_trans"], plain[j % 6]["final_trans"]) and torch.equal(r["final_labels"], plain[j % 6]["final_labels"])):
+                bad.append(j)
+        for k in names:
+            buf[k].copy_(g(pairs[i % 6][k]))
+        pending.append((i, gr(buf)))
+    gr.synchronize()
+    for j, r in pending:
+        if not (torch.equal(r["final_trans"], plain[j % 6]["final_trans"]) and torch.equal(r["final_labels"], plain[j % 6]["final_labels"])):
+            bad.append(j)
+    assert gr.graphs and gr.zero_copy and len(gr._captured) == depth and all(len(c) == 2 for c in gr._captured.values())
+    assert not bad, f"zero-copy replays differing from the plain call: {bad[:10]}"
+    # results ARE the graph's output tensors: the same storage comes back `depth` calls later
+    r0 = gr(bufs[0]); [gr(bufs[0]) for _ in range(depth - 1)]; r1 = gr(bufs[0])
+    gr.synchronize()
+    assert r0["final_trans"].data_ptr() == r1["final_trans"].data_ptr()
+    gr.close()
+
+
 @pytest.mark.parametrize("mode", ["plain streams", "tail streams", "hipGraphs"])
 def test_forwards_in_flight_stay_exact_under_load(mode):
     """Regression test of r03's exactness findings: batches of 2 pairs of N = 5000 kept in flight -- the shape on
