@@ -504,6 +504,17 @@ size_t pdsc_sm_workspace_bytes(int bs, int N);
 int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
                      int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
                      void* workspace, size_t workspace_bytes, int bs, int N, void* stream);
+/* Two forms, bit-identical results (same arithmetic in the same order):
+ *   streaming (form 1): the 4 N^2-byte matrix is written to the workspace once and streamed from HBM per iteration, the pairs of a
+ *                       batch in one launch; any N up to 65 536;
+ *   register-resident (form 2): ONE persistent launch per pair computes the matrix straight into the chip's vector registers
+ *                       (100 MB at N = 5000 of the 128 MiB the 256 compute units hold) and runs every power iteration from there;
+ *                       per iteration only y crosses the chip, behind a grid barrier.  N <= 5120, 20 rows per compute unit.
+ * pdsc_sm_baseline (= form 0) picks the resident form for 2048 <= N <= 5120 (one pair of N = 5000: 260 us against 447; 8 pairs
+ * 1.84 ms against 2.13; the forms cross between N = 1000 and 2000), the streaming form otherwise. */
+int pdsc_sm_baseline_form(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
+                          int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
+                          void* workspace, size_t workspace_bytes, int bs, int N, int form, void* stream);
 
 /* cal_confidence (models/PointDSC.py:366-401): confidence of a spectral-matching solution from its compatibility matrix
  * M [bs][N][ld] (ld >= N, multiple of 4) and leading eigenvector [bs][N]:

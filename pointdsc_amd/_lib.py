@@ -109,6 +109,7 @@ SIGNATURES = {
     "pdsc_build_corr_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pdsc_sm_workspace_bytes": (_sz, [_i, _i]),
     "pdsc_sm_baseline": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
+    "pdsc_sm_baseline_form": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "pdsc_cal_confidence_workspace_bytes": (_sz, [_i, _i]),
     "pdsc_cal_confidence": (_i, [_vp, _ll, _vp, _i, _i, _vp, _vp, _sz, _i, _i, _vp]),
     "pdsc_eval_stats": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _vp]),

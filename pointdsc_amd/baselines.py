@@ -14,10 +14,15 @@ from . import _lib
 
 
 def SM(corr: torch.Tensor, src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, inlier_threshold: float, top_ratio: float = 0.1,
-       num_iterations: int = 10, return_eig: bool = False):
+       num_iterations: int = 10, return_eig: bool = False, form: str = "auto"):
     """corr [N,6] (or [bs,N,6]) centred correspondence coordinates, src/tgt_keypts [bs,N,3] ->
     (pred_trans [bs,4,4], pred_labels [bs,N]) like the reference's SM(corr, src_keypts, tgt_keypts, args, top_ratio)
-    with ``args.inlier_threshold`` passed explicitly; bs > 1 = independent pairs."""
+    with ``args.inlier_threshold`` passed explicitly; bs > 1 = independent pairs.  ``form``: "streaming" (matrix in HBM, any N),
+    "resident" (the matrix stays in the chip's vector registers: N <= 5120) or "auto" (resident for 2048 <= N <= 5120, where it
+    is faster); same bits either way."""
+    forms = {"auto": 0, "streaming": 1, "resident": 2}
+    if form not in forms:
+        raise ValueError(f"form must be one of {sorted(forms)}, got {form!r}")
     lib = _lib.load()
     if not corr.is_cuda:
         raise RuntimeError("pointdsc_amd has no CPU path: move the tensors to the GPU")
@@ -33,10 +38,10 @@ def SM(corr: torch.Tensor, src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, i
     nb = int(lib.pdsc_sm_workspace_bytes(bs, n))
     ws = torch.empty(nb, device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
-        rc = lib.pdsc_sm_baseline(C.c_void_p(c.data_ptr()), C.c_void_p(src.data_ptr()), C.c_void_p(tgt.data_ptr()),
-                                  float(inlier_threshold), num_top, int(num_iterations), C.c_void_p(trans.data_ptr()),
-                                  C.c_void_p(labels.data_ptr()), C.c_void_p(eig.data_ptr()), C.c_void_p(ws.data_ptr()), nb,
-                                  bs, n, torch.cuda.current_stream().cuda_stream)
+        rc = lib.pdsc_sm_baseline_form(C.c_void_p(c.data_ptr()), C.c_void_p(src.data_ptr()), C.c_void_p(tgt.data_ptr()),
+                                       float(inlier_threshold), num_top, int(num_iterations), C.c_void_p(trans.data_ptr()),
+                                       C.c_void_p(labels.data_ptr()), C.c_void_p(eig.data_ptr()), C.c_void_p(ws.data_ptr()), nb,
+                                       bs, n, forms[form], torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pdsc_sm_baseline")
     return (trans, labels, eig) if return_eig else (trans, labels)
 

@@ -15,6 +15,7 @@
 //                      y^2 are summed in a fixed order, so the result is deterministic), one launch per iteration.
 // 4 N^2 bytes per iteration: 100 MB at N = 5000, i.e. the whole matrix fits the 256 MiB Infinity Cache.
 #include <math.h>
+#include <type_traits>
 #include "pdsc_common.h"
 
 namespace pdsc {
@@ -121,6 +122,202 @@ __global__ __launch_bounds__(256) void sm_matvec_kernel(const float* __restrict_
     if (lane == 0) wsum[wave] = sq;
     __syncthreads();
     if (t == 0) partial_out[(size_t)b * SMV_MAX_BLOCKS + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ---- the matrix in the register file (r04): single pairs of N <= 5120 ------------------------------------------------
+// The reference runs SM() one pair at a time (it asserts bs == 1).  4 N^2 bytes are 100 MB at N = 5000 and the chip's vector
+// register files hold 128 MiB (256 CUs x 512 KiB): ONE persistent launch computes the matrix straight into registers -- 20 rows
+// per workgroup (one workgroup per CU, one wave per SIMD with all 512 registers: 5 rows x 80 columns per lane), never written to
+// HBM -- and runs every power iteration from there; per iteration only y (20 KB) crosses the chip, behind one grid barrier.
+// Same arithmetic in the same order as sm_matrix_kernel + sm_matvec_kernel (column mapping of the lanes, fmaf chains, the
+// per-16-row partial sums of |y|^2 and their sequential total): y and the partials are bit-identical to the streaming path's.
+constexpr int SMR_CPL = 20;                      // f32x4 column groups per lane: columns 4 lane + 256 g .. + 3
+constexpr int SMR_RPW = 5;                       // rows per wave
+constexpr int SMR_ROWS = 4 * SMR_RPW;            // rows per workgroup
+constexpr int SMR_MAXN = SMR_CPL * 256;          // 5120
+constexpr int SMR_REPLICAS = 32;                 // copies of y (one wave instruction writes a row's value into all of them)
+
+template <int B, int E, class F>
+__device__ __forceinline__ void smr_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        smr_for<B + 1, E>(f);
+    }
+}
+
+struct SmResidentArgs {
+    const float* corr;      // [N][6]
+    float sigma2;
+    int N, iters, nwg;
+    float* ya;              // [N] y of even iterations
+    float* yb;              // [N] y of odd iterations
+    float* yrep;            // [2][SMR_REPLICAS][SMR_MAXN] the same y, replicated: what the workgroups read back (see the kernel)
+    float* partial_out;     // [nblocks] per-16-row partial sums of the LAST y (what sm_finish_kernel reads)
+    unsigned int* bar;      // grid barrier flags (256 arrival words + 8 release words 64 B apart), zero at launch
+};
+
+// Grid barrier.  Agent-scope accesses bypass the L2s (eight XCDs, eight L2s) and are performed at the memory side, one line at a
+// time -- so what a barrier costs is the number of requests that hit the same line.  Measured on this kernel (250 workgroups):
+// every workgroup adding to one counter, or to one of eight, and polling it: ~25 us per barrier; every workgroup polling all 250
+// arrival flags: the same.  Hence: every workgroup posts the round in ITS OWN arrival word (250 plain stores); workgroup 0 alone
+// polls the arrival words (one coalesced 1 KiB load per round) and then posts the round in eight release words, one per XCD and
+// 64 bytes apart; the other workgroups poll only their XCD's release word (~31 pollers per line).
+// No fences: an agent-scope release / acquire fence is an L2-wide write-back / invalidate, and 4 waves x 31 workgroups per XCD
+// issuing one each per barrier were the 35 us per iteration this kernel first showed -- whatever the flag protocol.  Instead the
+// data that crosses workgroups (y: 20 KB per iteration) is itself stored and loaded at agent scope (write-through / L2 bypass),
+// and a workgroup arrives only after its own stores have been acknowledged (s_waitcnt vmcnt(0) in every wave, then the
+// workgroup barrier).  All workgroups are resident (one per CU, checked by the launcher), so the waits cannot starve.
+constexpr int SMR_REL = 256, SMR_REL_STRIDE = 16;     // flag words: [0, 256) arrivals, 256 + 16 x: release word of XCD x
+__device__ __forceinline__ void smr_grid_barrier(unsigned int* flags, int nwg, unsigned int round /* 1, 2, ... */) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (;;) {
+            bool ok = true;
+            if (threadIdx.x > 0 && (int)threadIdx.x < nwg) ok = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= round;
+            if (__syncthreads_and(ok)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (threadIdx.x < 8) __hip_atomic_store(flags + SMR_REL + SMR_REL_STRIDE * threadIdx.x, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(flags + blockIdx.x, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int* rel = flags + SMR_REL + SMR_REL_STRIDE * (blockIdx.x & 7);
+            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void sm_resident_kernel(SmResidentArgs a) {
+    __shared__ __attribute__((aligned(16))) float vs[SMR_MAXN];      // scaled v, zero beyond N
+    __shared__ __attribute__((aligned(16))) float parts[SMR_MAXN / SMV_ROWS];      // 320 = a multiple of 16; [nblocks, 320) stays 0
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int N = a.N;
+    const int row0 = blockIdx.x * SMR_ROWS + wave * SMR_RPW;
+    const float* c = a.corr;
+
+    // ---- the matrix rows of this wave, computed once (arithmetic of sm_matrix_kernel) ----
+    // (every index below is a compile-time constant -- smr_for unrolls in the front end -- so the 400 matrix values of a lane are
+    //  registers from the start; with `#pragma unroll` loops the array went to scratch)
+    f32x4 m[SMR_RPW][SMR_CPL];
+    float ci[SMR_RPW][6];
+    smr_for<0, SMR_RPW>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        smr_for<0, 6>([&](auto dc) { ci[r][decltype(dc)::value] = c[(size_t)min(row0 + r, N - 1) * 6 + decltype(dc)::value]; });
+    });
+    smr_for<0, SMR_CPL>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        const int j4 = lane * 4 + 256 * g;
+        if (256 * g >= N) {                      // (workgroup-uniform) a column group entirely past N: never read by the mat-vec
+            smr_for<0, SMR_RPW>([&](auto rc) { m[decltype(rc)::value][g] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+            return;
+        }
+        float cj[4][6];
+        smr_for<0, 4>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const int j = min(j4 + e, N - 1);
+            smr_for<0, 6>([&](auto dc) { cj[e][decltype(dc)::value] = c[(size_t)j * 6 + decltype(dc)::value]; });
+        });
+        smr_for<0, SMR_RPW>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int i = row0 + r;
+            smr_for<0, 4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                const float ax = ci[r][0] - cj[e][0], ay = ci[r][1] - cj[e][1], az = ci[r][2] - cj[e][2];
+                const float bx = ci[r][3] - cj[e][3], by = ci[r][4] - cj[e][4], bz = ci[r][5] - cj[e][5];
+                const float ds = sqrtf((ax * ax + ay * ay) + az * az);
+                const float dt = sqrtf((bx * bx + by * by) + bz * bz);
+                const float d = ds - dt;
+                float mm = fmaxf(0.0f, 4.5f - ((d * d) / 2.0f) / a.sigma2);
+                if (j4 + e == i || j4 + e >= N) mm = 0.0f;
+                m[r][g][e] = mm;
+            });
+        });
+    });
+
+    const int nblocks = ceil_div_dev(N, SMV_ROWS);
+    for (int j = t; j < SMR_MAXN; j += 256) vs[j] = j < N ? 1.0f : 0.f;        // v0 = 1 (x scale 1)
+    for (int p = t; p < SMR_MAXN / SMV_ROWS; p += 256) parts[p] = 0.f;
+    __syncthreads();
+    for (int it = 0; it < a.iters; ++it) {
+        float* ycur = (it & 1) ? a.yb : a.ya;
+        // y = M v: the lane's columns ascending, one fmaf chain per element, (a0 + a1) + (a2 + a3), wave_sum -- as sm_matvec_kernel
+        float acc[SMR_RPW][4];
+        smr_for<0, SMR_RPW>([&](auto rc) { smr_for<0, 4>([&](auto ec) { acc[decltype(rc)::value][decltype(ec)::value] = 0.f; }); });
+        smr_for<0, SMR_CPL>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (256 * g < N && lane * 4 + 256 * g < ((N + 3) & ~3)) {       // the streaming kernel's loop bound (columns beyond contribute m = 0 anyway)
+                const f32x4 x = *reinterpret_cast<const f32x4*>(vs + lane * 4 + 256 * g);
+                smr_for<0, SMR_RPW>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    smr_for<0, 4>([&](auto ec) { constexpr int e = decltype(ec)::value; acc[r][e] = fmaf(m[r][g][e], x[e], acc[r][e]); });
+                });
+            }
+        });
+        smr_for<0, SMR_RPW>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const float yi = wave_sum((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]));
+            // y crosses the chip through memory (agent scope: no L2 in between).  250 workgroups reading the same 20 KB back from
+            // the handful of HBM channels it lives in took ~10 us per iteration; so a row's value is written into 32 copies by one
+            // wave instruction (lane l -> copy l) and workgroup w reads copy w % 32: 8 readers per copy.  Lane 32 writes the plain
+            // vector the finish kernel reads.
+            if (row0 + r < N) {
+                if (lane < SMR_REPLICAS)
+                    __hip_atomic_store(a.yrep + ((size_t)(it & 1) * SMR_REPLICAS + lane) * SMR_MAXN + row0 + r, yi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (lane == SMR_REPLICAS)
+                    ycur[row0 + r] = yi;
+            }
+        });
+        smr_grid_barrier(a.bar, a.nwg, (unsigned)(it + 1));
+        // every workgroup: y into LDS (one coalesced pass), |y|^2 in the streaming kernel's grouping (blocks of 16 rows: per wave a
+        // chain over its 4 rows, then (w0 + w1) + (w2 + w3)), the blocks summed in order -> the same scale bits
+        {
+            // agent-scope (sc0 sc1: past both caches) 16-byte loads; rows past N come back as the zeros the copies were filled with
+            const float* ysrc = a.yrep + ((size_t)(it & 1) * SMR_REPLICAS + (blockIdx.x & (SMR_REPLICAS - 1))) * SMR_MAXN;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ysrc, 0, SMR_MAXN * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < SMR_MAXN / 1024; ++u) {
+                const int j = 4 * t + 1024 * u;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, j * 4, 0, 1 | 16));
+                *reinterpret_cast<f32x4*>(vs + j) = v;
+            }
+        }
+        __syncthreads();
+        for (int p = t; p < nblocks; p += 256) {
+            float w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = p * SMV_ROWS + 4 * q + r;
+                    if (i < N) sq = fmaf(vs[i], vs[i], sq);
+                }
+                w[q] = sq;
+            }
+            parts[p] = (w[0] + w[1]) + (w[2] + w[3]);
+        }
+        __syncthreads();
+        if (it + 1 == a.iters) {
+            if (blockIdx.x == 0)
+                for (int p = t; p < nblocks; p += 256) a.partial_out[p] = parts[p];
+            break;
+        }
+        float s = 0.f;                                       // the blocks in order, as the streaming kernel sums them; the padding adds
+        for (int p0 = 0; p0 < nblocks; p0 += 16) {           // + 0.0f (exact), so a batch is 4 x ds_read_b128 and 16 dependent adds
+            f32x4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4*>(parts + p0 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += q[u][e];
+        }
+        const float scale = 1.0f / (sqrtf(s) + 1e-6f);
+        for (int j = t; j < N; j += 256) vs[j] = vs[j] * scale;       // (same product as the streaming kernel's vb[j] * scale)
+        __syncthreads();
+    }
 }
 
 // final normalisation + selection mask: eig = y * scale; weights = eig * [rank(eig) < num_top]  (stable descending
@@ -249,18 +446,31 @@ using namespace pdsc;
 extern "C" size_t pdsc_sm_workspace_bytes(int bs, int N) {
     if (bs <= 0 || N <= 0) return 0;
     const size_t ld = (size_t)pdsc_compat_ld(N);
-    return (size_t)bs * N * ld * 4 + (size_t)bs * N * 4 * 3 + (size_t)bs * SMV_MAX_BLOCKS * 4 * 2 + 1024;
+    // matrix (streaming form) | 3 vectors | 2 x partial sums / barrier flags | y copies of the register-resident form
+    return (size_t)bs * N * ld * 4 + (size_t)bs * N * 4 * 3 + (size_t)bs * SMV_MAX_BLOCKS * 4 * 2 +
+           (N <= SMR_MAXN ? (size_t)bs * 2 * SMR_REPLICAS * SMR_MAXN * 4 : 0) + 1024;
 }
 
-extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
-                                int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
-                                void* workspace, size_t workspace_bytes, int bs, int N, void* stream) {
-    PDSC_REQUIRE(corr_pos && src_keypts && tgt_keypts && pred_trans && pred_labels && workspace, "pdsc_sm_baseline: null pointer");
-    PDSC_REQUIRE(bs > 0 && N > 1 && num_top >= 0 && num_top <= N && num_iterations >= 1, "pdsc_sm_baseline: bs=%d N=%d top=%d iters=%d",
+static int sm_device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        cus = v;
+    }
+    return cus;
+}
+
+// form: 0 = pick, 1 = HBM-streaming form, 2 = register-resident matrix (N <= 5120 and 20 rows per CU, else an error)
+static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
+                            int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
+                            void* workspace, size_t workspace_bytes, int bs, int N, void* stream, int form, const char* who) {
+    PDSC_REQUIRE(corr_pos && src_keypts && tgt_keypts && pred_trans && pred_labels && workspace, "%s: null pointer", who);
+    PDSC_REQUIRE(bs > 0 && N > 1 && num_top >= 0 && num_top <= N && num_iterations >= 1, "%s: bs=%d N=%d top=%d iters=%d", who,
                  bs, N, num_top, num_iterations);
-    PDSC_REQUIRE(ceil_div(N, SMV_ROWS) <= SMV_MAX_BLOCKS, "pdsc_sm_baseline: N=%d too large (max %d)", N, SMV_ROWS * SMV_MAX_BLOCKS);
+    PDSC_REQUIRE(ceil_div(N, SMV_ROWS) <= SMV_MAX_BLOCKS, "%s: N=%d too large (max %d)", who, N, SMV_ROWS * SMV_MAX_BLOCKS);
     if (workspace_bytes < pdsc_sm_workspace_bytes(bs, N)) {
-        set_error("pdsc_sm_baseline: workspace %zu < %zu bytes", workspace_bytes, pdsc_sm_workspace_bytes(bs, N));
+        set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, pdsc_sm_workspace_bytes(bs, N));
         return PDSC_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -274,23 +484,55 @@ extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, 
     // sigma = inlier_threshold / 3 in double (python floats), sigma ** 2 in double, then the fp32 divisor of a tensor op
     const double sigma = (double)inlier_threshold / 3.0;
     const float sigma2 = (float)(sigma * sigma);
-    hipLaunchKernelGGL(sm_matrix_kernel, dim3(ceil_div((int)ld, 256), ceil_div(N, 64), bs), dim3(256), 0, st, corr_pos, sigma2, M, ld, N);
-    int rc = check_launch("pdsc_sm_baseline(matrix)");
-    if (rc != PDSC_OK) return rc;
-    // v0 = 1 (bit pattern of 1.0f)
-    rc = launch_fill_u32((unsigned int*)va, 0x3f800000u, (size_t)bs * N, st);      // a kernel, like every other fill of the library (no hipMemsetAsync)
-    if (rc != PDSC_OK) return rc;
-    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sm_matvec_kernel), 160 * 1024 - 64, "pdsc_sm_baseline(dynamic LDS)");
-    if (rc != PDSC_OK) return rc;
     const int nblocks = ceil_div(N, SMV_ROWS);
-    float *vin = va, *vout = vb, *pin = nullptr, *pout = pa;
-    for (int it = 0; it < num_iterations; ++it) {
-        hipLaunchKernelGGL(sm_matvec_kernel, dim3(nblocks, bs), dim3(256), (size_t)ld * sizeof(float), st, M, ld, vin, pin, nblocks, vout,
-                           pout, N);
-        rc = check_launch("pdsc_sm_baseline(matvec)");
+    int rc;
+    float *vin, *pin, *vout;
+    const int nwg = ceil_div(N, SMR_ROWS);
+    const bool fits = N <= SMR_MAXN && nwg <= sm_device_cus();
+    PDSC_REQUIRE(form != 2 || fits, "%s: the register-resident form needs N <= %d and %d rows per compute unit (N=%d, %d CUs)", who,
+                 SMR_MAXN, SMR_ROWS, N, sm_device_cus());
+    // which form: measured per call, 10 iterations (tools/sm_resident_probe.py, tools/sm_bench.py, profiles/r04_z_sm_resident.txt):
+    // one pair of N = 1000 114 us resident / 105 streaming, 2048: 150 / 174, 3000: 185 / 250, 5000: 260 / 447; 8 pairs of N = 5000
+    // 1841 / 2127 (consecutive pairs' launches overlap).  The resident form's iteration is a grid barrier and a y round trip
+    // (7.5-12.7 us whatever N), the streaming form's a pass over 4 N^2 bytes; they cross between N = 1000 and 2000.
+    if (form == 2 || (form == 0 && fits && N >= 2048)) {
+        // the matrix never leaves the register file: one persistent launch per pair (pairs one after the other on the stream; the
+        // reference itself runs one pair per call).  pb (unused by this form) holds each pair's grid-barrier counters.
+        rc = launch_fill_u32((unsigned int*)pb, 0u, (size_t)bs * SMV_MAX_BLOCKS + (size_t)bs * 2 * SMR_REPLICAS * SMR_MAXN, st);      // barrier flags + the y copies (zero past N)
         if (rc != PDSC_OK) return rc;
-        float* tv = vin; vin = vout; vout = tv;
-        pin = pout; pout = (pout == pa) ? pb : pa;
+        for (int b = 0; b < bs; ++b) {
+            SmResidentArgs a{};
+            a.corr = corr_pos + (size_t)b * N * 6; a.sigma2 = sigma2; a.N = N; a.iters = num_iterations; a.nwg = nwg;
+            a.ya = va + (size_t)b * N; a.yb = vb + (size_t)b * N;
+            a.yrep = pb + (size_t)bs * SMV_MAX_BLOCKS + (size_t)b * 2 * SMR_REPLICAS * SMR_MAXN;
+            a.partial_out = pa + (size_t)b * SMV_MAX_BLOCKS;
+            a.bar = (unsigned int*)pb + (size_t)b * SMV_MAX_BLOCKS;
+            hipLaunchKernelGGL(sm_resident_kernel, dim3(nwg), dim3(256), 0, st, a);
+        }
+        rc = check_launch("pdsc_sm_baseline(resident)");
+        if (rc != PDSC_OK) return rc;
+        vin = ((num_iterations - 1) & 1) ? vb : va;      // the last y (unnormalised)
+        vout = ((num_iterations - 1) & 1) ? va : vb;
+        pin = pa;
+    } else {
+        hipLaunchKernelGGL(sm_matrix_kernel, dim3(ceil_div((int)ld, 256), ceil_div(N, 64), bs), dim3(256), 0, st, corr_pos, sigma2, M, ld, N);
+        rc = check_launch("pdsc_sm_baseline(matrix)");
+        if (rc != PDSC_OK) return rc;
+        // v0 = 1 (bit pattern of 1.0f)
+        rc = launch_fill_u32((unsigned int*)va, 0x3f800000u, (size_t)bs * N, st);      // a kernel, like every other fill of the library (no hipMemsetAsync)
+        if (rc != PDSC_OK) return rc;
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sm_matvec_kernel), 160 * 1024 - 64, "pdsc_sm_baseline(dynamic LDS)");
+        if (rc != PDSC_OK) return rc;
+        float* pout = pa;
+        vin = va; vout = vb; pin = nullptr;
+        for (int it = 0; it < num_iterations; ++it) {
+            hipLaunchKernelGGL(sm_matvec_kernel, dim3(nblocks, bs), dim3(256), (size_t)ld * sizeof(float), st, M, ld, vin, pin, nblocks, vout,
+                               pout, N);
+            rc = check_launch("pdsc_sm_baseline(matvec)");
+            if (rc != PDSC_OK) return rc;
+            float* tv = vin; vin = vout; vout = tv;
+            pin = pout; pout = (pout == pa) ? pb : pa;
+        }
     }
     // vin = last y (unnormalised), pin = its partial sums
     float* eig = leading_eig ? leading_eig : vout;
@@ -298,6 +540,21 @@ extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, 
     rc = check_launch("pdsc_sm_baseline(finish)");
     if (rc != PDSC_OK) return rc;
     return pdsc_rigid_transform_3d(src_keypts, tgt_keypts, wts, 0.0f, pred_trans, bs, N, stream);
+}
+
+extern "C" int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
+                                int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
+                                void* workspace, size_t workspace_bytes, int bs, int N, void* stream) {
+    return sm_baseline_impl(corr_pos, src_keypts, tgt_keypts, inlier_threshold, num_top, num_iterations, pred_trans, pred_labels,
+                            leading_eig, workspace, workspace_bytes, bs, N, stream, 0, "pdsc_sm_baseline");
+}
+
+extern "C" int pdsc_sm_baseline_form(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
+                                     int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
+                                     void* workspace, size_t workspace_bytes, int bs, int N, int form, void* stream) {
+    PDSC_REQUIRE(form >= 0 && form <= 2, "pdsc_sm_baseline_form: form=%d (0 pick, 1 streaming, 2 register-resident)", form);
+    return sm_baseline_impl(corr_pos, src_keypts, tgt_keypts, inlier_threshold, num_top, num_iterations, pred_trans, pred_labels,
+                            leading_eig, workspace, workspace_bytes, bs, N, stream, form, "pdsc_sm_baseline_form");
 }
 
 extern "C" size_t pdsc_cal_confidence_workspace_bytes(int bs, int N) {

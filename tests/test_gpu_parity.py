@@ -1706,6 +1706,33 @@ def test_sm_baseline_matches_reference_golden(name):
     assert (trans[0].cpu() - torch.from_numpy(fx["ref_pred_trans"][0])).abs().max() < tol * max(1.0, float(fx["scale"]) / 3.0)
 
 
+@pytest.mark.parametrize("n,bs,iters", [(5000, 1, 10), (5120, 1, 10), (4999, 2, 10), (2053, 3, 7), (1000, 1, 10), (300, 2, 1), (21, 1, 3)])
+def test_sm_baseline_register_resident_form_equals_the_streaming_form(n, bs, iters):
+    """The spectral-matching baseline has two forms (pdsc_sm_baseline_form): the N x N matrix in the chip's vector registers (N <= 5120:
+    one persistent launch per pair, a grid barrier per power iteration), or written to HBM and streamed.  Same arithmetic in the
+    same order: poses, labels and the eigenvector agree bit for bit -- full and ragged last column groups, the largest size that
+    fits, several pairs, odd and even iteration counts (the y buffers alternate), a matrix smaller than one workgroup's rows."""
+    from pointdsc_amd import baselines
+    batch = synthetic.make_batch(bs, n, seed=40 + n, inlier_ratio=0.3)
+    c, s_, t_ = g(batch["corr_pos"]), g(batch["src_keypts"]), g(batch["tgt_keypts"])
+    a = baselines.SM(c, s_, t_, 0.10, num_iterations=iters, return_eig=True, form="resident")
+    b = baselines.SM(c, s_, t_, 0.10, num_iterations=iters, return_eig=True, form="streaming")
+    for x, y, what in zip(a, b, ("pred_trans", "pred_labels", "leading_eig")):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), what
+    for _ in range(20):                                   # repeated launches: the barrier counter starts from zero every time
+        again = baselines.SM(c, s_, t_, 0.10, num_iterations=iters, return_eig=True, form="resident")
+        assert all(torch.equal(x, y) for x, y in zip(again, a))
+    auto = baselines.SM(c, s_, t_, 0.10, num_iterations=iters, return_eig=True)          # whichever form the library picks
+    assert all(torch.equal(x, y) for x, y in zip(auto, a))
+    # one size past the register file: the resident form refuses, the library's own choice is the streaming form
+    if n == 5120:
+        big = synthetic.make_batch(1, 5121, seed=41, inlier_ratio=0.3)
+        args = (g(big["corr_pos"]), g(big["src_keypts"]), g(big["tgt_keypts"]), 0.10)
+        with pytest.raises(RuntimeError, match="register-resident"):
+            baselines.SM(*args, form="resident")
+        assert all(torch.equal(p, q) for p, q in zip(baselines.SM(*args, return_eig=True), baselines.SM(*args, return_eig=True, form="streaming")))
+
+
 def test_cal_confidence_matches_reference_golden():
     """pdsc_cal_confidence vs the reference's own PointDSC.cal_confidence (models/PointDSC.py:366-401) on seeded pairs:
     M rebuilt bit-exactly by pdsc_spatial_compat, leading eigenvector = the reference's; three methods; batch of 2."""
