@@ -15,6 +15,7 @@
 //                      y^2 are summed in a fixed order, so the result is deterministic), one launch per iteration.
 // 4 N^2 bytes per iteration: 100 MB at N = 5000, i.e. the whole matrix fits the 256 MiB Infinity Cache.
 #include <math.h>
+#include <mutex>
 #include <type_traits>
 #include "pdsc_common.h"
 
@@ -451,6 +452,34 @@ extern "C" size_t pdsc_sm_workspace_bytes(int bs, int N) {
            (N <= SMR_MAXN ? (size_t)bs * 2 * SMR_REPLICAS * SMR_MAXN * 4 : 0) + 1024;
 }
 
+// Two register-resident launches must never share the chip: each needs (nearly) every compute unit for its grid barrier, and two
+// half-dispatched grids would wait for each other forever.  Launches of one stream are ordered anyway; launches of different
+// streams of this process are chained through an event (the next one waits for the previous one's end, whatever its stream).
+// Not covered: another PROCESS running the same kernel on the same GPU at the same time.
+static std::mutex g_smr_mutex;
+static hipEvent_t g_smr_done = nullptr;
+static bool g_smr_recorded = false;
+
+static int smr_chain_begin(hipStream_t st) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return PDSC_OK;   // (a captured graph orders its own nodes)
+    if (!g_smr_done && hipEventCreateWithFlags(&g_smr_done, hipEventDisableTiming) != hipSuccess) {
+        set_error("pdsc_sm_baseline: hipEventCreate failed");
+        return PDSC_ERR_LAUNCH;
+    }
+    if (g_smr_recorded && hipStreamWaitEvent(st, g_smr_done, 0) != hipSuccess) {
+        set_error("pdsc_sm_baseline: hipStreamWaitEvent failed");
+        return PDSC_ERR_LAUNCH;
+    }
+    return PDSC_OK;
+}
+
+static void smr_chain_end(hipStream_t st) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
+    if (g_smr_done && hipEventRecord(g_smr_done, st) == hipSuccess) g_smr_recorded = true;
+}
+
 static int sm_device_cus() {
     static int cus = -1;
     if (cus < 0) {
@@ -498,6 +527,9 @@ static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, cons
     if (form == 2 || (form == 0 && fits && N >= 2048)) {
         // the matrix never leaves the register file: one persistent launch per pair (pairs one after the other on the stream; the
         // reference itself runs one pair per call).  pb (unused by this form) holds each pair's grid-barrier counters.
+        std::lock_guard<std::mutex> lock(g_smr_mutex);
+        rc = smr_chain_begin(st);
+        if (rc != PDSC_OK) return rc;
         rc = launch_fill_u32((unsigned int*)pb, 0u, (size_t)bs * SMV_MAX_BLOCKS + (size_t)bs * 2 * SMR_REPLICAS * SMR_MAXN, st);      // barrier flags + the y copies (zero past N)
         if (rc != PDSC_OK) return rc;
         for (int b = 0; b < bs; ++b) {
@@ -509,6 +541,7 @@ static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, cons
             a.bar = (unsigned int*)pb + (size_t)b * SMV_MAX_BLOCKS;
             hipLaunchKernelGGL(sm_resident_kernel, dim3(nwg), dim3(256), 0, st, a);
         }
+        smr_chain_end(st);
         rc = check_launch("pdsc_sm_baseline(resident)");
         if (rc != PDSC_OK) return rc;
         vin = ((num_iterations - 1) & 1) ? vb : va;      // the last y (unnormalised)

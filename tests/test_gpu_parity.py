@@ -1733,6 +1733,34 @@ def test_sm_baseline_register_resident_form_equals_the_streaming_form(n, bs, ite
         assert all(torch.equal(p, q) for p, q in zip(baselines.SM(*args, return_eig=True), baselines.SM(*args, return_eig=True, form="streaming")))
 
 
+@pytest.mark.timeout(120)
+def test_sm_baseline_register_resident_launches_of_two_streams_do_not_share_the_chip():
+    """Each register-resident launch needs nearly every compute unit for its grid barrier; two of them dispatched half each would
+    wait for each other forever.  The library chains them through an event whatever stream they are enqueued on: 30 rounds of two
+    streams launching at the same time complete, each with the streaming form's bits."""
+    from pointdsc_amd import baselines
+    n = 5000
+    a = synthetic.make_batch(1, n, seed=61, inlier_ratio=0.3)
+    b = synthetic.make_batch(1, n, seed=62, inlier_ratio=0.3)
+    A = tuple(g(a[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts"))
+    B = tuple(g(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts"))
+    want_a = baselines.SM(*A, 0.10, return_eig=True, form="streaming")
+    want_b = baselines.SM(*B, 0.10, return_eig=True, form="streaming")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(30):
+        with torch.cuda.stream(s1):
+            ra = baselines.SM(*A, 0.10, return_eig=True, form="resident")
+        with torch.cuda.stream(s2):
+            rb = baselines.SM(*B, 0.10, return_eig=True, form="resident")
+        outs.append((ra, rb))
+    s1.synchronize()
+    s2.synchronize()
+    for ra, rb in outs:
+        assert all(torch.equal(x, y) for x, y in zip(ra, want_a)) and all(torch.equal(x, y) for x, y in zip(rb, want_b))
+
+
 def test_cal_confidence_matches_reference_golden():
     """pdsc_cal_confidence vs the reference's own PointDSC.cal_confidence (models/PointDSC.py:366-401) on seeded pairs:
     M rebuilt bit-exactly by pdsc_spatial_compat, leading eigenvector = the reference's; three methods; batch of 2."""
