@@ -72,9 +72,25 @@ __global__ __launch_bounds__(256) void sm_matvec_kernel(const float* __restrict_
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float scale = 1.0f;
     if (partial_in) {
+        // sum of the previous iteration's per-block |y|^2 in block order (fixed order: deterministic; every workgroup needs it before
+        // its first multiply).  Staged through the (still unused) v area by one coalesced pass and summed from LDS in batches of 16
+        // -- read from global memory one dependent add at a time it was a fifth of a workgroup's life at N = 10 000.  The padding
+        // adds + 0.0f: same bits.
+        const int np16 = (n_partial_in + 15) & ~15;                  // <= ld
+        for (int p = t; p < np16; p += 256) vs[p] = p < n_partial_in ? partial_in[(size_t)b * SMV_MAX_BLOCKS + p] : 0.f;
+        __syncthreads();
         float s = 0.f;
-        for (int p = 0; p < n_partial_in; ++p) s += partial_in[(size_t)b * SMV_MAX_BLOCKS + p];   // fixed order: deterministic
+        for (int p0 = 0; p0 < np16; p0 += 16) {
+            f32x4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4*>(vs + p0 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += q[u][e];
+        }
         scale = 1.0f / (sqrtf(s) + 1e-6f);
+        __syncthreads();                                             // (the v area is overwritten next)
     }
     const float* vb = v + (size_t)b * N;
     for (int j = t; j < ld; j += 256) vs[j] = j < N ? vb[j] * scale : 0.f;
@@ -95,21 +111,37 @@ __global__ __launch_bounds__(256) void sm_matvec_kernel(const float* __restrict_
         }
         // columns >= N never enter the sums: a caller's padding columns [N, ld) may hold anything (0 * NaN would poison a row)
         const int n4 = (N + 3) & ~3;                                // <= ld (ld is a multiple of 4)
-        for (int j = lane * 4; j < n4; j += 256) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(vs + j);
-            f32x4 m[R];
+        // four column steps (16 loads of 1 KiB per wave) in flight before the first multiply: with one step per trip a wave had 4 KiB
+        // outstanding and a CU 16-32 KiB -- a quarter of what 8 TB/s x the HBM round trip asks for.  The fmaf chains still walk the
+        // columns in ascending order: same bits.
+        constexpr int U = 4;
+        for (int j0 = lane * 4; j0 < n4; j0 += 256 * U) {
+            f32x4 x[U], m[U][R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) m[r] = *reinterpret_cast<const f32x4*>(row[r] + j);
-            if (j + 4 > N) {                                        // the one ragged group of the row
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 256 * u;
+                if (j < n4) {
+                    x[u] = *reinterpret_cast<const f32x4*>(vs + j);
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) m[r][e] = j + e < N ? m[r][e] : 0.f;
+                    for (int r = 0; r < R; ++r) m[u][r] = *reinterpret_cast<const f32x4*>(row[r] + j);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 256 * u;
+                if (j < n4) {
+                    if (j + 4 > N) {                                    // the one ragged group of the row
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(m[r][e], x[e], acc[r][e]);
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m[u][r][e] = j + e < N ? m[u][r][e] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(m[u][r][e], x[u][e], acc[r][e]);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -521,10 +553,10 @@ static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, cons
     PDSC_REQUIRE(form != 2 || fits, "%s: the register-resident form needs N <= %d and %d rows per compute unit (N=%d, %d CUs)", who,
                  SMR_MAXN, SMR_ROWS, N, sm_device_cus());
     // which form: measured per call, 10 iterations (tools/sm_resident_probe.py, tools/sm_bench.py, profiles/r04_z_sm_resident.txt):
-    // one pair of N = 1000 114 us resident / 105 streaming, 2048: 150 / 174, 3000: 185 / 250, 5000: 260 / 447; 8 pairs of N = 5000
-    // 1841 / 2127 (consecutive pairs' launches overlap).  The resident form's iteration is a grid barrier and a y round trip
-    // (7.5-12.7 us whatever N), the streaming form's a pass over 4 N^2 bytes; they cross between N = 1000 and 2000.
-    if (form == 2 || (form == 0 && fits && N >= 2048)) {
+    // one pair of N = 1000 121 us resident / 89 streaming, 2048: 153 / 131, 3000: 187 / 180, 5000: 264 / 355; 8 pairs of N = 5000
+    // 1816 / 1997 (consecutive pairs' launches overlap).  The resident form's iteration is a grid barrier and a y round trip
+    // (8-13 us whatever N), the streaming form's a pass over 4 N^2 bytes (5.5-25 us); they cross a little above N = 3000.
+    if (form == 2 || (form == 0 && fits && N >= 3584)) {
         // the matrix never leaves the register file: one persistent launch per pair (pairs one after the other on the stream; the
         // reference itself runs one pair per call).  pb (unused by this form) holds each pair's grid-barrier counters.
         std::lock_guard<std::mutex> lock(g_smr_mutex);
