@@ -510,8 +510,8 @@ int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float
  *   register-resident (form 2): ONE persistent launch per pair computes the matrix straight into the chip's vector registers
  *                       (100 MB at N = 5000 of the 128 MiB the 256 compute units hold) and runs every power iteration from there;
  *                       per iteration only y crosses the chip, behind a grid barrier.  N <= 5120, 20 rows per compute unit.
- * pdsc_sm_baseline (= form 0) picks the resident form for 3584 <= N <= 5120 (one pair of N = 5000: 264 us against 355; 8 pairs
- * 1.82 ms against 2.00; the forms cross a little above N = 3000), the streaming form otherwise. */
+ * pdsc_sm_baseline (= form 0) picks the resident form for 3584 <= N <= 5120 (one pair of N = 5000: 252 us against 342; 8 pairs
+ * 1.78 ms against 1.90; the forms cross a little above N = 3000), the streaming form otherwise. */
 int pdsc_sm_baseline_form(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
                           int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
                           void* workspace, size_t workspace_bytes, int bs, int N, int form, void* stream);

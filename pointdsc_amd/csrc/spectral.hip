@@ -358,11 +358,23 @@ __global__ __launch_bounds__(256, 1) void sm_resident_kernel(SmResidentArgs a) {
 __global__ __launch_bounds__(256) void sm_finish_kernel(const float* __restrict__ y, const float* __restrict__ partial_in,
                                                         int n_partial_in, int num_top, float* __restrict__ eig,
                                                         float* __restrict__ labels, float* __restrict__ weights, int N) {
+    __shared__ __attribute__((aligned(16))) float parts[SMV_MAX_BLOCKS];      // the partials, zero padded to a multiple of 16
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int np16 = (n_partial_in + 15) & ~15;
+    for (int p = threadIdx.x; p < np16; p += 256) parts[p] = p < n_partial_in ? partial_in[(size_t)b * SMV_MAX_BLOCKS + p] : 0.f;
+    __syncthreads();
     if (i >= N) return;
-    float s = 0.f;
-    for (int p = 0; p < n_partial_in; ++p) s += partial_in[(size_t)b * SMV_MAX_BLOCKS + p];
+    float s = 0.f;                                                   // block order, as sm_matvec_kernel sums them (+ 0.0f padding: same bits)
+    for (int p0 = 0; p0 < np16; p0 += 16) {
+        f32x4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4*>(parts + p0 + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += q[u][e];
+    }
     const float scale = 1.0f / (sqrtf(s) + 1e-6f);
     const float* yb = y + (size_t)b * N;
     const float ei = yb[i] * scale;
@@ -553,8 +565,8 @@ static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, cons
     PDSC_REQUIRE(form != 2 || fits, "%s: the register-resident form needs N <= %d and %d rows per compute unit (N=%d, %d CUs)", who,
                  SMR_MAXN, SMR_ROWS, N, sm_device_cus());
     // which form: measured per call, 10 iterations (tools/sm_resident_probe.py, tools/sm_bench.py, profiles/r04_z_sm_resident.txt):
-    // one pair of N = 1000 121 us resident / 89 streaming, 2048: 153 / 131, 3000: 187 / 180, 5000: 264 / 355; 8 pairs of N = 5000
-    // 1816 / 1997 (consecutive pairs' launches overlap).  The resident form's iteration is a grid barrier and a y round trip
+    // one pair of N = 1000 120 us resident / 87 streaming, 2048: 149 / 127, 3000: 182 / 173, 5000: 252 / 342; 8 pairs of N = 5000
+    // 1776 / 1898 (consecutive pairs' launches overlap).  The resident form's iteration is a grid barrier and a y round trip
     // (8-13 us whatever N), the streaming form's a pass over 4 N^2 bytes (5.5-25 us); they cross a little above N = 3000.
     if (form == 2 || (form == 0 && fits && N >= 3584)) {
         // the matrix never leaves the register file: one persistent launch per pair (pairs one after the other on the stream; the
