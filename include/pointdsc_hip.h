@@ -510,8 +510,11 @@ int pdsc_sm_baseline(const float* corr_pos, const float* src_keypts, const float
  *   register-resident (form 2): ONE persistent launch per pair computes the matrix straight into the chip's vector registers
  *                       (100 MB at N = 5000 of the 128 MiB the 256 compute units hold) and runs every power iteration from there;
  *                       per iteration only y crosses the chip, behind a grid barrier.  N <= 5120, 20 rows per compute unit.
- * pdsc_sm_baseline (= form 0) picks the resident form for 3584 <= N <= 5120 (one pair of N = 5000: 252 us against 342; 8 pairs
- * 1.78 ms against 1.90; the forms cross a little above N = 3000), the streaming form otherwise. */
+ * pdsc_sm_baseline (= form 0) ALWAYS runs the streaming form (r05).  The resident form (one pair of N = 5000: 252 us against 342)
+ * needs the whole chip to itself for its grid barrier, which only the caller can promise: it is opt-in (form 2), launched
+ * cooperatively (the launch fails, PDSC_ERR_LAUNCH, when the runtime cannot make the grid co-resident), refused under stream
+ * capture, ordered against this process's other resident launches on the same device, and every in-kernel wait is bounded --
+ * a second PROCESS running it on the same GPU at the same time ends in NaN outputs after 0.5 s, never in a hang. */
 int pdsc_sm_baseline_form(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
                           int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
                           void* workspace, size_t workspace_bytes, int bs, int N, int form, void* stream);

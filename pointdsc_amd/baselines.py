@@ -18,8 +18,8 @@ def SM(corr: torch.Tensor, src_keypts: torch.Tensor, tgt_keypts: torch.Tensor, i
     """corr [N,6] (or [bs,N,6]) centred correspondence coordinates, src/tgt_keypts [bs,N,3] ->
     (pred_trans [bs,4,4], pred_labels [bs,N]) like the reference's SM(corr, src_keypts, tgt_keypts, args, top_ratio)
     with ``args.inlier_threshold`` passed explicitly; bs > 1 = independent pairs.  ``form``: "streaming" (matrix in HBM, any N),
-    "resident" (the matrix stays in the chip's vector registers: N <= 5120) or "auto" (resident for 3584 <= N <= 5120, where it
-    is faster); same bits either way."""
+    "resident" (opt-in: the matrix stays in the chip's vector registers, N <= 5120; needs the GPU to itself -- cooperative launch,
+    refused under graph capture) or "auto" (= "streaming", always); same bits either way."""
     forms = {"auto": 0, "streaming": 1, "resident": 2}
     if form not in forms:
         raise ValueError(f"form must be one of {sorted(forms)}, got {form!r}")

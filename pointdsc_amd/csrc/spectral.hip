@@ -201,14 +201,31 @@ struct SmResidentArgs {
 // and a workgroup arrives only after its own stores have been acknowledged (s_waitcnt vmcnt(0) in every wave, then the
 // workgroup barrier).  All workgroups are resident (one per CU, checked by the launcher), so the waits cannot starve.
 constexpr int SMR_REL = 256, SMR_REL_STRIDE = 16;     // flag words: [0, 256) arrivals, 256 + 16 x: release word of XCD x
-__device__ __forceinline__ void smr_grid_barrier(unsigned int* flags, int nwg, unsigned int round /* 1, 2, ... */) {
+constexpr int SMR_ABORT = SMR_REL + SMR_REL_STRIDE * 8;      // one more word: set by whoever gives up waiting
+// Every wait is BOUNDED (r05): the launcher asks the runtime for a cooperative launch (all workgroups co-resident or the launch
+// fails), but a wait that could spin forever turns any broken assumption -- a CU mask, a pre-empted queue -- into a dead GPU.  A
+// waiter that sees no progress for SMR_SPIN_BUDGET ticks of the 100 MHz constant clock raises the abort word; every waiter also polls
+// it, so the whole grid leaves within one more poll and the kernel poisons its outputs (NaN) instead of hanging.
+constexpr long long SMR_SPIN_BUDGET = 50ll * 1000 * 1000;     // 0.5 s at 100 MHz: ~40 000 x a healthy barrier
+// returns false when the barrier was abandoned (workgroup-uniform)
+__device__ __forceinline__ bool smr_grid_barrier(unsigned int* flags, int nwg, unsigned int round /* 1, 2, ... */) {
+    __shared__ int s_abort;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) s_abort = 0;
     __syncthreads();
+    const long long t0 = (long long)wall_clock64();
     if (blockIdx.x == 0) {
         for (;;) {
             bool ok = true;
             if (threadIdx.x > 0 && (int)threadIdx.x < nwg) ok = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= round;
             if (__syncthreads_and(ok)) break;
+            if (threadIdx.x == 0 && ((long long)wall_clock64() - t0 > SMR_SPIN_BUDGET ||
+                                     __hip_atomic_load(flags + SMR_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(flags + SMR_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_abort = 1;
+            }
+            __syncthreads();
+            if (s_abort) return false;
             __builtin_amdgcn_s_sleep(4);
         }
         if (threadIdx.x < 8) __hip_atomic_store(flags + SMR_REL + SMR_REL_STRIDE * threadIdx.x, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -216,10 +233,21 @@ __device__ __forceinline__ void smr_grid_barrier(unsigned int* flags, int nwg, u
         if (threadIdx.x == 0) {
             __hip_atomic_store(flags + blockIdx.x, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int* rel = flags + SMR_REL + SMR_REL_STRIDE * (blockIdx.x & 7);
-            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) __builtin_amdgcn_s_sleep(8);
+            unsigned int polls = 0;
+            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) {
+                if ((++polls & 63u) == 0u && ((long long)wall_clock64() - t0 > SMR_SPIN_BUDGET ||
+                                              __hip_atomic_load(flags + SMR_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(flags + SMR_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
         }
         __syncthreads();
+        if (s_abort) return false;
     }
+    return true;
 }
 
 __global__ __launch_bounds__(256, 1) void sm_resident_kernel(SmResidentArgs a) {
@@ -302,7 +330,12 @@ __global__ __launch_bounds__(256, 1) void sm_resident_kernel(SmResidentArgs a) {
                     ycur[row0 + r] = yi;
             }
         });
-        smr_grid_barrier(a.bar, a.nwg, (unsigned)(it + 1));
+        if (!smr_grid_barrier(a.bar, a.nwg, (unsigned)(it + 1))) {
+            // abandoned (see smr_grid_barrier): no hang, and nothing that could pass for a result -- the finish kernel's scale and
+            // every output derived from it become NaN
+            if (t == 0) a.partial_out[0] = __builtin_nanf("");
+            return;
+        }
         // every workgroup: y into LDS (one coalesced pass), |y|^2 in the streaming kernel's grouping (blocks of 16 rows: per wave a
         // chain over its 4 rows, then (w0 + w1) + (w2 + w3)), the blocks summed in order -> the same scale bits
         {
@@ -497,44 +530,48 @@ extern "C" size_t pdsc_sm_workspace_bytes(int bs, int N) {
 }
 
 // Two register-resident launches must never share the chip: each needs (nearly) every compute unit for its grid barrier, and two
-// half-dispatched grids would wait for each other forever.  Launches of one stream are ordered anyway; launches of different
-// streams of this process are chained through an event (the next one waits for the previous one's end, whatever its stream).
-// Not covered: another PROCESS running the same kernel on the same GPU at the same time.
+// half-dispatched grids would wait for each other.  Three guards (r05):
+//   1. the launch is COOPERATIVE (hipLaunchCooperativeKernel): the runtime refuses a grid it cannot make co-resident and orders
+//      cooperative launches of one device among themselves -- the launch fails instead of hanging;
+//   2. launches of different streams of this process are additionally chained through one event PER DEVICE (the next launch waits
+//      for the previous one's end, whatever its stream) -- state keyed by the device the stream belongs to, not by the first device
+//      this process happened to use;
+//   3. every wait inside the kernel is bounded (smr_grid_barrier): what the two guards above cannot see -- another PROCESS with
+//      the same kernel on the same GPU, a CU-masked queue -- ends in NaN outputs after 0.5 s, not in a dead GPU.
+// The form is opt-in (`form = 2`); `form = 0` never picks it.  It is refused under stream capture: a replayed graph bypasses guard 2.
+constexpr int SMR_MAX_DEVICES = 64;
+struct SmrDeviceState {
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+    int cus = -1;
+};
 static std::mutex g_smr_mutex;
-static hipEvent_t g_smr_done = nullptr;
-static bool g_smr_recorded = false;
+static SmrDeviceState g_smr_dev[SMR_MAX_DEVICES];
 
-static int smr_chain_begin(hipStream_t st) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return PDSC_OK;   // (a captured graph orders its own nodes)
-    if (!g_smr_done && hipEventCreateWithFlags(&g_smr_done, hipEventDisableTiming) != hipSuccess) {
-        set_error("pdsc_sm_baseline: hipEventCreate failed");
-        return PDSC_ERR_LAUNCH;
+static SmrDeviceState* smr_device_state() {      // (caller holds g_smr_mutex) state of the CURRENT device, nullptr when it cannot be identified
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SMR_MAX_DEVICES) return nullptr;
+    SmrDeviceState* s = &g_smr_dev[dev];
+    if (s->cus < 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        s->cus = v;
     }
-    if (g_smr_recorded && hipStreamWaitEvent(st, g_smr_done, 0) != hipSuccess) {
-        set_error("pdsc_sm_baseline: hipStreamWaitEvent failed");
-        return PDSC_ERR_LAUNCH;
-    }
-    return PDSC_OK;
+    return s;
 }
 
-static void smr_chain_end(hipStream_t st) {
+static bool stream_is_capturing(hipStream_t st) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
-    if (g_smr_done && hipEventRecord(g_smr_done, st) == hipSuccess) g_smr_recorded = true;
+    return hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
 }
 
 static int sm_device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        cus = v;
-    }
-    return cus;
+    std::lock_guard<std::mutex> lock(g_smr_mutex);
+    SmrDeviceState* s = smr_device_state();
+    return s ? s->cus : 0;
 }
 
-// form: 0 = pick, 1 = HBM-streaming form, 2 = register-resident matrix (N <= 5120 and 20 rows per CU, else an error)
+// form: 0 = the library's choice (= 1, always), 1 = HBM-streaming form, 2 = register-resident matrix, opt-in (N <= 5120 and 20 rows per CU, else an error)
 static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, const float* tgt_keypts, float inlier_threshold,
                             int num_top, int num_iterations, float* pred_trans, float* pred_labels, float* leading_eig,
                             void* workspace, size_t workspace_bytes, int bs, int N, void* stream, int form, const char* who) {
@@ -564,16 +601,28 @@ static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, cons
     const bool fits = N <= SMR_MAXN && nwg <= sm_device_cus();
     PDSC_REQUIRE(form != 2 || fits, "%s: the register-resident form needs N <= %d and %d rows per compute unit (N=%d, %d CUs)", who,
                  SMR_MAXN, SMR_ROWS, N, sm_device_cus());
-    // which form: measured per call, 10 iterations (tools/sm_resident_probe.py, tools/sm_bench.py, profiles/r04_z_sm_resident.txt):
+    // form 0 = the streaming form, always (r05): the register-resident form is faster above N ~ 3500 but needs the whole chip to itself
+    // (see the guards above), which a library cannot promise on behalf of its caller -- it is opt-in.
+    // measured per call, 10 iterations (tools/sm_resident_probe.py, tools/sm_bench.py, profiles/r04_z_sm_resident.txt):
     // one pair of N = 1000 120 us resident / 87 streaming, 2048: 149 / 127, 3000: 182 / 173, 5000: 252 / 342; 8 pairs of N = 5000
     // 1776 / 1898 (consecutive pairs' launches overlap).  The resident form's iteration is a grid barrier and a y round trip
     // (8-13 us whatever N), the streaming form's a pass over 4 N^2 bytes (5.5-25 us); they cross a little above N = 3000.
-    if (form == 2 || (form == 0 && fits && N >= 3584)) {
+    if (form == 2) {
         // the matrix never leaves the register file: one persistent launch per pair (pairs one after the other on the stream; the
         // reference itself runs one pair per call).  pb (unused by this form) holds each pair's grid-barrier counters.
+        PDSC_REQUIRE(!stream_is_capturing(st), "%s: the register-resident form cannot be captured into a graph (its launches are ordered "
+                     "through a per-device event a replay would bypass); use form 1", who);
         std::lock_guard<std::mutex> lock(g_smr_mutex);
-        rc = smr_chain_begin(st);
-        if (rc != PDSC_OK) return rc;
+        SmrDeviceState* ds = smr_device_state();
+        PDSC_REQUIRE(ds, "%s: current device not identified", who);
+        if (!ds->done && hipEventCreateWithFlags(&ds->done, hipEventDisableTiming) != hipSuccess) {
+            set_error("%s: hipEventCreate failed", who);
+            return PDSC_ERR_LAUNCH;
+        }
+        if (ds->recorded && hipStreamWaitEvent(st, ds->done, 0) != hipSuccess) {
+            set_error("%s: hipStreamWaitEvent failed", who);
+            return PDSC_ERR_LAUNCH;
+        }
         rc = launch_fill_u32((unsigned int*)pb, 0u, (size_t)bs * SMV_MAX_BLOCKS + (size_t)bs * 2 * SMR_REPLICAS * SMR_MAXN, st);      // barrier flags + the y copies (zero past N)
         if (rc != PDSC_OK) return rc;
         for (int b = 0; b < bs; ++b) {
@@ -583,11 +632,22 @@ static int sm_baseline_impl(const float* corr_pos, const float* src_keypts, cons
             a.yrep = pb + (size_t)bs * SMV_MAX_BLOCKS + (size_t)b * 2 * SMR_REPLICAS * SMR_MAXN;
             a.partial_out = pa + (size_t)b * SMV_MAX_BLOCKS;
             a.bar = (unsigned int*)pb + (size_t)b * SMV_MAX_BLOCKS;
-            hipLaunchKernelGGL(sm_resident_kernel, dim3(nwg), dim3(256), 0, st, a);
+            void* kargs[] = {(void*)&a};
+            const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&sm_resident_kernel), dim3(nwg), dim3(256), kargs, 0, st);
+            if (le != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("%s(resident): cooperative launch of %d workgroups refused: %s", who, nwg, hipGetErrorString(le));
+                return PDSC_ERR_LAUNCH;
+            }
+            rc = check_launch("pdsc_sm_baseline(resident)");
+            if (rc != PDSC_OK) return rc;
         }
-        smr_chain_end(st);
-        rc = check_launch("pdsc_sm_baseline(resident)");
-        if (rc != PDSC_OK) return rc;
+        if (hipEventRecord(ds->done, st) == hipSuccess) ds->recorded = true;
+        else {
+            (void)hipGetLastError();
+            set_error("%s(resident): hipEventRecord failed", who);
+            return PDSC_ERR_LAUNCH;
+        }
         vin = ((num_iterations - 1) & 1) ? vb : va;      // the last y (unnormalised)
         vout = ((num_iterations - 1) & 1) ? va : vb;
         pin = pa;

@@ -1761,6 +1761,30 @@ def test_sm_baseline_register_resident_launches_of_two_streams_do_not_share_the_
         assert all(torch.equal(x, y) for x, y in zip(ra, want_a)) and all(torch.equal(x, y) for x, y in zip(rb, want_b))
 
 
+def test_sm_baseline_register_resident_form_is_opt_in_and_refused_under_capture():
+    """r05 (spectral.hip): the library's own choice (`form` unset) is the streaming form at every N -- the resident form
+    needs the chip to itself, which only the caller can promise -- and a resident launch inside a stream capture is an error (a
+    replayed graph would bypass the per-device ordering of resident launches), raised before anything is enqueued."""
+    from pointdsc_amd import baselines
+    batch = synthetic.make_batch(1, 5000, seed=77, inlier_ratio=0.3)
+    args = tuple(g(batch[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts"))
+    want = baselines.SM(*args, 0.10, return_eig=True, form="streaming")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(graph, stream=st):
+            with pytest.raises(RuntimeError, match="cannot be captured"):
+                baselines.SM(*args, 0.10, return_eig=True, form="resident")
+            got = baselines.SM(*args, 0.10, return_eig=True)          # the library's choice captures fine
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(got, want))
+    # and outside a capture the opt-in form still returns the streaming form's bits
+    res = baselines.SM(*args, 0.10, return_eig=True, form="resident")
+    assert all(torch.equal(x, y) for x, y in zip(res, want))
+
+
 def test_cal_confidence_matches_reference_golden():
     """pdsc_cal_confidence vs the reference's own PointDSC.cal_confidence (models/PointDSC.py:366-401) on seeded pairs:
     M rebuilt bit-exactly by pdsc_spatial_compat, leading eigenvector = the reference's; three methods; batch of 2."""
