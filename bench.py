@@ -199,6 +199,12 @@ def parse():
                     help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank; gloo = rehearsal of the N>1 path with CPU-tensor collectives")
+    ap.add_argument("--att-leaves", default=None,
+                    help="summation tree of the attention's key dimension (enum pdsc_att_leaves): canonical (module default: a pair's bits do "
+                         "not depend on its batch) | per_launch | legacy | an int >= 2")
+    ap.add_argument("--latency", action="store_true",
+                    help="the number an UNCHANGED caller sees (evaluation/test_3DMatch.py:53-64): one forward at a time on the current stream, "
+                         "its pose and labels copied to the host before the next call (forces --in-flight 1, no graphs)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of this run's outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="extra measured leg after the timed region (0 = off)")
@@ -228,6 +234,17 @@ def parse():
                          "--config kitti_n5000_b16 --global-batch 2 --first-pair 60 times and checks the census pair the parity "
                          "section of DESIGN.md discusses")
     return ap.parse_args()
+
+
+def attention_plan(lib, B, N, leaves):
+    """(key split = workgroups per query block, leaves per pair) of the attention launches of this run."""
+    mode = {"legacy": -1, "per_launch": 0, "canonical": 1}.get(leaves, leaves)
+    if mode == -1:
+        ns = int(lib.pdsc_attention_split_default_split(B, N))
+        return {"key_split": ns, "leaves": ns, "merge": "fused layer kernel (or combine launch above 8 splits)"}
+    ns, nl = C.c_int(), C.c_int()
+    lib.pdsc_attention_merged_plan(B, N, int(mode), C.byref(ns), C.byref(nl))
+    return {"key_split": ns.value, "leaves": nl.value, "merge": "in the attention launch (ticket per 32-query tile)"}
 
 
 def fp32_att(args):
@@ -275,6 +292,10 @@ def main():
     model.load_state_dict(sd)
     model = model.eval().to(dev)
     model.attention_precision = args.attention_precision
+    if args.att_leaves is not None:
+        model.att_leaves = int(args.att_leaves) if args.att_leaves.lstrip("-").isdigit() else args.att_leaves
+    if args.latency:
+        args.in_flight, args.graphs = 1, "off"
     # each rank owns its shard of the global batch: pairs [rank*B, (rank+1)*B) of the workload's pair list
     batch = workloads.batch(args.config, args.first_pair + rank * B, B)
     data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
@@ -304,6 +325,10 @@ def main():
     def step():
         res = runners[depth["d"]](data, post=gather)
         last["res"] = res
+        if args.latency:
+            # what the reference's evaluation loop does with every result before it asks for the next one
+            # (evaluation/test_3DMatch.py:54,64: pred_labels.detach().cpu().numpy(), the pose for the metrics)
+            last["host"] = (res["final_trans"].cpu(), res["final_labels"].cpu())
         return res["post"]
 
     def fence():
@@ -471,7 +496,10 @@ def main():
     # and is bound by HBM: per point it reads the key-split partials (ns x (512 + 8) B) and the residual row (512 B) and
     # writes featB (512 B), the Q rows (512 B) and its share of the K/V tile image (32 KiB / 32)
     lay_h3 = (not fp32_att(args)) and model.layer_gemm == "h3"      # (since r03 the H3 arithmetic has its own kernels at every size)
+    # (merged attention -- every att_leaves mode but "legacy", H3 layer kernel: ONE merged message per point)
     lay_ns = int(lib.pdsc_attention_split_default_split(B, N))
+    if lay_h3 and model.att_leaves != "legacy" and not (model.att_leaves == "per_launch" and lay_ns == 1):
+        lay_ns = 1
     lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 32768 / 32.0) * N * B
     lay_gbs = lay_bytes / lay_avg / 1e9 if lay_n else None
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
@@ -512,10 +540,14 @@ def main():
                                       ("; spatial-consistency matrix stored as unorm16" if c16 else "") + ")"),
         "data": "synthetic",
         "config": {"workload": "%s: N=%d corr, %d pairs per step sharded over %d GPU(s) = %d per GPU, 12-layer PointDSC, "
-                               "seeded random weights" % (w["label"], N, total_pairs, world, B),
+                               "%s weights" % (w["label"], N, total_pairs, world, B,
+                                               "trained-like (tests/golden/%s.npz)" % w["weights"] if "weights" in w else "seeded random"),
                    "name": args.config, "num_corr": N, "pairs_per_gpu": B, "global_batch": total_pairs,
                    "sigma_d": kw["sigma_d"], "inlier_threshold": kw["inlier_threshold"],
                    "compat_format": "f32" if fp32 else model.compat_format, "layer_gemm": model.layer_gemm,
+                   "att_leaves": None if fp32 else model.att_leaves,
+                   "attention_plan": None if fp32 else attention_plan(lib, B, N, model.att_leaves),
+                   "latency_mode": bool(args.latency),
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s); %d forward(s) in flight per GPU "
                                   "(consecutive steps alternate between HIP streams%s)"
                                   % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU", depth["d"],

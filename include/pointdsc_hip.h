@@ -59,7 +59,22 @@ typedef struct pdsc_config {
     int attention_precision; /* enum pdsc_attention_precision: how the two N x N x C contractions are evaluated */
     int compat_format;       /* enum pdsc_compat_format: how the forward stores the N x N spatial-consistency matrix  */
     int layer_gemm;          /* enum pdsc_layer_gemm: arithmetic of the fc_message / PointCN GEMMs in the fused layer kernel */
+    int att_leaves;          /* enum pdsc_att_leaves: summation tree of the attention's key dimension (split-precision modes) */
 } pdsc_config;
+
+/* How the N keys of a query are summed (models/PointDSC.py:41-42: one softmax-weighted sum per query) when the key range is
+ * cut so that one pair can fill the chip.  A LEAF is a run of 32-key tiles accumulated from a fresh online-softmax state;
+ * leaves are merged in leaf order (weights exp2(m_leaf - max m), one reciprocal) by the last wavefront to finish a query
+ * tile, inside the attention launch (a ticket per tile, no waiting), and the fused layer kernel reads ONE merged message.
+ *   LEGACY     (-1): r01-r04 hand-off -- one partial per key split left in the workspace, merged by the layer kernel while it
+ *                    loads (or by a combine launch above 8 splits).  Same bits as PER_LAUNCH; A/B record.
+ *   PER_LAUNCH ( 0): one leaf per key split, the split planned per launch from (batch, N): the bits of a pair depend on how
+ *                    many pairs share its launch (both within the contract; the r01-r04 results).
+ *   CANONICAL  ( 1): pdsc_attention_leaf_count(N) leaves, a function of N alone; the launch plan only decides WHICH workgroup
+ *                    computes a leaf (a divisor of the leaf count), never the arithmetic -- a pair's result is bit-identical at
+ *                    every batch size, on one GPU or sharded over eight.                      [default of the Python module]
+ *   n >= 2         : n leaves (tuning). */
+enum pdsc_att_leaves { PDSC_LEAVES_LEGACY = -1, PDSC_LEAVES_PER_LAUNCH = 0, PDSC_LEAVES_CANONICAL = 1 };
 
 /* Arithmetic of the point-wise GEMMs whose results land on the residual stream (fc1..fc3 of fc_message, PointCN;
  * models/PointDSC.py:12-23,56-61) inside the fused layer kernel (split-precision attention modes).  H3 runs on
@@ -297,6 +312,11 @@ size_t pdsc_split_kv_bytes(int bs, int N);
 int    pdsc_pack_qkv_split(const float* qkv, void* q_split, void* kv_tiles, int bs, int N, void* stream);
 size_t pdsc_attention_split_scratch_bytes(int bs, int N, int nsplit);
 int    pdsc_attention_split_default_split(int bs, int N);
+/* merged form (enum pdsc_att_leaves): canonical leaf count of N; the plan (key split = workgroups per query block, leaves) the
+ * forward uses for (bs, N, leaves_mode >= PDSC_LEAVES_PER_LAUNCH); bytes of its scratch (leaf partials + merged message + tickets) */
+int    pdsc_attention_leaf_count(int N);
+int    pdsc_attention_merged_plan(int bs, int N, int leaves_mode, int* nsplit, int* nleaf);
+size_t pdsc_attention_merged_scratch_bytes(int bs, int N, int leaves_mode);
 int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
                                float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                void* stream);

@@ -25,6 +25,7 @@ class PdscConfig(C.Structure):
         ("num_iterations", C.c_int), ("k", C.c_int), ("refine_iters", C.c_int),
         ("inlier_threshold", C.c_float), ("nms_radius", C.c_float), ("refine_threshold", C.c_float),
         ("attention_precision", C.c_int), ("compat_format", C.c_int), ("layer_gemm", C.c_int),
+        ("att_leaves", C.c_int),
     ]
 
 
@@ -78,6 +79,9 @@ SIGNATURES = {
     "pdsc_pack_qkv_split": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "pdsc_attention_split_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_split_default_split": (_i, [_i, _i]),
+    "pdsc_attention_leaf_count": (_i, [_i]),
+    "pdsc_attention_merged_plan": (_i, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pdsc_attention_merged_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_trace": (_i, [_vp]),
     "pdsc_layer_trace": (_i, [_vp]),
     "pdsc_sc_attention_split": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),

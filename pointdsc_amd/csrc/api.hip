@@ -133,6 +133,7 @@ static bool config_ok(const pdsc_config* c) {
 #endif
     if (c->compat_format != PDSC_COMPAT_U16 && c->compat_format != PDSC_COMPAT_F32) { set_error("compat_format=%d", c->compat_format); return false; }
     if (c->layer_gemm != PDSC_LAYER_GEMM_F32 && c->layer_gemm != PDSC_LAYER_GEMM_H3) { set_error("layer_gemm=%d", c->layer_gemm); return false; }
+    if (c->att_leaves < PDSC_LEAVES_LEGACY || c->att_leaves > 64) { set_error("att_leaves=%d (enum pdsc_att_leaves, or 2..64 leaves)", c->att_leaves); return false; }
     return true;
 }
 
@@ -204,6 +205,10 @@ struct WsLayout {
         for (int i = 0; i < n; ++i) if (strcmp(e[i].name, name) == 0) return (long long)e[i].offset;
         return -1;
     }
+    size_t bytes_of(const char* name) const {
+        for (int i = 0; i < n; ++i) if (strcmp(e[i].name, name) == 0) return e[i].bytes;
+        return 0;
+    }
 };
 
 static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
@@ -224,7 +229,8 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("t64b", M * (C / 2) * f);
     {
         const size_t a32 = pdsc_attention_scratch_bytes(bs, N, 0), a16 = pdsc_attention_split_scratch_bytes(bs, N, 0);
-        L.add("att_scratch", c->attention_precision == PDSC_ATT_FP32 ? a32 : a16);
+        const size_t amg = c->att_leaves >= PDSC_LEAVES_PER_LAUNCH ? pdsc_attention_merged_scratch_bytes(bs, N, c->att_leaves) : 0;
+        L.add("att_scratch", c->attention_precision == PDSC_ATT_FP32 ? a32 : (a16 > amg ? a16 : amg));
     }
     L.add("q_split", c->attention_precision != PDSC_ATT_FP32 ? pdsc_split_q_bytes(bs, N) : 0);
     L.add("kv_tiles", c->attention_precision != PDSC_ATT_FP32 ? pdsc_split_kv_bytes(bs, N) : 0);
@@ -362,7 +368,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_REQUIRE(n_min > (cfg->k < N - 1 ? cfg->k : N - 1), "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has no "
                      "more than k=%d: the reference clamps k per pair (k = min(k, num_corr - 1)); run such a pair in its own call",
                      n_min, cfg->k < N - 1 ? cfg->k : N - 1);
-        PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
+        PDSC_REQUIRE(cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH || (n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
                      "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
                      "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
     }
@@ -396,7 +402,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     const bool x3_gemm = cfg->attention_precision == PDSC_ATT_BF16X3_ALL;
     PDSC_REQUIRE(!split || wsplit, "pdsc_forward_testing: the split-precision modes need the split-weight buffer (pdsc_wsplit_build)");
     auto WS = [&](int section, int layer) { return (const void*)((const unsigned short*)wsplit + pdsc_wsplit_offset(cfg, section, layer)); };
-    const size_t att_bytes = split ? pdsc_attention_split_scratch_bytes(bs, N, 0) : pdsc_attention_scratch_bytes(bs, N, 0);
+    const size_t att_bytes = L.bytes_of("att_scratch");
     void* q_split = split ? ws + L.find("q_split") : nullptr;
     void* kv_tiles = split ? ws + L.find("kv_tiles") : nullptr;
 
@@ -444,8 +450,21 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const int ws_head = gemm == PDSC_LAYER_GEMM_H3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD;
         // H3 + fused merge: the hand-offs attention -> layer kernel -> next layer kernel in point-fragment order (split_layout.h);
         // A/B knob PDSC_LAYER_PF = 0: plain rows
-        const bool pf = frag && gemm == PDSC_LAYER_GEMM_H3 && fuse_merge && env_int("PDSC_LAYER_PF", 1) != 0 &&
-                        env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
+        // merged form (r05, enum pdsc_att_leaves): the attention launch merges its own leaves (tickets) and the layer kernel reads ONE
+        // message in point-fragment order; H3 layer kernel only (the other layer kernels keep the legacy hand-off)
+        const bool pf_ok = frag && gemm == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_PF", 1) != 0 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
+        int mg_ns = 0, mg_leaves = 0, mg_nw = 0;
+        if (cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH) merged_plan(bs, N, cfg->att_leaves, &mg_nw, &mg_ns, &mg_leaves);
+        // (per-launch leaves with a single key split: the legacy un-split launch already writes the normalised rows -- its bits, kept)
+        const bool merged = pf_ok && cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH && (mg_leaves > 1 || cfg->att_leaves != PDSC_LEAVES_PER_LAUNCH) &&
+                            (!nvalid || (n_min + 31) / 32 >= mg_leaves);
+        if (nvalid && !merged)
+            PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
+                         "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
+                         "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
+        const bool pf = merged || (pf_ok && fuse_merge);
+        if (merged) PDSC_TRY(attention_merged_reset(att_scratch, bs, N, cfg->att_leaves, hst));
+        const float *mg_msg = nullptr, *mg_ml = nullptr;
         if (x3_gemm)
             PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
@@ -462,14 +481,17 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                             W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), WS(PDSC_W_QKV_W, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            if (pf)
+            if (merged)
+                PDSC_TRY(launch_attention_merged(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, att_scratch,
+                                                 att_bytes, bs, N, cfg->att_leaves, nvalid, n_min, &mg_msg, &mg_ml, hst));
+            else if (pf)
                 PDSC_TRY(launch_attention_split_ex(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, nullptr,
                                                    att_scratch, att_bytes, bs, N, ns, PDSC_PARTIALS_PF, nvalid, hst));
             else
                 PDSC_TRY(attention_split(fuse_merge ? nullptr : msg, ns));
             const bool last = i + 1 == cfg->num_layers;
             if (pf)
-                PDSC_TRY(pdsc_layer_fused_frag_io(nullptr, part_o, part_ml, ns, Npad, cur, nullptr, last ? featA : nullptr,
+                PDSC_TRY(pdsc_layer_fused_frag_io(nullptr, merged ? mg_msg : part_o, merged ? mg_ml : part_ml, merged ? 1 : ns, Npad, cur, nullptr, last ? featA : nullptr,
                                                   last ? nullptr : nxt, last ? nullptr : q_split, last ? nullptr : kv_tiles,
                                                   WS(ws_tail, i), last ? nullptr : WS(ws_head, i + 1), gemm,
                                                   PDSC_IO_PARTIALS_PF | PDSC_IO_RES_PF | (last ? 0 : PDSC_IO_FEATB_PF), bs, N, stream));

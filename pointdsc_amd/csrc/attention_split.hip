@@ -81,10 +81,19 @@ constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
 // previous item's last tiles.  Point-fragment partials only: that epilogue needs no LDS, the stages stay live across items.
 // PEEL: the split's last tile runs as peeled tail code (see tile_iteration); false = the r01-r03 straight-line loop (A/B record,
 // experiments builds: PDSC_ATT_PEEL=0)
-template <int NW, int CM = 0, bool TRACE = false, bool PS = false, bool PEEL = true>
+// MG (r05, merged form): the key range of a pair is cut into a.nleaf LEAVES (a function of the pair's own tile count and of
+// a.nleaf only -- with the canonical leaf count of attention_leaf_count(N) a function of N alone); every leaf is accumulated from a
+// fresh online-softmax state, whoever computes it, and leaves a partial (O, m, l) in point-fragment order; a workgroup owns the
+// consecutive leaves [sp C / nsplit, (sp + 1) C / nsplit) and streams through them without a break in its K / V / compat
+// pipeline.  The LAST wave to finish among the nsplit waves that share a 32-query tile (a ticket per tile, no waiting anywhere)
+// merges all C partials in leaf order with the arithmetic of merge_partials_finish and writes the normalised message: the
+// layer kernel loads 512 B per point instead of nsplit x 528 B, no combine launch for large splits, and with canonical leaves the
+// bits of a pair do not depend on how many pairs share its launch.
+template <int NW, int CM = 0, bool TRACE = false, bool PS = false, bool PEEL = true, bool MG = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
     constexpr bool C16 = CM == 1, CREG = CM == 2;
     static_assert(!PS || (!CREG && !TRACE), "the persistent form exists for the LDS-staged compat formats, untraced");
+    static_assert(!MG || (!PS && !TRACE && !CREG && PEEL), "the merged form: one-item, untraced, LDS-staged compat, peeled last tile");
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = TRACE ? (long long)__builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -130,6 +139,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const int per = ntiles / a.nsplit, rem = ntiles % a.nsplit;
     int kt0 = sp * per + min(sp, rem);
     int kt1 = kt0 + per + (sp < rem ? 1 : 0);
+    // MG: leaf c = tiles [c lper + min(c, lrem), ...) (a.nleaf <= ntiles); this workgroup owns leaves [leaf, lf1)
+    const int lper = MG ? ntiles / a.nleaf : 0, lrem = MG ? ntiles % a.nleaf : 0;
+    int leaf = 0, leaf_end = 0;
+    if constexpr (MG) {
+        const int lf1 = (sp + 1) * a.nleaf / a.nsplit;
+        leaf = sp * a.nleaf / a.nsplit;
+        kt0 = leaf * lper + min(leaf, lrem);
+        kt1 = lf1 * lper + min(lf1, lrem);
+        leaf_end = (leaf + 1) * lper + min(leaf + 1, lrem);
+    }
 
     // buffer descriptor of this pair's K/V tile stream (< 4 GiB)
     constexpr unsigned CEL = C16 ? 2u : 4u;      // bytes per compat element
@@ -294,6 +313,35 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     };
 
+    // MG: the partial of a finished leaf -> part_o / part_ml [pair][leaf][Npad] in point-fragment order, written THROUGH the
+    // caches (sc0 sc1): the wave that merges this query tile may run on another XCD, behind another L2.  The stores of a leaf that
+    // ends inside the workgroup's range leave at the top of the next loop iteration (after its barrier, like the persistent form's):
+    // a whole tile of time before the next s_waitcnt vmcnt(0) meets them.
+    __amdgpu_buffer_rsrc_t po_rsrc = kv_rsrc, pm_rsrc = kv_rsrc;
+    if constexpr (MG) {
+        po_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part_o + (size_t)b * a.nleaf * a.Npad * PDSC_CHANNELS), 0,
+                                                    (int)((unsigned)a.nleaf * (unsigned)a.Npad * (unsigned)(PDSC_CHANNELS * 4)), 0x00020000);
+        pm_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part_ml + (size_t)b * a.nleaf * a.Npad * 2), 0,
+                                                    (int)((unsigned)a.nleaf * (unsigned)a.Npad * 8u), 0x00020000);
+    }
+    const unsigned q0w = (unsigned)(qb * (NW * 32) + wave * 32);          // first query of this wave inside the pair
+    constexpr int AUX_THROUGH = 1 | 16;                                     // sc0 sc1
+    auto leaf_store = [&](int lf, float m_st, float l_st) {
+        const unsigned base = ((unsigned)lf * (unsigned)a.Npad + q0w) * (unsigned)(PDSC_CHANNELS * 4) + lane16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]}),
+                                                       po_rsrc, base + 1024u * (4 * c + g), 0, AUX_THROUGH);
+        if (h == 0) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m_st), __float_as_uint(l_st)}, pm_rsrc,
+                                                  ((unsigned)lf * (unsigned)a.Npad + q0w + (unsigned)l31) * 8u, 0, AUX_THROUGH);
+        }
+    };
+    int leaf_prev = 0;                          // MG: the leaf whose partial is pending (m_prev, l_prev, pend)
+
     const int koff = l31 * 16 + 512 * h;            // K image (chunk-major): chunk 2j+h of key l31 -> + 1024 j   (immediates)
     const int voff = l31 * 16 + 2048 * h;           // V^T image: chunk 2j+h of channel 32c + l31 -> + 4096 j + 512 c
     const int crow_off = (wave * 32 + l31) * CROW;  // compat row of this lane's query in a compat stage
@@ -425,6 +473,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         if constexpr (PS) {
             if (pend) { store_pending(); pend = false; }      // (phase A does not touch the accumulators)
         }
+        if constexpr (MG) {
+            if (pend) {                                        // (workgroup-uniform) the leaf that ended with the previous tile
+                leaf_store(leaf_prev, m_prev, l_prev);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+                pend = false;
+            }
+        }
+        // MG: tile kt + 1 starts a new leaf -> its logits are formed against a fresh reference (raw products, then their row maximum:
+        // bit for bit what the first-tile code above does for a workgroup that STARTS at that leaf)
+        const bool leaf_last = MG && !LAST && kt + 1 == leaf_end;
+        const float m_sub = leaf_last ? 0.f : m_run;
         if (CREG) {
             if (kt != kt0) {                     // (the loads issued one iteration ago have landed: vmcnt(0) above)
 #pragma unroll
@@ -518,21 +580,21 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                         float cc[4];
                         c16_group(cw, g, cc);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                        for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_sub);
                         mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                     }
                 } else if (CREG) {
                     if (u & 1) {
                         const int g = u >> 1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(ccur[g][e], sacc[4 * g + e], -m_run);
+                        for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(ccur[g][e], sacc[4 * g + e], -m_sub);
                         mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                     }
                 } else if (u & 1) {              // compat chunk 2g+h = keys 8g+4h..+3 = accumulator registers 4g..4g+3
                     const int g = u >> 1;
                     const f32x4 cc = *reinterpret_cast<const f32x4*>(Cn + (((2 * g + h) ^ csw) << 4));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_run);
+                    for (int e = 0; e < 4; ++e) tl[4 * g + e] = fmaf(cc[e], sacc[4 * g + e], -m_sub);
                     mx_next = fmaxf(fmaxf(mx_next, fmaxf(tl[4 * g], tl[4 * g + 1])), fmaxf(tl[4 * g + 2], tl[4 * g + 3]));
                 }
                 vh = nvh; vl = nvl;
@@ -542,7 +604,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 
         PDSC_TRACE_STAMP(6)                      // 6: phase B
         // ---- does tile kt+1 move the reference exponent of any query?  (rare after the first tiles) -------------
-        if (has_next) {
+        if (leaf_last) {
+            // the finished leaf's state waits for the next iteration's barrier (leaf_store); the next leaf starts from nothing
+            m_prev = m_run;
+            l_prev = l_run + __shfl_xor(l_run, 32, 64);
+            leaf_prev = leaf;
+            pend = true;
+            if ((kt + 2) * SPL_BK > N) mask_tail(kt + 1, tl);
+            m_run = row_max(tl);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tl[r] -= m_run;
+            l_run = 0.f;
+            ++leaf;
+            leaf_end = (leaf + 1) * lper + min(leaf + 1, lrem);
+        } else if (has_next) {
             float mloc;
             if ((kt + 2) * SPL_BK > N) {         // tile kt+1 is the ragged last tile of the pair (wave-uniform, once per pair)
                 mask_tail(kt + 1, tl);
@@ -600,6 +675,102 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // LDS (row pitch 528 B) and stores whole rows: one instruction = 2 rows = 8 full lines.
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int q0 = qb * (NW * 32) + wave * 32;
+    if constexpr (MG) {
+        float* const mbase = a.merged_o + ((size_t)b * a.Npad + q0) * PDSC_CHANNELS + lane * 4;
+        auto store_message = [&](const f32x16 (&acc)[4], float rden) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(mbase + pf_offset_floats(4 * c + g)) =
+                        f32x4{acc[c][4 * g] * rden, acc[c][4 * g + 1] * rden, acc[c][4 * g + 2] * rden, acc[c][4 * g + 3] * rden};
+            if (h == 0) {
+                // the layer kernel's one-partial merge (layer_h3.hip, NS = 1): w = exp2(0 - 0) = 1, den = fma(1, 1, 0) = 1, x = fma(v, 1, 0) * 1
+                // -- the message passes through bit for bit
+                float* ml = a.merged_ml + ((size_t)b * a.Npad + q0 + l31) * 2;
+                ml[0] = 0.f;
+                ml[1] = 1.f;
+            }
+        };
+        if (a.nleaf == 1) {                      // one leaf = one workgroup per query block: nothing to merge (fma(o, 1, 0) * (1 / fma(l, 1, 0)))
+            store_message(o, 1.0f / l_tot);
+            return;
+        }
+        leaf_store(leaf, m_run, l_tot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partials are at the memory side before it takes its ticket
+        unsigned int* const tk = a.tickets + (size_t)b * (a.Npad >> 5) + (q0 >> 5);
+        unsigned int arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived + 1u != (unsigned)a.nsplit) return;        // somebody else finishes later and merges
+        if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+        // ---- the last of the nsplit waves of this query tile: merge ALL leaves in leaf order (merge_partials_finish's arithmetic:
+        //      w_c = exp2(m_c - max m), den = fma chain of l_c w_c, acc = fma chain of O_c w_c, message = acc * (1 / den)) from the
+        //      partials as they lie in memory (its own included), loads past the caches
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const int C = a.nleaf;
+        const unsigned mlo = (q0w + (unsigned)l31) * 8u, mls = (unsigned)a.Npad * 8u;
+        const unsigned pvo = q0w * (unsigned)(PDSC_CHANNELS * 4) + lane16, pvs = (unsigned)a.Npad * (unsigned)(PDSC_CHANNELS * 4);
+        float mmax = -INFINITY;
+        for (int c0 = 0; c0 < C; c0 += 4) {          // four loads per round trip (index clamped: a repeated leaf does not move the maximum)
+            u32x2 ml4[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) ml4[d] = __builtin_amdgcn_raw_buffer_load_b64(pm_rsrc, mlo + (unsigned)min(c0 + d, C - 1) * mls, 0, AUX_THROUGH);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) mmax = fmaxf(mmax, __uint_as_float(ml4[d][0]));
+        }
+        // Two passes of 64 channels each (a pass keeps MD leaves of 8 KiB per wave in flight: the merge is a chain of memory round
+        // trips, and with all 128 channels of a leaf in registers only one leaf at a time fits beside the accumulators).  Loads are
+        // unconditional (leaf index clamped: the last rounds re-read the last leaf), only the arithmetic is guarded -- the compiler
+        // can then count the loads in flight exactly instead of draining them at every branch.
+        constexpr int MD = 4;
+        float den = 0.f, rden = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            u32x4 buf[MD][8];
+            u32x2 mlb[MD];
+            auto issue = [&](int d, int c) {
+                const unsigned cc = (unsigned)min(c, C - 1);
+                mlb[d] = __builtin_amdgcn_raw_buffer_load_b64(pm_rsrc, mlo + cc * mls, 0, AUX_THROUGH);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    buf[d][i] = __builtin_amdgcn_raw_buffer_load_b128(po_rsrc, pvo + cc * pvs + 1024u * (8 * pass + i), 0, AUX_THROUGH);
+            };
+#pragma unroll
+            for (int d = 0; d < MD; ++d) issue(d, d);
+            for (int c0 = 0; c0 < C; c0 += MD) {
+#pragma unroll
+                for (int d = 0; d < MD; ++d) {
+                    const int c = c0 + d;
+                    const float w = __builtin_amdgcn_exp2f(__uint_as_float(mlb[d][0]) - mmax);
+                    const float lc = __uint_as_float(mlb[d][1]);
+                    if (c < C) {                          // (wave-uniform)
+                        if (pass == 0) den = fmaf(lc, w, den);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, buf[d][i]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(v[e], w, acc[i][e]);
+                        }
+                    }
+                    issue(d, c + MD);                     // the slot's next leaf (three other leaves are in flight meanwhile)
+                }
+            }
+            if (pass == 0) rden = 1.0f / den;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(mbase + pf_offset_floats(8 * pass + i)) = f32x4{acc[i][0] * rden, acc[i][1] * rden, acc[i][2] * rden, acc[i][3] * rden};
+        }
+        if (h == 0) {
+            float* ml = a.merged_ml + ((size_t)b * a.Npad + q0 + l31) * 2;
+            ml[0] = 0.f;
+            ml[1] = 1.f;
+        }
+        return;
+    }
     if (a.nsplit != 1 && a.part_frag) {
         // point-fragment order (split_layout.h): the accumulator registers of lane (query l31, half h) ARE the 16-byte
         // pieces the fused layer kernel's lane loads -- 1 KiB of consecutive memory per store instruction, no LDS
@@ -746,9 +917,134 @@ static void split_plan(int bs, int N, int* nw_out, int* nsplit_out) {
     *nsplit_out = force_ns > 0 ? (force_ns < tiles ? force_ns : tiles) : best;
 }
 
+// ---- merged form: leaves and plan -------------------------------------------------------------------------------------
+// Canonical leaf count: a function of N ALONE (never of the batch), so that a pair's summation tree -- every leaf from a fresh
+// online-softmax state, leaves merged in leaf order -- and hence its bits do not depend on how many pairs share the launch.
+// 12 = the finest key split the per-launch planner ever asked for at these sizes (one pair of N = 5000: 12, two: 6, four: 3,
+// sixteen: 4, thirty-two: 2 -- all divisors), leaves of >= 4 tiles.
+int attention_leaf_count(int N) {
+    const int t = spl_num_tiles(N);
+    return t >= 48 ? 12 : t >= 32 ? 8 : t >= 16 ? 4 : t >= 8 ? 2 : 1;
+}
+
+// leaves_mode (pdsc_config.att_leaves): PDSC_LEAVES_PER_LAUNCH = one leaf per key split (the per-launch plan's arithmetic, the
+// r01-r04 bits); PDSC_LEAVES_CANONICAL = attention_leaf_count(N) leaves, the key split a divisor of it; >= 2: that many leaves (tuning)
+void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out) {
+    int nw, ns;
+    split_plan(bs, N, &nw, &ns);
+    if (leaves_mode == PDSC_LEAVES_PER_LAUNCH) { *nw_out = nw; *nsplit_out = ns; *nleaf_out = ns; return; }
+    const int tiles = spl_num_tiles(N);
+    int C = leaves_mode == PDSC_LEAVES_CANONICAL ? attention_leaf_count(N) : leaves_mode;
+    if (C > tiles) C = tiles;
+    if (C < 1) C = 1;
+    // the per-launch cost model over the divisors of C; a leaf that ends inside a workgroup's range costs about a third of a tile
+    // (its partial leaves through the caches and is read back by the merging wave)
+    const int nq = ceil_div(N, nw * 32), slots = nw == 8 ? 256 : 512;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int d = 1; d <= C; ++d) {
+        if (C % d) continue;
+        const int wgs = nq * bs * d, rounds = ceil_div(wgs, slots);
+        double cost = (double)rounds * (ceil_div(tiles, d) + 4.0 + 0.35 * (C / d));
+        if (((d * bs) & 7) != 0) cost *= 1.03;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = d; }
+    }
+    *nw_out = nw; *nsplit_out = best; *nleaf_out = C;
+}
+
+static size_t merged_scratch_bytes(int bs, int N, int nleaf) {
+    const size_t Npad = (size_t)round_up(N, 256);
+    return (size_t)bs * nleaf * Npad * (PDSC_CHANNELS + 2) * sizeof(float) + (size_t)bs * Npad * (PDSC_CHANNELS + 2) * sizeof(float) +
+           (size_t)bs * (Npad / 32) * sizeof(unsigned int) + 256;
+}
+
 }  // namespace pdsc
 
 using namespace pdsc;
+
+extern "C" int pdsc_attention_leaf_count(int N) { return N > 0 ? attention_leaf_count(N) : -1; }
+
+extern "C" int pdsc_attention_merged_plan(int bs, int N, int leaves_mode, int* nsplit, int* nleaf) {
+    PDSC_REQUIRE(bs > 0 && N > 0 && leaves_mode >= PDSC_LEAVES_PER_LAUNCH && nsplit && nleaf, "pdsc_attention_merged_plan: bs=%d N=%d leaves_mode=%d", bs, N, leaves_mode);
+    int nw;
+    merged_plan(bs, N, leaves_mode, &nw, nsplit, nleaf);
+    return PDSC_OK;
+}
+
+extern "C" size_t pdsc_attention_merged_scratch_bytes(int bs, int N, int leaves_mode) {
+    if (bs <= 0 || N <= 0 || leaves_mode < PDSC_LEAVES_PER_LAUNCH) return 0;
+    int nw, ns, C;
+    merged_plan(bs, N, leaves_mode, &nw, &ns, &C);
+    return merged_scratch_bytes(bs, N, C);
+}
+
+// the tickets of the merged form must be zero before a forward's first attention launch (every merging wave leaves its ticket
+// zero again, so once per forward is enough -- and repairs whatever an aborted launch left behind)
+int pdsc::attention_merged_reset(void* scratch, int bs, int N, int leaves_mode, hipStream_t st) {
+    int nw, ns, C;
+    merged_plan(bs, N, leaves_mode, &nw, &ns, &C);
+    const size_t Npad = (size_t)round_up(N, 256);
+    float* part_o = (float*)scratch;
+    float* merged_ml = part_o + (size_t)bs * C * Npad * (PDSC_CHANNELS + 2) + (size_t)bs * Npad * PDSC_CHANNELS;
+    return launch_fill_u32((unsigned int*)(merged_ml + (size_t)bs * Npad * 2), 0u, (size_t)bs * (Npad / 32), st);
+}
+
+// One attention launch in the merged form.  message / message_ml: where the layer kernel finds the merged message (inside scratch).
+int pdsc::launch_attention_merged(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
+                                  void* scratch, size_t scratch_bytes, int bs, int N, int leaves_mode, const int* nvalid, int n_min,
+                                  const float** message, const float** message_ml, hipStream_t st) {
+    PDSC_REQUIRE(q_split && kv_tiles && compat && scratch && message && message_ml, "pdsc_sc_attention_merged: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_merged: bs=%d N=%d", bs, N);
+    PDSC_REQUIRE(compat_format == PDSC_COMPAT_F32 || compat_format == PDSC_COMPAT_U16, "pdsc_sc_attention_merged: compat_format=%d", compat_format);
+    const bool c16 = compat_format == PDSC_COMPAT_U16;
+    PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % (c16 ? 8 : 4) == 0,
+                 "pdsc_sc_attention_merged: ld=%lld must be a multiple of %d and >= N rounded up to 32", ld, c16 ? 8 : 4);
+    int nw, ns, C;
+    merged_plan(bs, N, leaves_mode, &nw, &ns, &C);
+    // ragged batches: every pair cuts ITS OWN tiles into C leaves -- the shortest pair needs at least C of them
+    PDSC_REQUIRE(!nvalid || (n_min + 31) / 32 >= C, "pdsc_sc_attention_merged: the shortest pair (%d correspondences) has fewer 32-key tiles "
+                 "than the %d leaves planned for bs=%d, N=%d", n_min, C, bs, N);
+    const size_t need = merged_scratch_bytes(bs, N, C);
+    if (scratch_bytes < need) {
+        set_error("pdsc_sc_attention_merged: scratch %zu < %zu bytes", scratch_bytes, need);
+        return PDSC_ERR_WORKSPACE;
+    }
+    const int tiles = spl_num_tiles(N);
+    AttSplitArgs a{};
+    a.qs = (const __bf16*)q_split; a.kv = (const unsigned char*)kv_tiles; a.compat = compat; a.ld = ld; a.msg = nullptr;
+    a.N = N; a.Npad = (int)round_up(N, 256); a.nsplit = ns; a.num_tiles = tiles; a.bs = bs;
+    a.nq = ceil_div(N, nw * 32);
+    a.nleaf = C;
+    a.part_o = (float*)scratch;
+    a.part_ml = a.part_o + (size_t)bs * C * a.Npad * PDSC_CHANNELS;
+    a.merged_o = a.part_ml + (size_t)bs * C * a.Npad * 2;
+    a.merged_ml = a.merged_o + (size_t)bs * a.Npad * PDSC_CHANNELS;
+    a.tickets = (unsigned int*)(a.merged_ml + (size_t)bs * a.Npad * 2);
+    a.nvalid = nvalid;
+    a.part_frag = 1;
+    a.compat_nt = c16 ? 0 : 1;
+    *message = a.merged_o;
+    *message_ml = a.merged_ml;
+    const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
+    const unsigned grid = (unsigned)(a.nq * ns * bs);
+    a.items = (int)grid;
+    int rc = PDSC_OK;
+#define PDSC_ATT_LAUNCH_MG(NWV, CMV)                                                                                                        \
+    do {                                                                                                                                    \
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, CMV, false, false, true, true>), lds_bytes,   \
+                                "pdsc_sc_attention_merged(dynamic LDS)");                                                                   \
+        if (rc != PDSC_OK) return rc;                                                                                                       \
+        profile_mark_begin(PDSC_PROF_ATTENTION, st);                                                                                        \
+        hipLaunchKernelGGL((sc_attention_split_kernel<NWV, CMV, false, false, true, true>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);  \
+        profile_mark_end(PDSC_PROF_ATTENTION, st);                                                                                          \
+    } while (0)
+    if (nw == 8 && c16) PDSC_ATT_LAUNCH_MG(8, 1);
+    else if (nw == 8) PDSC_ATT_LAUNCH_MG(8, 0);
+    else if (c16) PDSC_ATT_LAUNCH_MG(4, 1);
+    else PDSC_ATT_LAUNCH_MG(4, 0);
+#undef PDSC_ATT_LAUNCH_MG
+    return check_launch("pdsc_sc_attention_merged");
+}
 
 extern "C" size_t pdsc_split_q_bytes(int bs, int N) {
     if (bs <= 0 || N <= 0) return 0;

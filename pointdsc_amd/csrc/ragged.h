@@ -30,6 +30,15 @@ int launch_attention_split_ex(const void* q_split, const void* kv_tiles, const v
                               float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, int partial_layout,
                               const int* nvalid, hipStream_t st);
 
+// merged form (attention_split.hip, sc_attention_split_kernel<..., MG = true>): leaves + ticketed in-kernel merge; the normalised
+// message is left in `scratch` in point-fragment order (*message, *message_ml = the one "partial" the H3 layer kernel reads)
+int attention_leaf_count(int N);
+void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out);
+int attention_merged_reset(void* scratch, int bs, int N, int leaves_mode, hipStream_t st);
+int launch_attention_merged(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
+                            void* scratch, size_t scratch_bytes, int bs, int N, int leaves_mode, const int* nvalid, int n_min,
+                            const float** message, const float** message_ml, hipStream_t st);
+
 // The three fused-layer entry points (pdsc_layer_fused_split / _frag_fmt / _frag_io: 18-24 arguments each) read the count
 // array from this thread-local slot when they fill LayerArgs; run_forward sets it for the duration of a ragged call and
 // clears it before returning (host-side, per thread: concurrent callers on other threads are unaffected).

@@ -58,6 +58,26 @@ WORKLOADS: Dict[str, dict] = {
                                label="3DMatch-like synthetic correspondences at the multiway evaluation size "
                                      "(multiway/test_multi_ate.py:245: N=20000)"),
 }
+# ---- trained-like weights (r05) -------------------------------------------------------------------------
+# The families above use seeded random weights: a regime with a nearly collapsed feature space (logits within a few 1e-2, top-k
+# boundary gaps of 5e-7) that a trained model never visits.  These use the checkpoints of oracle/make_trained_fixture.py -- the
+# UNMODIFIED reference trained with its own training forward and losses on synthetic pairs until its logits separate inliers
+# (tests/golden/trained_3dmatch.npz / trained_kitti.npz, 358 keys) -- and cycle the inlier ratio over 5 % .. 40 % so that the
+# hard low-overlap pairs, where the learned confidence matters, are a quarter of every census.
+TRAINED_CYCLE = (0.05, 0.1, 0.2, 0.4)
+WORKLOADS.update({
+    "trained_n1000_b1": dict(baseline_config=1, num_corr=1000, global_batch=1, model=BASE_MODEL, weights="trained_3dmatch", logit_shift=0.0,
+                             pair=dict(noise=0.01, scale=3.0), inlier_cycle=TRAINED_CYCLE, seed0=11000,
+                             label="3DMatch-like synthetic correspondences, TRAINED-LIKE weights (the unmodified reference trained on "
+                                   "synthetic pairs, oracle/make_trained_fixture.py), inlier ratio cycling 5/10/20/40 %"),
+    "trained_n5000_b32": dict(baseline_config=2, num_corr=5000, global_batch=32, model=BASE_MODEL, weights="trained_3dmatch", logit_shift=0.0,
+                              pair=dict(noise=0.01, scale=3.0), inlier_cycle=TRAINED_CYCLE, seed0=12000,
+                              label="3DMatch-like synthetic correspondences at N=5000, TRAINED-LIKE weights, inlier ratio cycling 5/10/20/40 %"),
+    "trained_kitti_n5000_b16": dict(baseline_config=3, num_corr=5000, global_batch=16, model=KITTI_MODEL, weights="trained_kitti", logit_shift=0.0,
+                                    pair=dict(noise=0.1, scale=60.0), inlier_cycle=TRAINED_CYCLE, seed0=13000,
+                                    label="KITTI-like synthetic correspondences (60 m, sigma_d=1.2 m, threshold 0.6 m), TRAINED-LIKE weights, "
+                                          "inlier ratio cycling 5/10/20/40 %"),
+})
 DEFAULT = "n5000_b32"
 
 # logit shifts of the workloads whose table entry says None: measured once by oracle/make_bench_goldens.py with the
@@ -73,6 +93,8 @@ MEASURED_LOGIT_SHIFT: Dict[str, float] = {
 
 def logit_shift(name: str) -> float:
     w = WORKLOADS[name]
+    if "weights" in w:
+        return 0.0                     # trained-like checkpoints are used as they are
     if w["logit_shift"] is not None:
         return float(w["logit_shift"])
     if name not in MEASURED_LOGIT_SHIFT:
@@ -80,8 +102,24 @@ def logit_shift(name: str) -> float:
     return MEASURED_LOGIT_SHIFT[name]
 
 
+def trained_state_dict(which: str, template: dict) -> dict:
+    """tests/golden/<which>.npz (oracle/make_trained_fixture.py) as a state_dict with the template's keys, dtypes and shapes."""
+    import numpy as np
+    from pathlib import Path
+    fx = np.load(Path(__file__).resolve().parents[1] / "tests" / "golden" / f"{which}.npz", allow_pickle=False)
+    out = {}
+    for k, ref in template.items():
+        v = torch.from_numpy(np.asarray(fx[k]))
+        if tuple(v.shape) != tuple(ref.shape):
+            raise ValueError(f"{which}: {k} has shape {tuple(v.shape)}, the module expects {tuple(ref.shape)}")
+        out[k] = v.to(ref.dtype).contiguous()
+    return out
+
+
 def state_dict(name: str, template: dict, shift: float | None = None) -> dict:
     w = WORKLOADS[name]
+    if "weights" in w:
+        return trained_state_dict(w["weights"], template)
     return synthetic.make_state_dict(template, seed=w["wseed"], logit_shift=logit_shift(name) if shift is None else shift,
                                      logit_sign=w.get("logit_sign", 1.0))
 
@@ -89,4 +127,9 @@ def state_dict(name: str, template: dict, shift: float | None = None) -> dict:
 def batch(name: str, first: int, count: int) -> Dict[str, torch.Tensor]:
     """Pairs [first, first+count) of the workload's global pair list (pair i is seeded seed0 + i)."""
     w = WORKLOADS[name]
+    if "inlier_cycle" in w:            # pair i: inlier ratio inlier_cycle[i % len]
+        cyc = w["inlier_cycle"]
+        pairs = [synthetic.make_pair(w["num_corr"], seed=w["seed0"] + i, inlier_ratio=cyc[i % len(cyc)], **w["pair"])
+                 for i in range(first, first + count)]
+        return {k: torch.cat([p[k] for p in pairs], dim=0).contiguous() for k in pairs[0]}
     return synthetic.make_batch(count, w["num_corr"], seed=w["seed0"] + first, **w["pair"])

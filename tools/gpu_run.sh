@@ -1,0 +1,95 @@
+#!/bin/bash
+# One parametrised GPU-box script (through gpurun) instead of a one-off script per experiment:
+#     bash tools/gpu_run.sh <tag> <step> [<step> ...]        -> gpurun_out/<tag>/...
+# steps:
+#   newtests        the r05 tests only (merged attention, canonical leaves, SM opt-in, trained census), fail-fast
+#   tests           pytest -m gpu, whole suite (tail of the log kept)
+#   smoke           __graft_entry__.smoke()
+#   ab_leaves       bench lines of n5000_b32 at 32 / 4 / 1 pairs for att_leaves = legacy | per_launch | canonical | 6 | 4
+#   ab_leaves_more  the same A/B on kitti_n5000_b16 (16, 2), lomatch_n10000_b8 (8, 1), n1000_b1 (1)
+#   latency         one pair per call, result read back (bench.py --latency): n5000 x1, n2000-like, n1000 x1
+#   census_trained  tools/parity_census.py on the trained-like families, every batch size, default and exact-fp32 arithmetic
+#   census          tools/parity_census.py on every family (default arithmetic), batches 0,1,2,4,8,16,32
+#   bundle          tools/gpu_profile_run.sh <tag> (the round's evidence bundle: bench lines, rocprof, PMC, micro-benches)
+#   kitti_stage     which arithmetic moves the KITTI pairs 60 / 21 / 26: one knob at a time
+set -u
+TAG=${1:?tag}
+shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$ROOT"
+line() { # file, bench args...
+  local f=$1; shift
+  timeout 400 python bench.py "$@" > "$OUT/$f.log" 2>&1
+  tail -1 "$OUT/$f.log" > "$OUT/$f.json"
+}
+summ() {
+python - "$OUT" <<'PY'
+import json, glob, sys, os
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "*.json"))):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        rl, ra = d.get("roofline_layer") or {}, d.get("roofline") or {}
+        print(os.path.basename(f).ljust(44), "value", round(d["value"], 1), "ms", d["ms_per_step"], "sust", round((d.get("sustained") or {}).get("value") or 0, 1),
+              "single", round((d.get("single_stream") or {}).get("value") or 0, 1), "att_ms", ra.get("avg_launch_ms"), "att_frac", ra.get("frac"),
+              "lay_ms", rl.get("avg_launch_ms"), "lay_frac", rl.get("frac"), "ok", (d.get("check") or {}).get("ok"), "plan", (d.get("config") or {}).get("attention_plan"))
+    except Exception as e:
+        print(os.path.basename(f), "ERR", repr(e)[:100])
+PY
+}
+for STEP in "$@"; do
+case $STEP in
+newtests)
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q --tb=short -k "leaves or merge or merged or leaf_plan or resident or trained" 2>&1 | tail -40 > "$OUT/newtests.txt"
+  tail -5 "$OUT/newtests.txt" ;;
+tests)
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60 > "$OUT/pytest_gpu.txt"
+  tail -5 "$OUT/pytest_gpu.txt" ;;
+smoke)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -5 > "$OUT/smoke.txt"; cat "$OUT/smoke.txt" ;;
+ab_leaves)
+  for L in legacy per_launch canonical 6 4; do
+    line ab_n5000_b32_x32_$L --config n5000_b32 --att-leaves $L --no-cpu-baseline --sustain-seconds 1.5
+  done
+  for L in legacy canonical 4; do
+    line ab_n5000_b32_x4_$L --config n5000_b32 --global-batch 4 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+    line ab_n5000_b32_x1_$L --config n5000_b32 --global-batch 1 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+  done
+  summ | tee "$OUT/ab_leaves_summary.txt" ;;
+ab_leaves_more)
+  for L in legacy canonical; do
+    line ab_kitti_x16_$L --config kitti_n5000_b16 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+    line ab_kitti_x2_$L --config kitti_n5000_b16 --global-batch 2 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+    line ab_lomatch_x8_$L --config lomatch_n10000_b8 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+    line ab_lomatch_x1_$L --config lomatch_n10000_b8 --global-batch 1 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+    line ab_n1000_x1_$L --config n1000_b1 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
+  done
+  summ | tee "$OUT/ab_leaves_more_summary.txt" ;;
+latency)
+  for L in legacy canonical; do
+    line lat_n5000_x1_$L --config n5000_b32 --global-batch 1 --latency --att-leaves $L --no-cpu-baseline --steps 200 --warmup 20 --sustain-seconds 1
+    line lat_n1000_x1_$L --config n1000_b1 --latency --att-leaves $L --no-cpu-baseline --steps 400 --warmup 20 --sustain-seconds 1
+    line lat_trained_n1000_x1_$L --config trained_n1000_b1 --latency --att-leaves $L --no-cpu-baseline --steps 400 --warmup 20 --sustain-seconds 1
+  done
+  summ | tee "$OUT/latency_summary.txt" ;;
+census_trained)
+  timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16 --batches 0,1,2,4,8,16,32 > "$OUT/parity_census_trained.txt" 2>&1
+  timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16 --batches 0,1 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/parity_census_trained_exact_fp32.txt" 2>&1
+  grep -E "^trained|strict pass|registration" "$OUT/parity_census_trained.txt" | cut -c1-400 | head -80 ;;
+census)
+  timeout 1500 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/parity_census.txt" 2>&1
+  grep -E "outside the fp32" "$OUT/parity_census.txt" | cut -c1-300 | head -80 ;;
+bundle)
+  bash tools/gpu_profile_run.sh "$TAG" ${BUNDLE_QUICK:-} ;;
+kitti_stage)
+  for K in "" "--compat-format f32" "--layer-gemm f32" "--attention-precision fp32 --compat-format f32" "--attention-precision fp32 --compat-format f32 --layer-gemm f32"; do
+    echo "== overrides: [$K]" >> "$OUT/kitti_stage.txt"
+    timeout 600 python tools/parity_census.py --families kitti_n5000_b16,kitti_n12000_b4 --batches 1,2,8 $K 2>&1 | grep -E "^kitti|outside the fp32|\"pair\"" | cut -c1-420 >> "$OUT/kitti_stage.txt"
+  done
+  grep -E "==|outside" "$OUT/kitti_stage.txt" | cut -c1-200 ;;
+*) echo "unknown step $STEP" ;;
+esac
+done
+ls -la "$OUT" | tail -40

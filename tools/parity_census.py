@@ -45,6 +45,17 @@ def judge(trans: torch.Tensor, labels: torch.Tensor, fx, n: int, first: int = 0)
     return ok32 | ok64, d32, torch.where(ok32, d32, torch.minimum(d32, d64)), f32, torch.where(ok32, 0, torch.where(ok64, 1, -1))
 
 
+def registration_columns(T: np.ndarray, gt: np.ndarray, re_thre: float, te_thre: float):
+    """Per pair (success, RE [deg], TE [cm]) with the reference's own expressions (libs/loss.py:44-51: RE = acos(clamp((tr(R^T R_gt)
+    - 1) / 2)), TE = |t - t_gt| * 100, success = RE < re_thre and TE < te_thre) -- the Registration-Recall columns of
+    evaluation/test_3DMatch.py:90-98 / test_KITTI.py, evaluated in fp64 from the returned poses."""
+    T, gt = np.asarray(T, np.float64), np.asarray(gt, np.float64)
+    tr = np.einsum("bij,bij->b", T[:, :3, :3], gt[:, :3, :3])
+    re = np.degrees(np.arccos(np.clip((tr - 1.0) / 2.0, -1.0, 1.0)))
+    te = np.linalg.norm(T[:, :3, 3] - gt[:, :3, 3], axis=1) * 100.0
+    return (re < re_thre) & (te < te_thre), re, te
+
+
 def decisions(model, bs: int, n: int):
     """The discrete decisions of the LAST forward, read from its workspace: per pair the seeds (correspondence indices, ranked),
     their inlier votes, the chosen seed's position and the refinement's inlier count per iteration (-1 padded)."""
@@ -146,7 +157,7 @@ def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None)
     return False, f"same hypothesis, same refinement sequence, neighbour set {'equal' if differs is not None else 'not recorded'}: no recorded discrete cause"
 
 
-def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0, attention_precision=None, model=None):
+def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: int = 0, attention_precision=None, model=None, att_leaves=None):
     fx = np.load(ROOT / "tests" / "golden" / f"census_{name}.npz", allow_pickle=False)
     ixp = ROOT / "tests" / "golden" / f"census_internals_{name}.npz"
     ix = np.load(ixp, allow_pickle=False) if ixp.exists() else None
@@ -163,6 +174,8 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
         model.layer_gemm = layer_gemm
     if attention_precision:
         model.attention_precision = attention_precision
+    if att_leaves is not None:
+        model.att_leaves = int(att_leaves) if str(att_leaves).lstrip("-").isdigit() else att_leaves
     out = {}
     for step in batches:
         T, L, D = [], [], []
@@ -198,7 +211,25 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
         t64 = torch.from_numpy(fx["ref64_final_trans"][:total]).double()
         d64 = (torch.cat(T).double() - t64).abs().amax(dim=(1, 2))
         ref_self = (torch.from_numpy(fx["ref32_final_trans"][:total]).double() - t64).abs().amax(dim=(1, 2))
-        out[step] = {"pairs": int(total), "failing_pairs": [int(i) for i in np.flatnonzero(~ok.numpy())],
+        # Registration-Recall surrogate (the released snapshots are absent): the reference's and this run's
+        # success / RE / TE columns on the same pairs (thresholds of config.py:67-68 / :75-76)
+        kitti = float(w["model"]["sigma_d"]) > 1.0
+        re_thre, te_thre = (5.0, 60.0) if kitti else (15.0, 30.0)
+        gt = fx["gt_trans"][:total]
+        s_ref, re_ref, te_ref = registration_columns(fx["ref32_final_trans"][:total], gt, re_thre, te_thre)
+        s_gpu, re_gpu, te_gpu = registration_columns(torch.cat(T).numpy(), gt, re_thre, te_thre)
+        both = s_ref & s_gpu
+        registration = {"re_thre_deg": re_thre, "te_thre_cm": te_thre, "recall_reference_fp32": float(s_ref.mean()), "recall_here": float(s_gpu.mean()),
+                        "pairs_where_success_differs": [int(i) for i in np.flatnonzero(s_ref != s_gpu)],
+                        "mean_RE_deg_reference": float(re_ref[both].mean()) if both.any() else None,
+                        "mean_RE_deg_here": float(re_gpu[both].mean()) if both.any() else None,
+                        "mean_TE_cm_reference": float(te_ref[both].mean()) if both.any() else None,
+                        "mean_TE_cm_here": float(te_gpu[both].mean()) if both.any() else None,
+                        "max_abs_RE_diff_deg": float(np.abs(re_ref - re_gpu)[both].max()) if both.any() else None,
+                        "max_abs_TE_diff_cm": float(np.abs(te_ref - te_gpu)[both].max()) if both.any() else None}
+        out[step] = {"pairs": int(total), "failing_pairs": [int(i) for i in np.flatnonzero(~ok.numpy())], "registration": registration,
+                     "strict_fp32_contract_pass_rate": float(strict.float().mean()),
+                     "excuses_used": sorted({("knn-tie" if "knn-tie" in v[1] else v[1].split(":")[0]) for v in verdicts.values() if v[0]}),
                      "failing_detail": [{"pair": int(i), "dT_vs_ref_fp32": float(d32[i]), "dT_vs_ref_fp64": float(d64[i]),
                                          "label_flips_vs_ref_fp32": int(f32[i]), "reference_fp32_vs_fp64_dT": float(ref_self[i])}
                                         for i in np.flatnonzero(~ok.numpy())],
@@ -222,14 +253,18 @@ def main():
     ap.add_argument("--layer-gemm", default=None)
     ap.add_argument("--attention-precision", default=None, help='"fp32" = the exact-fp32 path (with --compat-format f32 --layer-gemm f32)')
     ap.add_argument("--pairs", type=int, default=0, help="first K pairs of each family only")
+    ap.add_argument("--att-leaves", default=None, help="legacy | per_launch | canonical | an int (enum pdsc_att_leaves)")
+    ap.add_argument("--families", default=None, help="comma list of workload families (default: every family with a census fixture)")
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
     report = {}
     for name, w in workloads.WORKLOADS.items():
         if (a.only and name != a.only) or not (ROOT / "tests" / "golden" / f"census_{name}.npz").exists():
             continue
+        if a.families and name not in a.families.split(","):
+            continue
         batches = [int(x) or w["global_batch"] for x in a.batches.split(",")]
-        rep, model = run_family(name, batches, a.compat_format, a.layer_gemm, a.pairs, a.attention_precision)
+        rep, model = run_family(name, batches, a.compat_format, a.layer_gemm, a.pairs, a.attention_precision, att_leaves=a.att_leaves)
         report[name] = rep
         if not a.json:
             for step, r in rep.items():
@@ -240,7 +275,9 @@ def main():
                       flush=True)
                 for fd in r["failing_detail"]:
                     print("    ", json.dumps(fd), flush=True)
-                print(f"    outside the fp32 contract: {r['outside_fp32_contract']}; unexcused by the reference's recorded decisions: {r['unexcused']}", flush=True)
+                print(f"    outside the fp32 contract: {r['outside_fp32_contract']}; unexcused by the reference's recorded decisions: {r['unexcused']}; "
+                      f"strict pass rate {r['strict_fp32_contract_pass_rate']:.4f}; excuses used {r['excuses_used']}", flush=True)
+                print(f"    registration: {json.dumps(r['registration'])}", flush=True)
                 for fd in r["outside_fp32_contract_detail"]:
                     print("      ", json.dumps(fd), flush=True)
     if a.json:
