@@ -375,6 +375,12 @@ int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds
  * dist_scratch: [bs][S][ldd] floats, ldd = pdsc_compat_ld(N).  knn_idx: [bs][S][k] int32. */
 int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx,
                    int bs, int N, int S, int k, void* stream);
+/* form: 0 = the library's choice, 1 = two launches through the S x N distance matrix (Gram rows, then a selection launch),
+ * 2 = fused (r05: 32 seeds per workgroup, the distances never leave the chip -- only candidates below a per-seed bound reach an
+ * LDS list; needs k + 1 <= 48 and N >= 256; dist_scratch unused).  Same distance bits, same (dist, index) order: the neighbour
+ * indices of the two forms are identical.  form 0 takes the fused form when bs * ceil(S / 32) >= 384 workgroups. */
+int pdsc_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx,
+                        int bs, int N, int S, int k, int form, void* stream);
 
 /* ---- a-7/a-8  per-seed compatibility + power iteration ----------------------------------------
  * replaces models/PointDSC.py:257-281 and cal_leading_eigenvector (:347-358).

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pdsc_nms_keys_grid": (_i, [_vp, _vp, _f, _vp, _vp, _sz, _i, _i, _vp]),
     "pdsc_rank_select": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pdsc_knn_seeds": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pdsc_knn_seeds_form": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pdsc_seed_power_iteration": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pdsc_seed_solve": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _vp]),
     "pdsc_seed_transforms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

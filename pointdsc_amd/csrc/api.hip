@@ -133,7 +133,7 @@ static bool config_ok(const pdsc_config* c) {
 #endif
     if (c->compat_format != PDSC_COMPAT_U16 && c->compat_format != PDSC_COMPAT_F32) { set_error("compat_format=%d", c->compat_format); return false; }
     if (c->layer_gemm != PDSC_LAYER_GEMM_F32 && c->layer_gemm != PDSC_LAYER_GEMM_H3) { set_error("layer_gemm=%d", c->layer_gemm); return false; }
-    if (c->att_leaves < PDSC_LEAVES_LEGACY || c->att_leaves > 64) { set_error("att_leaves=%d (enum pdsc_att_leaves, or 2..64 leaves)", c->att_leaves); return false; }
+    if (c->att_leaves < PDSC_LEAVES_LEGACY || c->att_leaves > PDSC_ATT_MAX_LEAVES) { set_error("att_leaves=%d (enum pdsc_att_leaves, or 2..%d leaves)", c->att_leaves, PDSC_ATT_MAX_LEAVES); return false; }
     return true;
 }
 
@@ -457,6 +457,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         if (cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH) merged_plan(bs, N, cfg->att_leaves, &mg_nw, &mg_ns, &mg_leaves);
         // (per-launch leaves with a single key split: the legacy un-split launch already writes the normalised rows -- its bits, kept)
         const bool merged = pf_ok && cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH && (mg_leaves > 1 || cfg->att_leaves != PDSC_LEAVES_PER_LAUNCH) &&
+                            mg_leaves <= PDSC_ATT_MAX_LEAVES &&
                             (!nvalid || (n_min + 31) / 32 >= mg_leaves);
         if (nvalid && !merged)
             PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),

@@ -53,6 +53,7 @@ __device__ __forceinline__ f32x16 scale_acc(f32x16 o, float alpha) {
     return o;
 }
 
+constexpr int ATT_MAX_LEAVES = PDSC_ATT_MAX_LEAVES;         // merged form: leaves per pair the merging wavefront is unrolled for
 constexpr float ATT_RESCALE_THR = 8.0f;   // running max is only moved when a logit exceeds it by 2^8 (log2 domain)
 constexpr int SPL_K_BYTES = 2 * SPL_K_PLANE;    // Kh | Kl   16 KiB
 constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
@@ -476,10 +477,16 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         if constexpr (MG) {
             if (pend) {                                        // (workgroup-uniform) the leaf that ended with the previous tile
                 leaf_store(leaf_prev, m_prev, l_prev);
+                // zero IN PLACE (one asm statement per register, as scale_acc: a plain `o[c][r] = 0.f` inside this branch made the
+                // register allocator keep two copies of O and move one per tile -- 280 v_mov per iteration, +15 % per launch, r05a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        float v = o[c][r];
+                        asm volatile("v_mov_b32 %0, 0" : "+v"(v));
+                        o[c][r] = v;
+                    }
                 pend = false;
             }
         }
@@ -708,58 +715,68 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         //      w_c = exp2(m_c - max m), den = fma chain of l_c w_c, acc = fma chain of O_c w_c, message = acc * (1 / den)) from the
         //      partials as they lie in memory (its own included), loads past the caches
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const int C = a.nleaf;
+        const int C = a.nleaf;                       // <= ATT_MAX_LEAVES (launcher)
         const unsigned mlo = (q0w + (unsigned)l31) * 8u, mls = (unsigned)a.Npad * 8u;
         const unsigned pvo = q0w * (unsigned)(PDSC_CHANNELS * 4) + lane16, pvs = (unsigned)a.Npad * (unsigned)(PDSC_CHANNELS * 4);
-        float mmax = -INFINITY;
-        for (int c0 = 0; c0 < C; c0 += 4) {          // four loads per round trip (index clamped: a repeated leaf does not move the maximum)
-            u32x2 ml4[4];
+        // The merge is a chain of memory round trips (the partials lie at the memory side), so everything is asked for as early as
+        // the registers allow: all (m, l) pairs and the first MD half-leaves at once, then a continuous stream -- two passes of 64
+        // channels over the leaves, every consumed slot refilled at once with the stream's next half-leaf (the second pass starts
+        // arriving while the first is still being summed).  Loads are unconditional (indices clamped; a few are wasted at the ends),
+        // only the arithmetic is guarded, and every loop is unrolled to ATT_MAX_LEAVES: the compiler counts the loads in flight
+        // exactly and every register index is a constant.
+        constexpr int MD = 3, RMAX = ATT_MAX_LEAVES / MD;
+        static_assert(ATT_MAX_LEAVES % MD == 0, "whole rounds");
+        const int R = (C + MD - 1) / MD;             // rounds per pass
+        u32x2 mlv[ATT_MAX_LEAVES];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) ml4[d] = __builtin_amdgcn_raw_buffer_load_b64(pm_rsrc, mlo + (unsigned)min(c0 + d, C - 1) * mls, 0, AUX_THROUGH);
+        for (int c = 0; c < ATT_MAX_LEAVES; ++c) mlv[c] = __builtin_amdgcn_raw_buffer_load_b64(pm_rsrc, mlo + (unsigned)min(c, C - 1) * mls, 0, AUX_THROUGH);
+        u32x4 buf[MD][8];
+        auto issue = [&](int d, int pass, int c) {
+            const unsigned off = pvo + (unsigned)min(c, C - 1) * pvs + 8192u * (unsigned)pass;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) mmax = fmaxf(mmax, __uint_as_float(ml4[d][0]));
+            for (int i = 0; i < 8; ++i) buf[d][i] = __builtin_amdgcn_raw_buffer_load_b128(po_rsrc, off + 1024u * i, 0, AUX_THROUGH);
+        };
+#pragma unroll
+        for (int d = 0; d < MD; ++d) issue(d, 0, d);
+        float wv[ATT_MAX_LEAVES];
+        float mmax = __uint_as_float(mlv[0][0]);
+#pragma unroll
+        for (int c = 1; c < ATT_MAX_LEAVES; ++c) mmax = fmaxf(mmax, __uint_as_float(mlv[c][0]));      // (repeats of the last leaf do not move it)
+        float den = 0.f;
+#pragma unroll
+        for (int c = 0; c < ATT_MAX_LEAVES; ++c) {
+            wv[c] = __builtin_amdgcn_exp2f(__uint_as_float(mlv[c][0]) - mmax);
+            if (c < C) den = fmaf(__uint_as_float(mlv[c][1]), wv[c], den);
         }
-        // Two passes of 64 channels each (a pass keeps MD leaves of 8 KiB per wave in flight: the merge is a chain of memory round
-        // trips, and with all 128 channels of a leaf in registers only one leaf at a time fits beside the accumulators).  Loads are
-        // unconditional (leaf index clamped: the last rounds re-read the last leaf), only the arithmetic is guarded -- the compiler
-        // can then count the loads in flight exactly instead of draining them at every branch.
-        constexpr int MD = 4;
-        float den = 0.f, rden = 0.f;
+        const float rden = 1.0f / den;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             f32x4 acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            u32x4 buf[MD][8];
-            u32x2 mlb[MD];
-            auto issue = [&](int d, int c) {
-                const unsigned cc = (unsigned)min(c, C - 1);
-                mlb[d] = __builtin_amdgcn_raw_buffer_load_b64(pm_rsrc, mlo + cc * mls, 0, AUX_THROUGH);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    buf[d][i] = __builtin_amdgcn_raw_buffer_load_b128(po_rsrc, pvo + cc * pvs + 1024u * (8 * pass + i), 0, AUX_THROUGH);
-            };
+            for (int r = 0; r < RMAX; ++r) {
+                if (r < R) {                              // (wave-uniform)
 #pragma unroll
-            for (int d = 0; d < MD; ++d) issue(d, d);
-            for (int c0 = 0; c0 < C; c0 += MD) {
+                    for (int d = 0; d < MD; ++d) {
+                        const int c = r * MD + d;
+                        if (c < C) {
+                            const float w = wv[c];
 #pragma unroll
-                for (int d = 0; d < MD; ++d) {
-                    const int c = c0 + d;
-                    const float w = __builtin_amdgcn_exp2f(__uint_as_float(mlb[d][0]) - mmax);
-                    const float lc = __uint_as_float(mlb[d][1]);
-                    if (c < C) {                          // (wave-uniform)
-                        if (pass == 0) den = fmaf(lc, w, den);
+                            for (int i = 0; i < 8; ++i) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, buf[d][i]);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const f32x4 v = __builtin_bit_cast(f32x4, buf[d][i]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(v[e], w, acc[i][e]);
+                                for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(v[e], w, acc[i][e]);
+                            }
                         }
+                        // the slot's next half-leaf: leaf c + MD of this pass, or -- in the pass's last round -- leaf d of the next pass
+                        const bool more = r + 1 < R;
+                        if (more || pass == 0) issue(d, more ? pass : 1, more ? c + MD : d);
+                        __builtin_amdgcn_sched_barrier(0);       // (fully unrolled: left alone the scheduler hoists every load of the stream to the top)
                     }
-                    issue(d, c + MD);                     // the slot's next leaf (three other leaves are in flight meanwhile)
                 }
             }
-            if (pass == 0) rden = 1.0f / den;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 *reinterpret_cast<f32x4*>(mbase + pf_offset_floats(8 * pass + i)) = f32x4{acc[i][0] * rden, acc[i][1] * rden, acc[i][2] * rden, acc[i][3] * rden};
@@ -936,6 +953,7 @@ void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, i
     const int tiles = spl_num_tiles(N);
     int C = leaves_mode == PDSC_LEAVES_CANONICAL ? attention_leaf_count(N) : leaves_mode;
     if (C > tiles) C = tiles;
+    if (C > ATT_MAX_LEAVES) C = ATT_MAX_LEAVES;
     if (C < 1) C = 1;
     // the per-launch cost model over the divisors of C; a leaf that ends inside a workgroup's range costs about a third of a tile
     // (its partial leaves through the caches and is read back by the merging wave)

@@ -32,6 +32,7 @@ int launch_attention_split_ex(const void* q_split, const void* kv_tiles, const v
 
 // merged form (attention_split.hip, sc_attention_split_kernel<..., MG = true>): leaves + ticketed in-kernel merge; the normalised
 // message is left in `scratch` in point-fragment order (*message, *message_ml = the one "partial" the H3 layer kernel reads)
+constexpr int PDSC_ATT_MAX_LEAVES = 12;      // leaves per pair the merging wavefront is unrolled for (a per-launch plan with more key splits takes the legacy hand-off)
 int attention_leaf_count(int N);
 void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out);
 int attention_merged_reset(void* scratch, int bs, int N, int leaves_mode, hipStream_t st);

@@ -564,8 +564,203 @@ int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_see
     return check_launch("pdsc_rank_select");
 }
 
+// ---- kNN of the seeds WITHOUT the S x N distance matrix (r05): Gram rows on the fp32 matrix cores and the selection in one launch.
+// knn_dist_rows + knn_select_kernel write and re-read 4 S N bytes per pair (320 MB at 32 pairs of N = 5000: 1.7 x the Gram's
+// algorithmic traffic); here a workgroup owns 32 seeds, its four waves walk the columns in blocks of 32 (wave w: blocks w, w + 4, ..),
+// and a distance leaves the registers only if it can still be among its seed's k + 1 smallest:
+//   * arithmetic of gram_rows_kernel<1, .> to the bit: A = the seed's feature row (registers), B = 32 columns' rows loaded straight
+//     from L2 (the normalised features of a pair are 2.5 MB), 64 x v_mfma_f32_32x32x2_f32 in the same order, dist = 2 - 2 * dot;
+//   * candidate = composite (monotone(dist) << idx_bits | column), unique; per seed an LDS list of KF_CAP composites and an upper
+//     bound tau on its (k+1)-th smallest composite: a composite enters the list only if < tau (tau starts at "everything");
+//   * after every round of 128 columns (one workgroup barrier) a list longer than KF_CAP - 128 is cut back: tau = the (k+1)-th
+//     smallest of 64 lane minima over the list (an upper bound of the list's (k+1)-th smallest, hence of the seed's), entries
+//     above it are dropped; should more than KF_KEEP survive (many equal distances) the list is cut to exactly the k + 1 smallest;
+//   * at the end the list holds every one of the seed's k + 1 smallest composites: exact ranking, ranks 1..k are the neighbours
+//     (rank 0 dropped like `[:, :, 1:]`, models/common.py:69) -- the same selection on the same distance bits as knn_select_kernel.
+constexpr int KF_ROWS = 32, KF_CAP = 256, KF_KEEP = 96, KF_MAX_WANT = 48;
+
+struct KnnFusedArgs {
+    const float* X;          // [bs][NS][128] normalised features
+    const int* seeds;        // [bs][S]
+    int* knn_idx;            // [bs][S][k]
+    int NS, S, k, idx_bits;
+    const int* nvalid;       // ragged batches: [bs] rows per pair, or NULL
+};
+
+__global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long kf_dyn[];
+    unsigned long long (*list)[KF_CAP] = reinterpret_cast<unsigned long long (*)[KF_CAP]>(kf_dyn);       // [KF_ROWS][KF_CAP]: 64 KiB (dynamic: past the static limit)
+    __shared__ unsigned long long tau[KF_ROWS];
+    __shared__ int cnt[KF_ROWS];
+    __shared__ unsigned long long gmin[4][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, r0 = blockIdx.x * KF_ROWS;
+    const int N = a.nvalid ? a.nvalid[b] : a.NS;
+    const float* X = a.X + (size_t)b * a.NS * PDSC_CHANNELS;
+    const int want = a.k + 1;
+    const unsigned long long idx_mask = (1ULL << a.idx_bits) - 1ULL;
+    if (t < KF_ROWS) { tau[t] = ~0ULL; cnt[t] = 0; }
+
+    // A fragments of this lane's seed row (k-slot (4q+e, half h) <-> channel 8q+4h+e): identical in the four waves
+    f32x4 af[16];
+    {
+        const int row = a.seeds[(size_t)b * a.S + min(r0 + l31, a.S - 1)];
+        const float* p = X + (size_t)row * PDSC_CHANNELS + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+    }
+    const int nblocks = (N + 31) >> 5, rounds = (nblocks + 3) >> 2;
+    f32x4 bf[16];
+    auto load_b = [&](int cb) {
+        const int col = min(cb * 32 + l31, N - 1);
+        const float* p = X + (size_t)col * PDSC_CHANNELS + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bf[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+    };
+    load_b(wave);
+    __syncthreads();
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int cb = rd * 4 + wave;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][e], bf[q][e], acc, 0, 0, 0);
+        load_b(cb + 4);                                               // next round's columns: in flight under the filter and the barrier
+        const int col = cb * 32 + l31;
+        if (col < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = 2.0f - 2.0f * acc[r];                 // == reference `2 - 2*matmul` (gram_rows_kernel MODE 1)
+                const unsigned long long key = ((unsigned long long)float_order_bits(v) << a.idx_bits) | (unsigned)col;
+                if (r0 + row < a.S && key < tau[row]) {
+                    const int slot = atomicAdd(&cnt[row], 1);
+                    list[row][slot] = key;                            // slot < KF_CAP: a round adds at most 128 to a list of at most KF_CAP - 128
+                }
+            }
+        }
+        __syncthreads();
+        // cut back the long lists: wave w looks after rows 8 w .. 8 w + 7
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            const int n = cnt[row];                                    // (wave-uniform)
+            if (n <= KF_CAP - 128) continue;
+            // lane minima over the list (n > 128: every lane owns at least two entries), the (k+1)-th smallest of them bounds the
+            // list's (k+1)-th smallest from above
+            unsigned long long e[KF_CAP / 64], mine = ~0ULL;
+#pragma unroll
+            for (int u = 0; u < KF_CAP / 64; ++u) {
+                e[u] = lane + 64 * u < n ? list[row][lane + 64 * u] : ~0ULL;
+                mine = e[u] < mine ? e[u] : mine;
+            }
+            gmin[wave][lane] = mine;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int rk = 0;
+#pragma unroll 8
+            for (int u = 0; u < 64; ++u) rk += gmin[wave][u] < mine;
+            const unsigned long long vote = __ballot(rk == want - 1);       // exactly one lane (minima are distinct composites)
+            const int src = __ffsll((long long)vote) - 1;
+            unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), src) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffULL), src);
+            // survivors (<= ub) back to the front of the list, in any order
+            int kept = 0;
+#pragma unroll
+            for (int u = 0; u < KF_CAP / 64; ++u) {
+                const bool keep = e[u] <= ub;                              // (padding ~0 is never <= a real composite)
+                const unsigned long long bal = __ballot(keep);
+                if (keep) list[row][kept + __popcll(bal & ((1ULL << lane) - 1ULL))] = e[u];
+                kept += __popcll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (kept > KF_KEEP) {
+                // many entries at or below the bound (equal distances): cut to exactly the k + 1 smallest by exact ranking
+                unsigned long long f[KF_CAP / 64], cand = 0ULL;
+                int rank[KF_CAP / 64];
+#pragma unroll
+                for (int u = 0; u < KF_CAP / 64; ++u) { f[u] = lane + 64 * u < kept ? list[row][lane + 64 * u] : ~0ULL; rank[u] = 0; }
+                for (int j = 0; j < kept; ++j) {
+                    const unsigned long long o = list[row][j];
+#pragma unroll
+                    for (int u = 0; u < KF_CAP / 64; ++u) rank[u] += o < f[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                            // every lane has read the list: now it is rewritten in rank order
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int u = 0; u < KF_CAP / 64; ++u) {
+                    const bool real = lane + 64 * u < kept;
+                    if (real && rank[u] < want) list[row][rank[u]] = f[u];
+                    if (real && rank[u] == want - 1) cand = f[u];           // (composites are never 0: the distance bits have their top bit set)
+                }
+                const unsigned long long who = __ballot(cand != 0ULL);     // exactly one lane
+                const int sl = __ffsll((long long)who) - 1;
+                ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cand >> 32), sl) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)(cand & 0xffffffffULL), sl);
+                kept = want;
+            }
+            if (lane == 0) { cnt[row] = kept; tau[row] = ub; }             // later composites enter only below the bound (they cannot equal it)
+        }
+        __syncthreads();
+    }
+    // ---- every list now holds its seed's k + 1 smallest composites (and some more): exact ranks, 1 .. k are the neighbours ----
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr;
+        if (r0 + row >= a.S) continue;
+        const int n = cnt[row];
+        unsigned long long f[KF_CAP / 64];
+        int rank[KF_CAP / 64];
+#pragma unroll
+        for (int u = 0; u < KF_CAP / 64; ++u) { f[u] = lane + 64 * u < n ? list[row][lane + 64 * u] : ~0ULL; rank[u] = 0; }
+        for (int j = 0; j < n; ++j) {
+            const unsigned long long o = list[row][j];
+#pragma unroll
+            for (int u = 0; u < KF_CAP / 64; ++u) rank[u] += o < f[u];
+        }
+#pragma unroll
+        for (int u = 0; u < KF_CAP / 64; ++u)
+            if (lane + 64 * u < n && rank[u] >= 1 && rank[u] < want)
+                a.knn_idx[((size_t)b * a.S + r0 + row) * a.k + (rank[u] - 1)] = (int)(f[u] & idx_mask);
+    }
+}
+
+// form: 0 = the library's choice, 1 = two launches through the S x N matrix (knn_dist_rows + knn_select_kernel), 2 = fused
+int launch_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
+                          const int* nvalid, int form, hipStream_t st);
+
 int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
                      const int* nvalid, hipStream_t st) {
+    return launch_knn_seeds_form(normed, seeds, dist_scratch, knn_idx, bs, N, S, k, nvalid, 0, st);
+}
+
+int launch_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
+                          const int* nvalid, int form, hipStream_t st) {
+    PDSC_REQUIRE(form >= 0 && form <= 2, "pdsc_knn_seeds: form=%d", form);
+    // fused: enough workgroups of 32 seeds to fill the chip (else the two-launch form, whose Gram splits the columns too), k + 1
+    // within the 64 lane minima's reach, and at least k + 1 columns per pair
+    const bool fits = k + 1 <= KF_MAX_WANT && N >= 256;
+    PDSC_REQUIRE(form != 2 || fits, "pdsc_knn_seeds: the fused form needs k + 1 <= %d and N >= 256 (k=%d, N=%d)", KF_MAX_WANT, k, N);
+    if (form == 2 || (form == 0 && fits && (long long)bs * ceil_div(S, KF_ROWS) >= 384)) {
+        PDSC_REQUIRE(normed && seeds && knn_idx, "pdsc_knn_seeds: null pointer");
+        PDSC_REQUIRE(bs > 0 && N > 1 && S > 0, "pdsc_knn_seeds: bs=%d N=%d S=%d", bs, N, S);
+        PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K && k <= N - 1, "pdsc_knn_seeds: k=%d (N=%d, max %d)", k, N, PDSC_MAX_K);
+        KnnFusedArgs a{};
+        a.X = normed; a.seeds = seeds; a.knn_idx = knn_idx; a.NS = N; a.S = S; a.k = k; a.nvalid = nvalid;
+        a.idx_bits = 1;
+        while ((1 << a.idx_bits) < N) ++a.idx_bits;
+        const size_t lds_bytes = (size_t)KF_ROWS * KF_CAP * sizeof(unsigned long long);
+        const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fused_kernel), lds_bytes, "pdsc_knn_seeds(fused, dynamic LDS)");
+        if (rc_lds != PDSC_OK) return rc_lds;
+        hipLaunchKernelGGL(knn_fused_kernel, dim3(ceil_div(S, KF_ROWS), bs), dim3(256), lds_bytes, st, a);
+        return check_launch("pdsc_knn_seeds(fused)");
+    }
+
     PDSC_REQUIRE(normed && seeds && dist_scratch && knn_idx, "pdsc_knn_seeds: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 1 && S > 0, "pdsc_knn_seeds: bs=%d N=%d S=%d", bs, N, S);
     PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K && k <= N - 1, "pdsc_knn_seeds: k=%d (N=%d, max %d)", k, N, PDSC_MAX_K);
@@ -593,6 +788,11 @@ extern "C" int pdsc_nms_keys_grid(const float* src, const float* conf, float rad
 
 extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, void* stream) {
     return pdsc::launch_rank_select(keys, seeds, bs, N, num_seeds, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pdsc_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
+                                   int S, int k, int form, void* stream) {
+    return pdsc::launch_knn_seeds_form(normed, seeds, dist_scratch, knn_idx, bs, N, S, k, nullptr, form, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,

@@ -160,12 +160,12 @@ class PointDSC(nn.Module):
             raise ValueError(f"compat_format must be one of {sorted(COMPAT_FORMATS)}, got {self.compat_format!r}")
         if self.layer_gemm not in LAYER_GEMMS:
             raise ValueError(f"layer_gemm must be one of {sorted(LAYER_GEMMS)}, got {self.layer_gemm!r}")
-        if isinstance(self.att_leaves, int) and not isinstance(self.att_leaves, bool) and 2 <= self.att_leaves <= 64:
+        if isinstance(self.att_leaves, int) and not isinstance(self.att_leaves, bool) and 2 <= self.att_leaves <= 12:
             leaves = int(self.att_leaves)
         elif self.att_leaves in ATT_LEAVES:
             leaves = ATT_LEAVES[self.att_leaves]
         else:
-            raise ValueError(f"att_leaves must be one of {sorted(ATT_LEAVES)} or an int in [2, 64], got {self.att_leaves!r}")
+            raise ValueError(f"att_leaves must be one of {sorted(ATT_LEAVES)} or an int in [2, 12], got {self.att_leaves!r}")
         return _lib.PdscConfig(self.in_dim, self.num_layers, self.num_channels, self.num_iterations, self.k, 20,
                                float(self.inlier_threshold), float(self.nms_radius), float(refine_thr),
                                ATTENTION_PRECISIONS[self.attention_precision], COMPAT_FORMATS[self.compat_format],

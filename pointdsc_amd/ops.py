@@ -463,8 +463,10 @@ def pick_seeds(src_keypts, scores, R: float, max_num: int) -> torch.Tensor:
 
 
 @_on_device
-def knn_seeds(normed, seeds, k: int, return_dist: bool = False):
-    """normed [bs,N,128], seeds [bs,S] int32 -> knn_idx [bs,S,k] int32."""
+def knn_seeds(normed, seeds, k: int, return_dist: bool = False, form: str = "auto"):
+    """normed [bs,N,128], seeds [bs,S] int32 -> knn_idx [bs,S,k] int32.  form: "auto" (the library's choice), "matrix" (Gram rows
+    written to HBM, then a selection launch) or "fused" (one launch, no S x N matrix; the returned distances are then undefined)."""
+    forms = {"auto": 0, "matrix": 1, "fused": 2}
     lib = _lib.load()
     normed, seeds = _chk(normed, "normed"), _chk(seeds, "seeds", torch.int32)
     bs, n = normed.shape[0], normed.shape[1]
@@ -472,7 +474,7 @@ def knn_seeds(normed, seeds, k: int, return_dist: bool = False):
     ld = compat_ld(n)
     dist = torch.empty(bs, s, ld, device=normed.device, dtype=torch.float32)
     idx = torch.empty(bs, s, k, device=normed.device, dtype=torch.int32)
-    _lib.check(lib.pdsc_knn_seeds(_p(normed), _p(seeds), _p(dist), _p(idx), bs, n, s, k, _stream()), "pdsc_knn_seeds")
+    _lib.check(lib.pdsc_knn_seeds_form(_p(normed), _p(seeds), _p(dist), _p(idx), bs, n, s, k, forms[form], _stream()), "pdsc_knn_seeds")
     return (idx, dist[..., :n]) if return_dist else idx
 
 

@@ -1496,6 +1496,42 @@ def test_forward_is_bitwise_repeatable():
         model.compat_format = COMPAT_FORMAT_DEFAULT
 
 
+@pytest.mark.parametrize("bs,n,s,k,dup", [(2, 1000, 100, 40, 0), (32, 5000, 500, 40, 0), (3, 2053, 205, 40, 0), (1, 5000, 500, 40, 0),
+                                        (4, 700, 70, 47, 0), (2, 1500, 150, 40, 600), (1, 300, 33, 10, 0), (8, 10000, 1000, 40, 0)])
+def test_knn_fused_form_equals_the_matrix_form(bs, n, s, k, dup):
+    """r05: pdsc_knn_seeds_form 2 computes the seeds' Gram rows on the fp32 matrix cores and selects the k
+    neighbours in the same launch -- the S x N distance matrix (320 MB at 32 pairs of N = 5000) is never written.  Same MFMA order
+    -> same distance bits; same (distance, index) composite order -> the neighbour indices equal the two-launch form's exactly,
+    including rows with hundreds of EQUAL distances (duplicated feature rows: ties resolve by ascending index in both)."""
+    rs = np.random.RandomState(700 + n + bs)
+    x = rs.standard_normal((bs, n, 128)).astype(np.float32)
+    if dup:
+        x[:, dup:2 * dup] = x[:, :dup]                      # every distance to a duplicated row appears twice
+        x[:, 2 * dup:2 * dup + 200] = x[:, :1]              # ... and 200 copies of row 0: 200-way ties
+    x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    normed = g(torch.from_numpy(x))
+    seeds = g(torch.from_numpy(np.stack([rs.permutation(n)[:s] for _ in range(bs)]).astype(np.int32)))
+    want = ops.knn_seeds(normed, seeds, k, form="matrix")
+    got = ops.knn_seeds(normed, seeds, k, form="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), (int((got != want).sum()), got.shape)
+    auto = ops.knn_seeds(normed, seeds, k)
+    assert torch.equal(auto, want)
+    for _ in range(3):                                       # repeated launches: nothing carried over between them
+        assert torch.equal(ops.knn_seeds(normed, seeds, k, form="fused"), want)
+
+
+def test_knn_fused_form_rejections():
+    normed = g(torch.nn.functional.normalize(torch.randn(1, 200, 128), dim=-1))
+    seeds = g(torch.arange(20, dtype=torch.int32)[None])
+    with pytest.raises(RuntimeError, match="fused form"):
+        ops.knn_seeds(normed, seeds, 40, form="fused")                   # N < 256
+    normed = g(torch.nn.functional.normalize(torch.randn(1, 600, 128), dim=-1))
+    with pytest.raises(RuntimeError, match="fused form"):
+        ops.knn_seeds(normed, seeds, 60, form="fused")                   # k + 1 > 48
+    assert ops.knn_seeds(normed, seeds, 60).shape == (1, 20, 60)         # the library's choice falls back
+
+
 LEAVES_DEFAULT = "canonical"
 
 

@@ -11,6 +11,7 @@
 #   census_trained  tools/parity_census.py on the trained-like families, every batch size, default and exact-fp32 arithmetic
 #   census          tools/parity_census.py on every family (default arithmetic), batches 0,1,2,4,8,16,32
 #   bundle          tools/gpu_profile_run.sh <tag> (the round's evidence bundle: bench lines, rocprof, PMC, micro-benches)
+#   knn_bench       kNN of the seeds: two-launch (S x N matrix) form against the fused form
 #   kitti_stage     which arithmetic moves the KITTI pairs 60 / 21 / 26: one knob at a time
 set -u
 TAG=${1:?tag}
@@ -42,7 +43,7 @@ PY
 for STEP in "$@"; do
 case $STEP in
 newtests)
-  timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q --tb=short -k "leaves or merge or merged or leaf_plan or resident or trained" 2>&1 | tail -40 > "$OUT/newtests.txt"
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q --tb=short -k "leaves or merge or merged or leaf_plan or resident or trained or knn_fused" 2>&1 | tail -40 > "$OUT/newtests.txt"
   tail -5 "$OUT/newtests.txt" ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60 > "$OUT/pytest_gpu.txt"
@@ -89,6 +90,30 @@ kitti_stage)
     timeout 600 python tools/parity_census.py --families kitti_n5000_b16,kitti_n12000_b4 --batches 1,2,8 $K 2>&1 | grep -E "^kitti|outside the fp32|\"pair\"" | cut -c1-420 >> "$OUT/kitti_stage.txt"
   done
   grep -E "==|outside" "$OUT/kitti_stage.txt" | cut -c1-200 ;;
+knn_bench)
+  python - > "$OUT/knn_bench.txt" 2>&1 <<'PY'
+import numpy as np, torch
+from pointdsc_amd import ops
+for bs, n in ((32, 5000), (16, 5000), (8, 10000), (4, 5000)):
+    s = n // 10
+    rs = np.random.RandomState(1)
+    x = rs.standard_normal((bs, n, 128)).astype(np.float32); x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    normed = torch.from_numpy(x).cuda()
+    seeds = torch.from_numpy(np.stack([rs.permutation(n)[:s] for _ in range(bs)]).astype(np.int32)).cuda()
+    out = {}
+    for form in ("matrix", "fused"):
+        for _ in range(3): r = ops.knn_seeds(normed, seeds, 40, form=form)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): r = ops.knn_seeds(normed, seeds, 40, form=form)
+        e1.record(); torch.cuda.synchronize()
+        out[form] = (e0.elapsed_time(e1) / 20 * 1e3, r)
+    flops = 256.0 * bs * s * n
+    print(f"kNN of the seeds, {bs} pairs of N={n}, S={s}, k=40: matrix form {out['matrix'][0]:.1f} us, fused {out['fused'][0]:.1f} us "
+          f"({flops / out['fused'][0] / 1e6:.1f} TFLOP/s = {flops / out['fused'][0] / 1e6 / 157.3:.3f} of the fp32-MFMA peak); indices equal: {bool(torch.equal(out['matrix'][1], out['fused'][1]))}")
+PY
+  cat "$OUT/knn_bench.txt" ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
