@@ -200,8 +200,8 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank; gloo = rehearsal of the N>1 path with CPU-tensor collectives")
     ap.add_argument("--att-leaves", default=None,
-                    help="summation tree of the attention's key dimension (enum pdsc_att_leaves): canonical (module default: a pair's bits do "
-                         "not depend on its batch) | per_launch | legacy | an int >= 2")
+                    help="summation tree of the attention's key dimension (enum pdsc_att_leaves): canonical (a pair's bits do not depend on "
+                         "its batch) | per_launch | an int 2..8 (default: the module's)")
     ap.add_argument("--latency", action="store_true",
                     help="the number an UNCHANGED caller sees (evaluation/test_3DMatch.py:53-64): one forward at a time on the current stream, "
                          "its pose and labels copied to the host before the next call (forces --in-flight 1, no graphs)")
@@ -237,14 +237,14 @@ def parse():
 
 
 def attention_plan(lib, B, N, leaves):
-    """(key split = workgroups per query block, leaves per pair) of the attention launches of this run."""
-    mode = {"legacy": -1, "per_launch": 0, "canonical": 1}.get(leaves, leaves)
-    if mode == -1:
+    """(key split = workgroups per query block, partials per query the layer kernel merges) of the attention launches of this run."""
+    mode = {"per_launch": 0, "canonical": 1}.get(leaves, leaves)
+    if mode == 0:
         ns = int(lib.pdsc_attention_split_default_split(B, N))
-        return {"key_split": ns, "leaves": ns, "merge": "fused layer kernel (or combine launch above 8 splits)"}
+        return {"key_split": ns, "leaves": ns, "form": "key split planned per launch (bits depend on the batch)"}
     ns, nl = C.c_int(), C.c_int()
-    lib.pdsc_attention_merged_plan(B, N, int(mode), C.byref(ns), C.byref(nl))
-    return {"key_split": ns.value, "leaves": nl.value, "merge": "in the attention launch (ticket per 32-query tile)"}
+    lib.pdsc_attention_leaf_plan(B, N, int(mode), C.byref(ns), C.byref(nl))
+    return {"key_split": ns.value, "leaves": nl.value, "form": "leaves that depend on N alone (bits independent of the batch)"}
 
 
 def fp32_att(args):
@@ -496,10 +496,10 @@ def main():
     # and is bound by HBM: per point it reads the key-split partials (ns x (512 + 8) B) and the residual row (512 B) and
     # writes featB (512 B), the Q rows (512 B) and its share of the K/V tile image (32 KiB / 32)
     lay_h3 = (not fp32_att(args)) and model.layer_gemm == "h3"      # (since r03 the H3 arithmetic has its own kernels at every size)
-    # (merged attention -- every att_leaves mode but "legacy", H3 layer kernel: ONE merged message per point)
+    # (leaf form: one partial per LEAF)
     lay_ns = int(lib.pdsc_attention_split_default_split(B, N))
-    if lay_h3 and model.att_leaves != "legacy" and not (model.att_leaves == "per_launch" and lay_ns == 1):
-        lay_ns = 1
+    if lay_h3 and model.att_leaves != "per_launch":
+        lay_ns = attention_plan(lib, B, N, model.att_leaves)["leaves"]
     lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 32768 / 32.0) * N * B
     lay_gbs = lay_bytes / lay_avg / 1e9 if lay_n else None
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch

@@ -64,17 +64,15 @@ typedef struct pdsc_config {
 
 /* How the N keys of a query are summed (models/PointDSC.py:41-42: one softmax-weighted sum per query) when the key range is
  * cut so that one pair can fill the chip.  A LEAF is a run of 32-key tiles accumulated from a fresh online-softmax state;
- * leaves are merged in leaf order (weights exp2(m_leaf - max m), one reciprocal) by the last wavefront to finish a query
- * tile, inside the attention launch (a ticket per tile, no waiting), and the fused layer kernel reads ONE merged message.
- *   LEGACY     (-1): r01-r04 hand-off -- one partial per key split left in the workspace, merged by the layer kernel while it
- *                    loads (or by a combine launch above 8 splits).  Same bits as PER_LAUNCH; A/B record.
- *   PER_LAUNCH ( 0): one leaf per key split, the split planned per launch from (batch, N): the bits of a pair depend on how
- *                    many pairs share its launch (both within the contract; the r01-r04 results).
- *   CANONICAL  ( 1): pdsc_attention_leaf_count(N) leaves, a function of N alone; the launch plan only decides WHICH workgroup
- *                    computes a leaf (a divisor of the leaf count), never the arithmetic -- a pair's result is bit-identical at
- *                    every batch size, on one GPU or sharded over eight.                      [default of the Python module]
- *   n >= 2         : n leaves (tuning). */
-enum pdsc_att_leaves { PDSC_LEAVES_LEGACY = -1, PDSC_LEAVES_PER_LAUNCH = 0, PDSC_LEAVES_CANONICAL = 1 };
+ * the fused layer kernel merges the partials (O, m, l) in order (weights exp2(m - max m), one reciprocal) while it loads them.
+ *   PER_LAUNCH (0): one partial per key split, the split planned per launch from (batch, N): the bits of a pair depend on how
+ *                   many pairs share its launch (all within the contract; the r01-r04 results).
+ *   CANONICAL  (1): pdsc_attention_leaf_count(N) leaves, a function of N alone; the launch plan only decides WHICH workgroup
+ *                   computes a leaf (the key split is a divisor of the leaf count), never the arithmetic -- a pair's result is
+ *                   bit-identical at every batch size, on one GPU or sharded over eight.  Split-precision attention with the
+ *                   H3 layer kernel only (the other arithmetic modes keep PER_LAUNCH).        [default of the Python module]
+ *   2 .. 8        : that many leaves (tuning). */
+enum pdsc_att_leaves { PDSC_LEAVES_PER_LAUNCH = 0, PDSC_LEAVES_CANONICAL = 1 };
 
 /* Arithmetic of the point-wise GEMMs whose results land on the residual stream (fc1..fc3 of fc_message, PointCN;
  * models/PointDSC.py:12-23,56-61) inside the fused layer kernel (split-precision attention modes).  H3 runs on
@@ -312,11 +310,11 @@ size_t pdsc_split_kv_bytes(int bs, int N);
 int    pdsc_pack_qkv_split(const float* qkv, void* q_split, void* kv_tiles, int bs, int N, void* stream);
 size_t pdsc_attention_split_scratch_bytes(int bs, int N, int nsplit);
 int    pdsc_attention_split_default_split(int bs, int N);
-/* merged form (enum pdsc_att_leaves): canonical leaf count of N; the plan (key split = workgroups per query block, leaves) the
- * forward uses for (bs, N, leaves_mode >= PDSC_LEAVES_PER_LAUNCH); bytes of its scratch (leaf partials + merged message + tickets) */
+/* leaf form (enum pdsc_att_leaves >= PDSC_LEAVES_CANONICAL): canonical leaf count of N; the plan (key split = workgroups per query
+ * block, leaves per pair) the forward uses for (bs, N, leaves_mode); bytes of its scratch (the leaf partials) */
 int    pdsc_attention_leaf_count(int N);
-int    pdsc_attention_merged_plan(int bs, int N, int leaves_mode, int* nsplit, int* nleaf);
-size_t pdsc_attention_merged_scratch_bytes(int bs, int N, int leaves_mode);
+int    pdsc_attention_leaf_plan(int bs, int N, int leaves_mode, int* nsplit, int* nleaf);
+size_t pdsc_attention_leaf_scratch_bytes(int bs, int N, int leaves_mode);
 int    pdsc_sc_attention_split(const void* q_split, const void* kv_tiles, const float* compat, long long ld,
                                float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit,
                                void* stream);
@@ -378,9 +376,15 @@ int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, i
 /* form: 0 = the library's choice, 1 = two launches through the S x N distance matrix (Gram rows, then a selection launch),
  * 2 = fused (r05: 32 seeds per workgroup, the distances never leave the chip -- only candidates below a per-seed bound reach an
  * LDS list; needs k + 1 <= 48 and N >= 256; dist_scratch unused).  Same distance bits, same (dist, index) order: the neighbour
- * indices of the two forms are identical.  form 0 takes the fused form when bs * ceil(S / 32) >= 384 workgroups. */
-int pdsc_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx,
+ * indices of the two forms are identical.  form 0 takes the fused form when bs * ceil(S / 32) >= 384 workgroups.
+ * normed_pf (optional, fused form): the same normalised rows in point-fragment order, [bs][ceil(N / 32) * 32][128]
+ * (pdsc_normalize_confidence_pf writes both) -- the kernel then loads its column operand 1 KiB per instruction; NULL = gathered
+ * from `normed` (32 pieces of 32 bytes per instruction: 2 x slower, same results). */
+int pdsc_knn_seeds_form(const float* normed, const float* normed_pf, const int* seeds, float* dist_scratch, int* knn_idx,
                         int bs, int N, int S, int k, int form, void* stream);
+/* pdsc_normalize_confidence per pair (feat [bs][N][128] ...), additionally leaving the normalised rows in point-fragment order */
+int pdsc_normalize_confidence_pf(const float* feat, const float* h2, const float* w3, const float* b3, float* normed,
+                                 float* normed_pf, float* conf, int bs, int N, void* stream);
 
 /* ---- a-7/a-8  per-seed compatibility + power iteration ----------------------------------------
  * replaces models/PointDSC.py:257-281 and cal_leading_eigenvector (:347-358).

@@ -80,8 +80,8 @@ SIGNATURES = {
     "pdsc_attention_split_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_split_default_split": (_i, [_i, _i]),
     "pdsc_attention_leaf_count": (_i, [_i]),
-    "pdsc_attention_merged_plan": (_i, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "pdsc_attention_merged_scratch_bytes": (_sz, [_i, _i, _i]),
+    "pdsc_attention_leaf_plan": (_i, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pdsc_attention_leaf_scratch_bytes": (_sz, [_i, _i, _i]),
     "pdsc_attention_trace": (_i, [_vp]),
     "pdsc_layer_trace": (_i, [_vp]),
     "pdsc_sc_attention_split": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _sz, _i, _i, _i, _vp]),
@@ -95,7 +95,8 @@ SIGNATURES = {
     "pdsc_nms_keys_grid": (_i, [_vp, _vp, _f, _vp, _vp, _sz, _i, _i, _vp]),
     "pdsc_rank_select": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pdsc_knn_seeds": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pdsc_knn_seeds_form": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pdsc_knn_seeds_form": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pdsc_normalize_confidence_pf": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "pdsc_seed_power_iteration": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pdsc_seed_solve": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _vp]),
     "pdsc_seed_transforms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

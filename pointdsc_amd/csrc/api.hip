@@ -133,7 +133,7 @@ static bool config_ok(const pdsc_config* c) {
 #endif
     if (c->compat_format != PDSC_COMPAT_U16 && c->compat_format != PDSC_COMPAT_F32) { set_error("compat_format=%d", c->compat_format); return false; }
     if (c->layer_gemm != PDSC_LAYER_GEMM_F32 && c->layer_gemm != PDSC_LAYER_GEMM_H3) { set_error("layer_gemm=%d", c->layer_gemm); return false; }
-    if (c->att_leaves < PDSC_LEAVES_LEGACY || c->att_leaves > PDSC_ATT_MAX_LEAVES) { set_error("att_leaves=%d (enum pdsc_att_leaves, or 2..%d leaves)", c->att_leaves, PDSC_ATT_MAX_LEAVES); return false; }
+    if (c->att_leaves < PDSC_LEAVES_PER_LAUNCH || c->att_leaves > PDSC_ATT_MAX_LEAVES) { set_error("att_leaves=%d (enum pdsc_att_leaves, or 2..%d leaves)", c->att_leaves, PDSC_ATT_MAX_LEAVES); return false; }
     return true;
 }
 
@@ -229,12 +229,13 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("t64b", M * (C / 2) * f);
     {
         const size_t a32 = pdsc_attention_scratch_bytes(bs, N, 0), a16 = pdsc_attention_split_scratch_bytes(bs, N, 0);
-        const size_t amg = c->att_leaves >= PDSC_LEAVES_PER_LAUNCH ? pdsc_attention_merged_scratch_bytes(bs, N, c->att_leaves) : 0;
+        const size_t amg = c->att_leaves >= PDSC_LEAVES_CANONICAL ? pdsc_attention_leaf_scratch_bytes(bs, N, c->att_leaves) : 0;
         L.add("att_scratch", c->attention_precision == PDSC_ATT_FP32 ? a32 : (a16 > amg ? a16 : amg));
     }
     L.add("q_split", c->attention_precision != PDSC_ATT_FP32 ? pdsc_split_q_bytes(bs, N) : 0);
     L.add("kv_tiles", c->attention_precision != PDSC_ATT_FP32 ? pdsc_split_kv_bytes(bs, N) : 0);
     L.add("normed", M * C * f);
+    L.add("normed_pf", knn_seeds_uses_fused(bs, N, S, k) ? Mpf * C * f : 0);      // the fused kNN's B operand (point-fragment order)
     L.add("h1", M * 32 * f);
     L.add("h2", M * 32 * f);
     L.add("conf", M * f);
@@ -368,7 +369,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_REQUIRE(n_min > (cfg->k < N - 1 ? cfg->k : N - 1), "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has no "
                      "more than k=%d: the reference clamps k per pair (k = min(k, num_corr - 1)); run such a pair in its own call",
                      n_min, cfg->k < N - 1 ? cfg->k : N - 1);
-        PDSC_REQUIRE(cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH || (n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
+        PDSC_REQUIRE(cfg->att_leaves >= PDSC_LEAVES_CANONICAL || (n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
                      "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
                      "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
     }
@@ -450,22 +451,19 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const int ws_head = gemm == PDSC_LAYER_GEMM_H3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD;
         // H3 + fused merge: the hand-offs attention -> layer kernel -> next layer kernel in point-fragment order (split_layout.h);
         // A/B knob PDSC_LAYER_PF = 0: plain rows
-        // merged form (r05, enum pdsc_att_leaves): the attention launch merges its own leaves (tickets) and the layer kernel reads ONE
-        // message in point-fragment order; H3 layer kernel only (the other layer kernels keep the legacy hand-off)
+        // leaf form (r05, enum pdsc_att_leaves): the key range cut into leaves that depend on N alone; the H3 layer kernel merges the
+        // leaf partials exactly as it merges key-split partials (the other layer kernels keep the per-launch key split)
         const bool pf_ok = frag && gemm == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_PF", 1) != 0 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
-        int mg_ns = 0, mg_leaves = 0, mg_nw = 0;
-        if (cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH) merged_plan(bs, N, cfg->att_leaves, &mg_nw, &mg_ns, &mg_leaves);
-        // (per-launch leaves with a single key split: the legacy un-split launch already writes the normalised rows -- its bits, kept)
-        const bool merged = pf_ok && cfg->att_leaves >= PDSC_LEAVES_PER_LAUNCH && (mg_leaves > 1 || cfg->att_leaves != PDSC_LEAVES_PER_LAUNCH) &&
-                            mg_leaves <= PDSC_ATT_MAX_LEAVES &&
-                            (!nvalid || (n_min + 31) / 32 >= mg_leaves);
-        if (nvalid && !merged)
+        int lf_ns = 0, lf_leaves = 0, lf_nw = 0;
+        if (cfg->att_leaves >= PDSC_LEAVES_CANONICAL) leaf_plan(bs, N, cfg->att_leaves, &lf_nw, &lf_ns, &lf_leaves);
+        const bool leaves = pf_ok && cfg->att_leaves >= PDSC_LEAVES_CANONICAL && (!nvalid || (n_min + 31) / 32 >= lf_leaves);
+        if (nvalid && !leaves)
             PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
                          "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
                          "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
-        const bool pf = merged || (pf_ok && fuse_merge);
-        if (merged) PDSC_TRY(attention_merged_reset(att_scratch, bs, N, cfg->att_leaves, hst));
-        const float *mg_msg = nullptr, *mg_ml = nullptr;
+        const bool pf = leaves || (pf_ok && fuse_merge);
+        const float* lf_o = (const float*)att_scratch;
+        const float* lf_ml = lf_o + (size_t)bs * lf_leaves * Npad * C;
         if (x3_gemm)
             PDSC_TRY(pdsc_layer_fused_x3(nullptr, nullptr, nullptr, 0, 0, nullptr, featA, nullptr, featB, nullptr, q_split, kv_tiles,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, WS(PDSC_W_PCN_W, 0), W(PDSC_W_PCN_B, 0),
@@ -482,9 +480,9 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                             W(PDSC_W_QKV_W, 0), W(PDSC_W_QKV_B, 0), WS(PDSC_W_QKV_W, 0), bs, N, stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            if (merged)
-                PDSC_TRY(launch_attention_merged(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, att_scratch,
-                                                 att_bytes, bs, N, cfg->att_leaves, nvalid, n_min, &mg_msg, &mg_ml, hst));
+            if (leaves)
+                PDSC_TRY(launch_attention_leaves(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, att_scratch,
+                                                 att_bytes, bs, N, cfg->att_leaves, nvalid, n_min, hst));
             else if (pf)
                 PDSC_TRY(launch_attention_split_ex(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, nullptr,
                                                    att_scratch, att_bytes, bs, N, ns, PDSC_PARTIALS_PF, nvalid, hst));
@@ -492,7 +490,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                 PDSC_TRY(attention_split(fuse_merge ? nullptr : msg, ns));
             const bool last = i + 1 == cfg->num_layers;
             if (pf)
-                PDSC_TRY(pdsc_layer_fused_frag_io(nullptr, merged ? mg_msg : part_o, merged ? mg_ml : part_ml, merged ? 1 : ns, Npad, cur, nullptr, last ? featA : nullptr,
+                PDSC_TRY(pdsc_layer_fused_frag_io(nullptr, leaves ? lf_o : part_o, leaves ? lf_ml : part_ml, leaves ? lf_leaves : ns, Npad, cur, nullptr, last ? featA : nullptr,
                                                   last ? nullptr : nxt, last ? nullptr : q_split, last ? nullptr : kv_tiles,
                                                   WS(ws_tail, i), last ? nullptr : WS(ws_head, i + 1), gemm,
                                                   PDSC_IO_PARTIALS_PF | PDSC_IO_RES_PF | (last ? 0 : PDSC_IO_FEATB_PF), bs, N, stream));
@@ -575,7 +573,13 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_TRY(pdsc_linear(featA, C, W(PDSC_W_CLS1_W, 0), W(PDSC_W_CLS1_B, 0), nullptr, 0, h1, 32, M, C, 32, 1, stream));
         PDSC_TRY(pdsc_linear(h1, 32, W(PDSC_W_CLS2_W, 0), W(PDSC_W_CLS2_B, 0), nullptr, 0, h2, 32, M, 32, 32, 1, stream));
     }
-    PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
+    // (mode 0, large batches: the seeds' kNN runs fused -- knn_fused_kernel -- and takes the normalised rows in point-fragment order too)
+    const bool knn_fused = mode == 0 && knn_seeds_uses_fused(bs, N, S, k);
+    float* normed_pf = knn_fused ? F("normed_pf") : nullptr;
+    if (knn_fused)
+        PDSC_TRY(launch_normalize_conf_pf(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, normed_pf, conf, bs, N, hst));
+    else
+        PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
     if (mode == 0) {
         PDSC_TRY(launch_nms_keys_grid(src, conf, cfg->nms_radius, keys, ws + L.find("nms_ws"), pdsc_nms_workspace_bytes(bs, N), bs, N, nvalid, hst));
         PDSC_TRY(launch_rank_select(keys, seeds, bs, N, S, nvalid, svalid, hst));
@@ -585,7 +589,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_TRY(pdsc_rank_select(conf, seeds, bs, N, S, stream));
     }
     // Step 3 & 4 (:182 -> :234-336): per-seed hypotheses, scoring, best
-    PDSC_TRY(launch_knn_seeds(normed, seeds, knn_dist, knn_idx, bs, N, S, k, nvalid, hst));
+    PDSC_TRY(launch_knn_seeds_form(normed, normed_pf, seeds, knn_dist, knn_idx, bs, N, S, k, nvalid, knn_fused ? 2 : 1, hst));
     if (mode == 1 && bs > 1) {
         // validation forward: the early exit is taken over the seeds of ALL pairs of the batch (one torch.allclose over
         // [bs*S, k]) -- the per-pair masks are AND-ed before the iterate is chosen, so the two steps stay apart

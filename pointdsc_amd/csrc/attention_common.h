@@ -31,11 +31,8 @@ struct AttSplitArgs {
     int part_frag;               // key-split partials in point-fragment order (split_layout.h: PF), straight from the accumulators
     const int* nvalid;           // ragged batches: [bs] correspondences per pair (<= N), or NULL: every pair has N
     long long* trace;            // diagnostics (pdsc_attention_trace): [workgroup][wave][8] cycle sums, else NULL
-    // merged form (sc_attention_split_kernel<..., MG = true>): part_o / part_ml are [bs][nleaf][Npad][..] (point-fragment order)
-    int nleaf;                   // leaves per pair (>= nsplit; <= the tile count of the shortest pair)
-    float* merged_o;             // [bs][Npad][128] the normalised message, point-fragment order
-    float* merged_ml;            // [bs][Npad][2]   (0, 1): the layer kernel reads the message as ONE already merged partial
-    unsigned int* tickets;       // [bs][Npad / 32] arrivals per 32-query tile; zero at launch, left zero by the merging wave
+    // leaf form (sc_attention_split_kernel<..., MG = true>): part_o / part_ml are [bs][nleaf][Npad][..] (point-fragment order)
+    int nleaf;                   // leaves per pair (a multiple of nsplit; <= the tile count of the shortest pair)
 };
 
 int launch_attention_wide(const AttSplitArgs& a, unsigned grid, hipStream_t st);

@@ -53,7 +53,6 @@ __device__ __forceinline__ f32x16 scale_acc(f32x16 o, float alpha) {
     return o;
 }
 
-constexpr int ATT_MAX_LEAVES = PDSC_ATT_MAX_LEAVES;         // merged form: leaves per pair the merging wavefront is unrolled for
 constexpr float ATT_RESCALE_THR = 8.0f;   // running max is only moved when a logit exceeds it by 2^8 (log2 domain)
 constexpr int SPL_K_BYTES = 2 * SPL_K_PLANE;    // Kh | Kl   16 KiB
 constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
@@ -82,14 +81,16 @@ constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
 // previous item's last tiles.  Point-fragment partials only: that epilogue needs no LDS, the stages stay live across items.
 // PEEL: the split's last tile runs as peeled tail code (see tile_iteration); false = the r01-r03 straight-line loop (A/B record,
 // experiments builds: PDSC_ATT_PEEL=0)
-// MG (r05, merged form): the key range of a pair is cut into a.nleaf LEAVES (a function of the pair's own tile count and of
-// a.nleaf only -- with the canonical leaf count of attention_leaf_count(N) a function of N alone); every leaf is accumulated from a
-// fresh online-softmax state, whoever computes it, and leaves a partial (O, m, l) in point-fragment order; a workgroup owns the
-// consecutive leaves [sp C / nsplit, (sp + 1) C / nsplit) and streams through them without a break in its K / V / compat
-// pipeline.  The LAST wave to finish among the nsplit waves that share a 32-query tile (a ticket per tile, no waiting anywhere)
-// merges all C partials in leaf order with the arithmetic of merge_partials_finish and writes the normalised message: the
-// layer kernel loads 512 B per point instead of nsplit x 528 B, no combine launch for large splits, and with canonical leaves the
-// bits of a pair do not depend on how many pairs share its launch.
+// MG (r05, leaf form): the key range of a pair is cut into a.nleaf LEAVES (a function of the pair's own tile count and of a.nleaf
+// only -- with the canonical leaf count of attention_leaf_count(N) a function of N alone); every leaf is accumulated from a fresh
+// online-softmax state, whoever computes it, and leaves a partial (O, m, l) in point-fragment order in part_o / part_ml
+// [pair][leaf][Npad]; a workgroup owns the consecutive leaves [sp C / nsplit, (sp + 1) C / nsplit) and streams through them without
+// a break in its K / V / compat pipeline (a leaf that ends inside its range costs 17 store instructions per wave and a reset of the
+// accumulators).  The fused layer kernel merges the C leaf partials in leaf order while it loads them (merge_partials.h), exactly as
+// it merges key-split partials: with canonical leaves the bits of a pair do not depend on how many pairs share its launch.
+// (Measured and dropped, profiles/r05_b_ab_leaves_in_kernel_merge.txt: merging inside this launch -- the last wave to finish a
+//  query tile, found through a ticket, loads the other partials past the caches -- puts 20-30 us of dependent memory round trips at
+//  the end of every workgroup: +14 % per launch at 32 pairs of N = 5000, against -5 % for the layer launch that then loads one message.)
 template <int NW, int CM = 0, bool TRACE = false, bool PS = false, bool PEEL = true, bool MG = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
     constexpr bool C16 = CM == 1, CREG = CM == 2;
@@ -314,31 +315,22 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     };
 
-    // MG: the partial of a finished leaf -> part_o / part_ml [pair][leaf][Npad] in point-fragment order, written THROUGH the
-    // caches (sc0 sc1): the wave that merges this query tile may run on another XCD, behind another L2.  The stores of a leaf that
-    // ends inside the workgroup's range leave at the top of the next loop iteration (after its barrier, like the persistent form's):
-    // a whole tile of time before the next s_waitcnt vmcnt(0) meets them.
-    __amdgpu_buffer_rsrc_t po_rsrc = kv_rsrc, pm_rsrc = kv_rsrc;
-    if constexpr (MG) {
-        po_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part_o + (size_t)b * a.nleaf * a.Npad * PDSC_CHANNELS), 0,
-                                                    (int)((unsigned)a.nleaf * (unsigned)a.Npad * (unsigned)(PDSC_CHANNELS * 4)), 0x00020000);
-        pm_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part_ml + (size_t)b * a.nleaf * a.Npad * 2), 0,
-                                                    (int)((unsigned)a.nleaf * (unsigned)a.Npad * 8u), 0x00020000);
-    }
-    const unsigned q0w = (unsigned)(qb * (NW * 32) + wave * 32);          // first query of this wave inside the pair
-    constexpr int AUX_THROUGH = 1 | 16;                                     // sc0 sc1
+    // MG: the partial of a finished leaf -> part_o / part_ml [pair][leaf][Npad] in point-fragment order (the accumulator registers of
+    // lane (query l31, half h) ARE the 16-byte pieces the fused layer kernel's lane loads: 1 KiB of consecutive memory per store
+    // instruction).  The stores of a leaf that ends inside the workgroup's range leave at the top of the next loop iteration (after
+    // its barrier, like the persistent form's): a whole tile of time before the next s_waitcnt vmcnt(0) meets them.
+    const int q0w = qb * (NW * 32) + wave * 32;                       // first query of this wave inside the pair
     auto leaf_store = [&](int lf, float m_st, float l_st) {
-        const unsigned base = ((unsigned)lf * (unsigned)a.Npad + q0w) * (unsigned)(PDSC_CHANNELS * 4) + lane16;
+        const size_t slot = ((size_t)b * a.nleaf + lf) * a.Npad + q0w;
+        float* base = a.part_o + slot * PDSC_CHANNELS + lane * 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]}),
-                                                       po_rsrc, base + 1024u * (4 * c + g), 0, AUX_THROUGH);
+                *reinterpret_cast<f32x4*>(base + pf_offset_floats(4 * c + g)) = f32x4{o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]};
         if (h == 0) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m_st), __float_as_uint(l_st)}, pm_rsrc,
-                                                  ((unsigned)lf * (unsigned)a.Npad + q0w + (unsigned)l31) * 8u, 0, AUX_THROUGH);
+            a.part_ml[(slot + l31) * 2 + 0] = m_st;
+            a.part_ml[(slot + l31) * 2 + 1] = l_st;
         }
     };
     int leaf_prev = 0;                          // MG: the leaf whose partial is pending (m_prev, l_prev, pend)
@@ -683,109 +675,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int q0 = qb * (NW * 32) + wave * 32;
     if constexpr (MG) {
-        float* const mbase = a.merged_o + ((size_t)b * a.Npad + q0) * PDSC_CHANNELS + lane * 4;
-        auto store_message = [&](const f32x16 (&acc)[4], float rden) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(mbase + pf_offset_floats(4 * c + g)) =
-                        f32x4{acc[c][4 * g] * rden, acc[c][4 * g + 1] * rden, acc[c][4 * g + 2] * rden, acc[c][4 * g + 3] * rden};
-            if (h == 0) {
-                // the layer kernel's one-partial merge (layer_h3.hip, NS = 1): w = exp2(0 - 0) = 1, den = fma(1, 1, 0) = 1, x = fma(v, 1, 0) * 1
-                // -- the message passes through bit for bit
-                float* ml = a.merged_ml + ((size_t)b * a.Npad + q0 + l31) * 2;
-                ml[0] = 0.f;
-                ml[1] = 1.f;
-            }
-        };
-        if (a.nleaf == 1) {                      // one leaf = one workgroup per query block: nothing to merge (fma(o, 1, 0) * (1 / fma(l, 1, 0)))
-            store_message(o, 1.0f / l_tot);
-            return;
-        }
-        leaf_store(leaf, m_run, l_tot);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partials are at the memory side before it takes its ticket
-        unsigned int* const tk = a.tickets + (size_t)b * (a.Npad >> 5) + (q0 >> 5);
-        unsigned int arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived + 1u != (unsigned)a.nsplit) return;        // somebody else finishes later and merges
-        if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
-        // ---- the last of the nsplit waves of this query tile: merge ALL leaves in leaf order (merge_partials_finish's arithmetic:
-        //      w_c = exp2(m_c - max m), den = fma chain of l_c w_c, acc = fma chain of O_c w_c, message = acc * (1 / den)) from the
-        //      partials as they lie in memory (its own included), loads past the caches
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const int C = a.nleaf;                       // <= ATT_MAX_LEAVES (launcher)
-        const unsigned mlo = (q0w + (unsigned)l31) * 8u, mls = (unsigned)a.Npad * 8u;
-        const unsigned pvo = q0w * (unsigned)(PDSC_CHANNELS * 4) + lane16, pvs = (unsigned)a.Npad * (unsigned)(PDSC_CHANNELS * 4);
-        // The merge is a chain of memory round trips (the partials lie at the memory side), so everything is asked for as early as
-        // the registers allow: all (m, l) pairs and the first MD half-leaves at once, then a continuous stream -- two passes of 64
-        // channels over the leaves, every consumed slot refilled at once with the stream's next half-leaf (the second pass starts
-        // arriving while the first is still being summed).  Loads are unconditional (indices clamped; a few are wasted at the ends),
-        // only the arithmetic is guarded, and every loop is unrolled to ATT_MAX_LEAVES: the compiler counts the loads in flight
-        // exactly and every register index is a constant.
-        constexpr int MD = 3, RMAX = ATT_MAX_LEAVES / MD;
-        static_assert(ATT_MAX_LEAVES % MD == 0, "whole rounds");
-        const int R = (C + MD - 1) / MD;             // rounds per pass
-        u32x2 mlv[ATT_MAX_LEAVES];
-#pragma unroll
-        for (int c = 0; c < ATT_MAX_LEAVES; ++c) mlv[c] = __builtin_amdgcn_raw_buffer_load_b64(pm_rsrc, mlo + (unsigned)min(c, C - 1) * mls, 0, AUX_THROUGH);
-        u32x4 buf[MD][8];
-        auto issue = [&](int d, int pass, int c) {
-            const unsigned off = pvo + (unsigned)min(c, C - 1) * pvs + 8192u * (unsigned)pass;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) buf[d][i] = __builtin_amdgcn_raw_buffer_load_b128(po_rsrc, off + 1024u * i, 0, AUX_THROUGH);
-        };
-#pragma unroll
-        for (int d = 0; d < MD; ++d) issue(d, 0, d);
-        float wv[ATT_MAX_LEAVES];
-        float mmax = __uint_as_float(mlv[0][0]);
-#pragma unroll
-        for (int c = 1; c < ATT_MAX_LEAVES; ++c) mmax = fmaxf(mmax, __uint_as_float(mlv[c][0]));      // (repeats of the last leaf do not move it)
-        float den = 0.f;
-#pragma unroll
-        for (int c = 0; c < ATT_MAX_LEAVES; ++c) {
-            wv[c] = __builtin_amdgcn_exp2f(__uint_as_float(mlv[c][0]) - mmax);
-            if (c < C) den = fmaf(__uint_as_float(mlv[c][1]), wv[c], den);
-        }
-        const float rden = 1.0f / den;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            f32x4 acc[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-                if (r < R) {                              // (wave-uniform)
-#pragma unroll
-                    for (int d = 0; d < MD; ++d) {
-                        const int c = r * MD + d;
-                        if (c < C) {
-                            const float w = wv[c];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const f32x4 v = __builtin_bit_cast(f32x4, buf[d][i]);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(v[e], w, acc[i][e]);
-                            }
-                        }
-                        // the slot's next half-leaf: leaf c + MD of this pass, or -- in the pass's last round -- leaf d of the next pass
-                        const bool more = r + 1 < R;
-                        if (more || pass == 0) issue(d, more ? pass : 1, more ? c + MD : d);
-                        __builtin_amdgcn_sched_barrier(0);       // (fully unrolled: left alone the scheduler hoists every load of the stream to the top)
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<f32x4*>(mbase + pf_offset_floats(8 * pass + i)) = f32x4{acc[i][0] * rden, acc[i][1] * rden, acc[i][2] * rden, acc[i][3] * rden};
-        }
-        if (h == 0) {
-            float* ml = a.merged_ml + ((size_t)b * a.Npad + q0 + l31) * 2;
-            ml[0] = 0.f;
-            ml[1] = 1.f;
-        }
+        leaf_store(leaf, m_run, l_tot);          // the last leaf of this workgroup's range (lanes past N: copies of query N-1, the tile's padding)
         return;
     }
     if (a.nsplit != 1 && a.part_frag) {
@@ -934,29 +824,29 @@ static void split_plan(int bs, int N, int* nw_out, int* nsplit_out) {
     *nsplit_out = force_ns > 0 ? (force_ns < tiles ? force_ns : tiles) : best;
 }
 
-// ---- merged form: leaves and plan -------------------------------------------------------------------------------------
+// ---- leaf form: leaves and plan ----------------------------------------------------------------------------------------
 // Canonical leaf count: a function of N ALONE (never of the batch), so that a pair's summation tree -- every leaf from a fresh
-// online-softmax state, leaves merged in leaf order -- and hence its bits do not depend on how many pairs share the launch.
-// 12 = the finest key split the per-launch planner ever asked for at these sizes (one pair of N = 5000: 12, two: 6, four: 3,
-// sixteen: 4, thirty-two: 2 -- all divisors), leaves of >= 4 tiles.
+// online-softmax state, leaves merged in leaf order by the layer kernel -- and hence its bits do not depend on how many pairs share
+// the launch.  At most MERGE_MAX_SPLIT_H3 = 8 (what the layer kernel merges while loading), leaves of at least 4 tiles:
+//   N <= 1504 (< 48 tiles): as many leaves as the per-launch planner's finest split for one pair (N = 1000: 8);
+//   larger N: 4 -- every leaf partial is 528 B per point that the attention writes and the layer launch reads back, whatever the
+//   batch: at 32 pairs of N = 5000 the price of 4 leaves (two per workgroup) is measured in profiles/r05_*ab_leaves*.txt.
 int attention_leaf_count(int N) {
     const int t = spl_num_tiles(N);
-    return t >= 48 ? 12 : t >= 32 ? 8 : t >= 16 ? 4 : t >= 8 ? 2 : 1;
+    return t >= 48 ? 4 : t >= 32 ? 8 : t >= 16 ? 4 : t >= 8 ? 2 : 1;
 }
 
-// leaves_mode (pdsc_config.att_leaves): PDSC_LEAVES_PER_LAUNCH = one leaf per key split (the per-launch plan's arithmetic, the
-// r01-r04 bits); PDSC_LEAVES_CANONICAL = attention_leaf_count(N) leaves, the key split a divisor of it; >= 2: that many leaves (tuning)
-void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out) {
+// leaves_mode (pdsc_config.att_leaves): PDSC_LEAVES_CANONICAL = attention_leaf_count(N) leaves, the key split a divisor of it;
+// >= 2: that many leaves (tuning, at most PDSC_ATT_MAX_LEAVES).  (PDSC_LEAVES_PER_LAUNCH does not come here: it is the key-split form.)
+void leaf_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out) {
     int nw, ns;
     split_plan(bs, N, &nw, &ns);
-    if (leaves_mode == PDSC_LEAVES_PER_LAUNCH) { *nw_out = nw; *nsplit_out = ns; *nleaf_out = ns; return; }
     const int tiles = spl_num_tiles(N);
     int C = leaves_mode == PDSC_LEAVES_CANONICAL ? attention_leaf_count(N) : leaves_mode;
     if (C > tiles) C = tiles;
-    if (C > ATT_MAX_LEAVES) C = ATT_MAX_LEAVES;
+    if (C > PDSC_ATT_MAX_LEAVES) C = PDSC_ATT_MAX_LEAVES;
     if (C < 1) C = 1;
     // the per-launch cost model over the divisors of C; a leaf that ends inside a workgroup's range costs about a third of a tile
-    // (its partial leaves through the caches and is read back by the merging wave)
     const int nq = ceil_div(N, nw * 32), slots = nw == 8 ? 256 : 512;
     int best = 1;
     double best_cost = 1e30;
@@ -970,61 +860,46 @@ void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, i
     *nw_out = nw; *nsplit_out = best; *nleaf_out = C;
 }
 
-static size_t merged_scratch_bytes(int bs, int N, int nleaf) {
-    const size_t Npad = (size_t)round_up(N, 256);
-    return (size_t)bs * nleaf * Npad * (PDSC_CHANNELS + 2) * sizeof(float) + (size_t)bs * Npad * (PDSC_CHANNELS + 2) * sizeof(float) +
-           (size_t)bs * (Npad / 32) * sizeof(unsigned int) + 256;
-}
-
 }  // namespace pdsc
 
 using namespace pdsc;
 
 extern "C" int pdsc_attention_leaf_count(int N) { return N > 0 ? attention_leaf_count(N) : -1; }
 
-extern "C" int pdsc_attention_merged_plan(int bs, int N, int leaves_mode, int* nsplit, int* nleaf) {
-    PDSC_REQUIRE(bs > 0 && N > 0 && leaves_mode >= PDSC_LEAVES_PER_LAUNCH && nsplit && nleaf, "pdsc_attention_merged_plan: bs=%d N=%d leaves_mode=%d", bs, N, leaves_mode);
+extern "C" int pdsc_attention_leaf_plan(int bs, int N, int leaves_mode, int* nsplit, int* nleaf) {
+    PDSC_REQUIRE(bs > 0 && N > 0 && leaves_mode >= PDSC_LEAVES_CANONICAL && leaves_mode <= PDSC_ATT_MAX_LEAVES && nsplit && nleaf,
+                 "pdsc_attention_leaf_plan: bs=%d N=%d leaves_mode=%d", bs, N, leaves_mode);
     int nw;
-    merged_plan(bs, N, leaves_mode, &nw, nsplit, nleaf);
+    leaf_plan(bs, N, leaves_mode, &nw, nsplit, nleaf);
     return PDSC_OK;
 }
 
-extern "C" size_t pdsc_attention_merged_scratch_bytes(int bs, int N, int leaves_mode) {
-    if (bs <= 0 || N <= 0 || leaves_mode < PDSC_LEAVES_PER_LAUNCH) return 0;
+extern "C" size_t pdsc_attention_leaf_scratch_bytes(int bs, int N, int leaves_mode) {
+    if (bs <= 0 || N <= 0 || leaves_mode < PDSC_LEAVES_CANONICAL) return 0;
     int nw, ns, C;
-    merged_plan(bs, N, leaves_mode, &nw, &ns, &C);
-    return merged_scratch_bytes(bs, N, C);
+    leaf_plan(bs, N, leaves_mode, &nw, &ns, &C);
+    return (size_t)bs * C * round_up(N, 256) * (PDSC_CHANNELS + 2) * sizeof(float);
 }
 
-// the tickets of the merged form must be zero before a forward's first attention launch (every merging wave leaves its ticket
-// zero again, so once per forward is enough -- and repairs whatever an aborted launch left behind)
-int pdsc::attention_merged_reset(void* scratch, int bs, int N, int leaves_mode, hipStream_t st) {
-    int nw, ns, C;
-    merged_plan(bs, N, leaves_mode, &nw, &ns, &C);
-    const size_t Npad = (size_t)round_up(N, 256);
-    float* part_o = (float*)scratch;
-    float* merged_ml = part_o + (size_t)bs * C * Npad * (PDSC_CHANNELS + 2) + (size_t)bs * Npad * PDSC_CHANNELS;
-    return launch_fill_u32((unsigned int*)(merged_ml + (size_t)bs * Npad * 2), 0u, (size_t)bs * (Npad / 32), st);
-}
-
-// One attention launch in the merged form.  message / message_ml: where the layer kernel finds the merged message (inside scratch).
-int pdsc::launch_attention_merged(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
+// One attention launch in the leaf form: C leaf partials per query in scratch ([bs][C][Npad][128] then [bs][C][Npad][2], point-
+// fragment order) for the H3 layer kernel to merge (C <= MERGE_MAX_SPLIT_H3).
+int pdsc::launch_attention_leaves(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
                                   void* scratch, size_t scratch_bytes, int bs, int N, int leaves_mode, const int* nvalid, int n_min,
-                                  const float** message, const float** message_ml, hipStream_t st) {
-    PDSC_REQUIRE(q_split && kv_tiles && compat && scratch && message && message_ml, "pdsc_sc_attention_merged: null pointer");
-    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_merged: bs=%d N=%d", bs, N);
-    PDSC_REQUIRE(compat_format == PDSC_COMPAT_F32 || compat_format == PDSC_COMPAT_U16, "pdsc_sc_attention_merged: compat_format=%d", compat_format);
+                                  hipStream_t st) {
+    PDSC_REQUIRE(q_split && kv_tiles && compat && scratch, "pdsc_sc_attention_leaves: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention_leaves: bs=%d N=%d", bs, N);
+    PDSC_REQUIRE(compat_format == PDSC_COMPAT_F32 || compat_format == PDSC_COMPAT_U16, "pdsc_sc_attention_leaves: compat_format=%d", compat_format);
     const bool c16 = compat_format == PDSC_COMPAT_U16;
     PDSC_REQUIRE(ld >= round_up(N, SPL_BK) && ld % (c16 ? 8 : 4) == 0,
-                 "pdsc_sc_attention_merged: ld=%lld must be a multiple of %d and >= N rounded up to 32", ld, c16 ? 8 : 4);
+                 "pdsc_sc_attention_leaves: ld=%lld must be a multiple of %d and >= N rounded up to 32", ld, c16 ? 8 : 4);
     int nw, ns, C;
-    merged_plan(bs, N, leaves_mode, &nw, &ns, &C);
+    leaf_plan(bs, N, leaves_mode, &nw, &ns, &C);
     // ragged batches: every pair cuts ITS OWN tiles into C leaves -- the shortest pair needs at least C of them
-    PDSC_REQUIRE(!nvalid || (n_min + 31) / 32 >= C, "pdsc_sc_attention_merged: the shortest pair (%d correspondences) has fewer 32-key tiles "
+    PDSC_REQUIRE(!nvalid || (n_min + 31) / 32 >= C, "pdsc_sc_attention_leaves: the shortest pair (%d correspondences) has fewer 32-key tiles "
                  "than the %d leaves planned for bs=%d, N=%d", n_min, C, bs, N);
-    const size_t need = merged_scratch_bytes(bs, N, C);
+    const size_t need = (size_t)bs * C * round_up(N, 256) * (PDSC_CHANNELS + 2) * sizeof(float);
     if (scratch_bytes < need) {
-        set_error("pdsc_sc_attention_merged: scratch %zu < %zu bytes", scratch_bytes, need);
+        set_error("pdsc_sc_attention_leaves: scratch %zu < %zu bytes", scratch_bytes, need);
         return PDSC_ERR_WORKSPACE;
     }
     const int tiles = spl_num_tiles(N);
@@ -1035,14 +910,9 @@ int pdsc::launch_attention_merged(const void* q_split, const void* kv_tiles, con
     a.nleaf = C;
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o + (size_t)bs * C * a.Npad * PDSC_CHANNELS;
-    a.merged_o = a.part_ml + (size_t)bs * C * a.Npad * 2;
-    a.merged_ml = a.merged_o + (size_t)bs * a.Npad * PDSC_CHANNELS;
-    a.tickets = (unsigned int*)(a.merged_ml + (size_t)bs * a.Npad * 2);
     a.nvalid = nvalid;
     a.part_frag = 1;
     a.compat_nt = c16 ? 0 : 1;
-    *message = a.merged_o;
-    *message_ml = a.merged_ml;
     const size_t lds_bytes = 2 * (size_t)(SPL_TILE_BYTES + nw * 32 * (c16 ? 64 : 128));
     const unsigned grid = (unsigned)(a.nq * ns * bs);
     a.items = (int)grid;
@@ -1050,7 +920,7 @@ int pdsc::launch_attention_merged(const void* q_split, const void* kv_tiles, con
 #define PDSC_ATT_LAUNCH_MG(NWV, CMV)                                                                                                        \
     do {                                                                                                                                    \
         rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sc_attention_split_kernel<NWV, CMV, false, false, true, true>), lds_bytes,   \
-                                "pdsc_sc_attention_merged(dynamic LDS)");                                                                   \
+                                "pdsc_sc_attention_leaves(dynamic LDS)");                                                                   \
         if (rc != PDSC_OK) return rc;                                                                                                       \
         profile_mark_begin(PDSC_PROF_ATTENTION, st);                                                                                        \
         hipLaunchKernelGGL((sc_attention_split_kernel<NWV, CMV, false, false, true, true>), dim3(grid), dim3(NWV * 64), lds_bytes, st, a);  \
@@ -1061,7 +931,7 @@ int pdsc::launch_attention_merged(const void* q_split, const void* kv_tiles, con
     else if (c16) PDSC_ATT_LAUNCH_MG(4, 1);
     else PDSC_ATT_LAUNCH_MG(4, 0);
 #undef PDSC_ATT_LAUNCH_MG
-    return check_launch("pdsc_sc_attention_merged");
+    return check_launch("pdsc_sc_attention_leaves");
 }
 
 extern "C" size_t pdsc_split_q_bytes(int bs, int N) {

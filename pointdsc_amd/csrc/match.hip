@@ -64,15 +64,33 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
         }
     }
     float best = MODE == 0 ? INFINITY : -INFINITY;
+    float best_lo = INFINITY;        // MODE 0: smallest radicand whose square root is `best`
     int best_j = 0x7fffffff;
     bool best_nan = false;
 
+    // staging: descriptor lengths that are multiples of 4 (FCGF: 32) move as 16-byte pieces, 4 per thread and tile (r05: the
+    // scalar loop below -- 32 dependent 4-byte loads per thread and tile, half of them zero fill -- was the other half of this
+    // kernel's time); the columns past D that the last 8-column group reads are zeroed once
+    const bool vec4 = (D & 3) == 0 && (reinterpret_cast<size_t>(tgt) & 15) == 0;
+    if (vec4) {
+        for (int idx = t; idx < MT_TGT * LD; idx += 256) Ts[idx] = 0.f;
+    }
     for (int j0 = j_begin; j0 < j_end; j0 += MT_TGT) {
-        __syncthreads();                             // previous tile consumed
-        for (int idx = t; idx < MT_TGT * KP; idx += 256) {
-            const int r = idx / KP, c = idx - r * KP;
-            const int j = j0 + r;
-            Ts[r * LD + c] = (j < j_end && c < D) ? tgt[(size_t)j * D + c] : 0.f;
+        __syncthreads();                             // previous tile consumed (first pass: the zero fill done)
+        if (vec4) {
+            const int c4n = D >> 2;
+            for (int idx = t; idx < MT_TGT * c4n; idx += 256) {
+                const int r = idx / c4n, c4 = idx - r * c4n;
+                const int j = j0 + r;
+                const f32x4 v = j < j_end ? *reinterpret_cast<const f32x4*>(tgt + (size_t)j * D + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(Ts + r * LD + 4 * c4) = v;
+            }
+        } else {
+            for (int idx = t; idx < MT_TGT * KP; idx += 256) {
+                const int r = idx / KP, c = idx - r * KP;
+                const int j = j0 + r;
+                Ts[r * LD + c] = (j < j_end && c < D) ? tgt[(size_t)j * D + c] : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -89,14 +107,39 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
             }
             // lane = source point l31; register r = target j0 + 32 sub + (r&3) + 8 (r>>2) + 4 h.  Ascending target order
             // within a lane is r = 0..15; the other half of the targets lives in lane + 32 (merged at the end).
+            // r05: the comparison runs on the RADICAND (2 - 2 dot + 1e-6: three fp32 operations instead of a correctly rounded
+            // square root per element -- the launch was bound by that vector work, not by its MFMAs).  sqrt is monotone, but two
+            // neighbouring radicands may share one square root, and the reference's arg-min takes the FIRST index among equal
+            // DISTANCES: so the lane keeps `best_lo` = the smallest radicand whose square root equals its best distance; a
+            // candidate at or above it cannot win (same distance, later index -- a lane walks its targets in ascending order),
+            // one below it is a strictly smaller distance.  The square root is taken only on that rare path (~ln N times per
+            // lane), and the result -- (distance, index) -- is the same pair the per-element form found.
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float d = MODE == 0 ? sqrtf((2.0f - 2.0f * acc[r]) + 1e-6f) : acc[r];          // reference arithmetic, fp32
-                const bool dn = d != d;
-                const bool better = MODE == 0 ? d < best : d > best;
-                const bool take = j < j_end && !best_nan && (dn || better || (d == best && j < best_j));
-                if (take) { best = d; best_j = j; best_nan = dn; }
+                const float x = MODE == 0 ? (2.0f - 2.0f * acc[r]) + 1e-6f : acc[r];                  // reference arithmetic, fp32
+                const bool maybe = MODE == 0 ? !(x >= best_lo) : !(x <= best);                         // (a NaN always takes the slow path)
+                if (j < j_end && maybe) {
+                    const float d = MODE == 0 ? sqrtf(x) : x;
+                    const bool dn = d != d;
+                    const bool better = MODE == 0 ? d < best : d > best;
+                    const bool take = !best_nan && (dn || better || (d == best && j < best_j));
+                    if (take) {
+                        best = d; best_j = j; best_nan = dn;
+                        if (MODE == 0) {
+                            float lo = x;
+                            if (!dn) {
+                                for (;;) {                               // at most a few steps: sqrt maps ~2 neighbouring floats to one
+                                    if (!(lo > 0.f)) break;
+                                    const float p = __uint_as_float(__float_as_uint(lo) - 1u);
+                                    if (sqrtf(p) != d) break;
+                                    lo = p;
+                                }
+                            }
+                            best_lo = dn ? -INFINITY : lo;               // after a NaN nothing wins any more (np.argmin: the first NaN)
+                        }
+                    }
+                }
             }
         }
     }

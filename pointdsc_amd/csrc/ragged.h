@@ -15,6 +15,12 @@ int launch_nms_keys_grid(const float* src, const float* conf, float radius, floa
 int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st);
 int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
                      const int* nvalid, hipStream_t st);
+// r05: the fused form (no S x N matrix) and its point-fragment operand
+bool knn_seeds_uses_fused(int bs, int N, int S, int k);
+int launch_knn_seeds_form(const float* normed, const float* normed_pf, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
+                          int S, int k, const int* nvalid, int form, hipStream_t st);
+int launch_normalize_conf_pf(const float* feat, const float* h2, const float* w3, const float* b3, float* normed, float* normed_pf,
+                             float* conf, int bs, int N, hipStream_t st);
 int launch_score_hypotheses_slp(const float* seed_trans, const float* src, const float* tgt, float thr2, int* counts, int bs, int N, int S,
                                 const int* nvalid, hipStream_t st);      // score_slp.hip (experiments builds)
 float*& score_debug_slot();      // score.hip (experiments builds: diagnostics of the next scoring launch)
@@ -30,15 +36,14 @@ int launch_attention_split_ex(const void* q_split, const void* kv_tiles, const v
                               float* msg, void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, int partial_layout,
                               const int* nvalid, hipStream_t st);
 
-// merged form (attention_split.hip, sc_attention_split_kernel<..., MG = true>): leaves + ticketed in-kernel merge; the normalised
-// message is left in `scratch` in point-fragment order (*message, *message_ml = the one "partial" the H3 layer kernel reads)
-constexpr int PDSC_ATT_MAX_LEAVES = 12;      // leaves per pair the merging wavefront is unrolled for (a per-launch plan with more key splits takes the legacy hand-off)
+// leaf form (attention_split.hip, sc_attention_split_kernel<..., MG = true>): C leaf partials per query, left in `scratch` in
+// point-fragment order for the H3 layer kernel to merge
+constexpr int PDSC_ATT_MAX_LEAVES = 8;       // = MERGE_MAX_SPLIT_H3 (merge_partials.h): what the layer kernel merges while it loads
 int attention_leaf_count(int N);
-void merged_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out);
-int attention_merged_reset(void* scratch, int bs, int N, int leaves_mode, hipStream_t st);
-int launch_attention_merged(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
+void leaf_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int* nleaf_out);
+int launch_attention_leaves(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,
                             void* scratch, size_t scratch_bytes, int bs, int N, int leaves_mode, const int* nvalid, int n_min,
-                            const float** message, const float** message_ml, hipStream_t st);
+                            hipStream_t st);
 
 // The three fused-layer entry points (pdsc_layer_fused_split / _frag_fmt / _frag_io: 18-24 arguments each) read the count
 // array from this thread-local slot when they fill LayerArgs; run_forward sets it for the duration of a ragged call and

@@ -35,6 +35,52 @@ __global__ __launch_bounds__(256) void normalize_conf_kernel(const float* __rest
     if (lane == 0) conf[row] = p + b3[0];
 }
 
+// ... the forward's variant (r05): a workgroup owns one 32-row tile of one pair and ALSO leaves the normalised rows in point-fragment
+// order (split_layout.h: tile = [q = 0..15][lane = 0..63][4 floats], lane (l31, h) = channels 8q + 4h .. + 3 of row l31) -- the B
+// operand of the fused kNN kernel below, which then loads 1 KiB of consecutive memory per instruction instead of 32 pieces of 32
+// bytes.  Same per-row arithmetic as normalize_conf_kernel (same bits); rows past N inside the last tile are zero in the image.
+__global__ __launch_bounds__(256) void normalize_conf_pf_kernel(const float* __restrict__ feat, const float* __restrict__ h2,
+                                                                const float* __restrict__ w3, const float* __restrict__ b3,
+                                                                float* __restrict__ normed, float* __restrict__ normed_pf,
+                                                                float* __restrict__ conf, int N, int Npf) {
+    __shared__ __attribute__((aligned(16))) float img[32 * PDSC_CHANNELS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int q = lane >> 2, hh = (lane >> 1) & 1, e = (lane & 1) * 2;       // this lane's channels 2 lane, 2 lane + 1 = 8q + 4hh + e, + 1
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr, i = tile * 32 + r;
+        float2 o = make_float2(0.f, 0.f);
+        if (i < N) {                                                         // (wave-uniform)
+            const long long row = (long long)b * N + i;
+            const float2 v = *reinterpret_cast<const float2*>(feat + row * PDSC_CHANNELS + lane * 2);
+            const float ss = wave_sum(fmaf(v.y, v.y, v.x * v.x));
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            o.x = v.x / nrm;
+            o.y = v.y / nrm;
+            *reinterpret_cast<float2*>(normed + row * PDSC_CHANNELS + lane * 2) = o;
+            float p = lane < 32 ? h2[row * 32 + lane] * w3[lane] : 0.f;
+            p = wave_sum(p);
+            if (lane == 0) conf[row] = p + b3[0];
+        }
+        *reinterpret_cast<float2*>(img + q * 256 + (r + 32 * hh) * 4 + e) = o;
+    }
+    __syncthreads();
+    float* dst = normed_pf + ((size_t)b * Npf + (size_t)tile * 32) * PDSC_CHANNELS;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<f32x4*>(dst + (t + 256 * u) * 4) = *reinterpret_cast<const f32x4*>(img + (t + 256 * u) * 4);
+}
+
+int launch_normalize_conf_pf(const float* feat, const float* h2, const float* w3, const float* b3, float* normed, float* normed_pf,
+                             float* conf, int bs, int N, hipStream_t st) {
+    PDSC_REQUIRE(feat && h2 && w3 && b3 && normed && normed_pf && conf, "pdsc_normalize_confidence(pf): null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_normalize_confidence(pf): bs=%d N=%d", bs, N);
+    hipLaunchKernelGGL(normalize_conf_pf_kernel, dim3(ceil_div(N, 32), bs), dim3(256), 0, st, feat, h2, w3, b3, normed, normed_pf, conf, N,
+                       (int)round_up(N, 32));
+    return check_launch("pdsc_normalize_confidence(pf)");
+}
+
 // ---- NMS keys: key[i] = conf[i] * all_j( conf[i] >= conf[j] || dist(i,j) >= R ) ---------------------
 // `radius2` = the smallest fp32 x with sqrt_rn(x) >= radius (computed on the host): since the correctly rounded square
 // root is monotone, `sqrt(x) >= radius` and `x >= radius2` are the same predicate bit for bit -- without the ~20
@@ -580,7 +626,8 @@ int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_see
 constexpr int KF_ROWS = 32, KF_CAP = 256, KF_KEEP = 96, KF_MAX_WANT = 48;
 
 struct KnnFusedArgs {
-    const float* X;          // [bs][NS][128] normalised features
+    const float* X;          // [bs][NS][128] normalised features (the seeds' rows: A operand)
+    const float* Xpf;        // [bs][round_up(NS, 32)][128] the same rows in point-fragment order (B operand), or NULL: gather from X
     const int* seeds;        // [bs][S]
     int* knn_idx;            // [bs][S][k]
     int NS, S, k, idx_bits;
@@ -611,11 +658,21 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
     }
     const int nblocks = (N + 31) >> 5, rounds = (nblocks + 3) >> 2;
     f32x4 bf[16];
+    const int Npf = (a.NS + 31) & ~31;
+    const float* Xpf = a.Xpf ? a.Xpf + (size_t)b * Npf * PDSC_CHANNELS + lane * 4 : nullptr;
     auto load_b = [&](int cb) {
-        const int col = min(cb * 32 + l31, N - 1);
-        const float* p = X + (size_t)col * PDSC_CHANNELS + 4 * h;
+        if (Xpf) {
+            // point-fragment image: instruction q of the wave reads 1 KiB of consecutive memory (columns past N: whatever the image
+            // holds there -- those lanes' results are never looked at)
+            const float* p = Xpf + (size_t)min(cb, nblocks - 1) * 32 * PDSC_CHANNELS;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) bf[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+            for (int q = 0; q < 16; ++q) bf[q] = *reinterpret_cast<const f32x4*>(p + 256 * q);
+        } else {
+            const int col = min(cb * 32 + l31, N - 1);
+            const float* p = X + (size_t)col * PDSC_CHANNELS + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bf[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+        }
     };
     load_b(wave);
     __syncthreads();
@@ -731,27 +788,29 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
 }
 
 // form: 0 = the library's choice, 1 = two launches through the S x N matrix (knn_dist_rows + knn_select_kernel), 2 = fused
-int launch_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
-                          const int* nvalid, int form, hipStream_t st);
-
 int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
                      const int* nvalid, hipStream_t st) {
-    return launch_knn_seeds_form(normed, seeds, dist_scratch, knn_idx, bs, N, S, k, nvalid, 0, st);
+    return launch_knn_seeds_form(normed, nullptr, seeds, dist_scratch, knn_idx, bs, N, S, k, nvalid, 0, st);
 }
 
-int launch_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
-                          const int* nvalid, int form, hipStream_t st) {
+bool knn_seeds_uses_fused(int bs, int N, int S, int k) {
+    return k + 1 <= KF_MAX_WANT && N >= 256 && (long long)bs * ceil_div(S, KF_ROWS) >= 384;
+}
+
+// normed_pf (optional): the normalised rows in point-fragment order (normalize_conf_pf_kernel): the fused form's B operand
+int launch_knn_seeds_form(const float* normed, const float* normed_pf, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
+                          int S, int k, const int* nvalid, int form, hipStream_t st) {
     PDSC_REQUIRE(form >= 0 && form <= 2, "pdsc_knn_seeds: form=%d", form);
     // fused: enough workgroups of 32 seeds to fill the chip (else the two-launch form, whose Gram splits the columns too), k + 1
     // within the 64 lane minima's reach, and at least k + 1 columns per pair
     const bool fits = k + 1 <= KF_MAX_WANT && N >= 256;
     PDSC_REQUIRE(form != 2 || fits, "pdsc_knn_seeds: the fused form needs k + 1 <= %d and N >= 256 (k=%d, N=%d)", KF_MAX_WANT, k, N);
-    if (form == 2 || (form == 0 && fits && (long long)bs * ceil_div(S, KF_ROWS) >= 384)) {
+    if (form == 2 || (form == 0 && knn_seeds_uses_fused(bs, N, S, k))) {
         PDSC_REQUIRE(normed && seeds && knn_idx, "pdsc_knn_seeds: null pointer");
         PDSC_REQUIRE(bs > 0 && N > 1 && S > 0, "pdsc_knn_seeds: bs=%d N=%d S=%d", bs, N, S);
         PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K && k <= N - 1, "pdsc_knn_seeds: k=%d (N=%d, max %d)", k, N, PDSC_MAX_K);
         KnnFusedArgs a{};
-        a.X = normed; a.seeds = seeds; a.knn_idx = knn_idx; a.NS = N; a.S = S; a.k = k; a.nvalid = nvalid;
+        a.X = normed; a.Xpf = normed_pf; a.seeds = seeds; a.knn_idx = knn_idx; a.NS = N; a.S = S; a.k = k; a.nvalid = nvalid;
         a.idx_bits = 1;
         while ((1 << a.idx_bits) < N) ++a.idx_bits;
         const size_t lds_bytes = (size_t)KF_ROWS * KF_CAP * sizeof(unsigned long long);
@@ -790,9 +849,14 @@ extern "C" int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, in
     return pdsc::launch_rank_select(keys, seeds, bs, N, num_seeds, nullptr, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int pdsc_knn_seeds_form(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,
-                                   int S, int k, int form, void* stream) {
-    return pdsc::launch_knn_seeds_form(normed, seeds, dist_scratch, knn_idx, bs, N, S, k, nullptr, form, (hipStream_t)stream);
+extern "C" int pdsc_knn_seeds_form(const float* normed, const float* normed_pf, const int* seeds, float* dist_scratch, int* knn_idx,
+                                   int bs, int N, int S, int k, int form, void* stream) {
+    return pdsc::launch_knn_seeds_form(normed, normed_pf, seeds, dist_scratch, knn_idx, bs, N, S, k, nullptr, form, (hipStream_t)stream);
+}
+
+extern "C" int pdsc_normalize_confidence_pf(const float* feat, const float* h2, const float* w3, const float* b3, float* normed,
+                                            float* normed_pf, float* conf, int bs, int N, void* stream) {
+    return pdsc::launch_normalize_conf_pf(feat, h2, w3, b3, normed, normed_pf, conf, bs, N, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N,

@@ -36,7 +36,7 @@ COMPAT_FORMATS = {"f32": 0, "u16": 1}
 # enum pdsc_layer_gemm
 LAYER_GEMMS = {"f32": 0, "h3": 1}
 # enum pdsc_att_leaves (an int >= 2 = that many leaves)
-ATT_LEAVES = {"legacy": -1, "per_launch": 0, "canonical": 1}
+ATT_LEAVES = {"per_launch": 0, "canonical": 1}
 
 
 def _conv(cin: int, cout: int) -> nn.Conv1d:
@@ -134,8 +134,8 @@ class PointDSC(nn.Module):
         self.layer_gemm = "h3"
         # summation tree of the attention's key dimension (enum pdsc_att_leaves): "canonical" = a leaf count that depends on N alone,
         # so a pair's result is bit-identical whatever the batch it shares a launch with (1 GPU x 32 pairs == 8 GPUs x 4 pairs);
-        # "per_launch" = one leaf per key split of the launch plan (the r01-r04 bits: they move with the batch size, within the
-        # contract); "legacy" = per_launch's bits through the r01-r04 hand-off (the layer kernel merges the partials); int >= 2: tuning
+        # "per_launch" = one partial per key split of the launch plan (the r01-r04 bits: they move with the batch size, within the
+        # contract; the fastest form); int 2..8: that many leaves (tuning)
         self.att_leaves = "canonical"
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
@@ -160,12 +160,12 @@ class PointDSC(nn.Module):
             raise ValueError(f"compat_format must be one of {sorted(COMPAT_FORMATS)}, got {self.compat_format!r}")
         if self.layer_gemm not in LAYER_GEMMS:
             raise ValueError(f"layer_gemm must be one of {sorted(LAYER_GEMMS)}, got {self.layer_gemm!r}")
-        if isinstance(self.att_leaves, int) and not isinstance(self.att_leaves, bool) and 2 <= self.att_leaves <= 12:
+        if isinstance(self.att_leaves, int) and not isinstance(self.att_leaves, bool) and 2 <= self.att_leaves <= 8:
             leaves = int(self.att_leaves)
         elif self.att_leaves in ATT_LEAVES:
             leaves = ATT_LEAVES[self.att_leaves]
         else:
-            raise ValueError(f"att_leaves must be one of {sorted(ATT_LEAVES)} or an int in [2, 12], got {self.att_leaves!r}")
+            raise ValueError(f"att_leaves must be one of {sorted(ATT_LEAVES)} or an int in [2, 8], got {self.att_leaves!r}")
         return _lib.PdscConfig(self.in_dim, self.num_layers, self.num_channels, self.num_iterations, self.k, 20,
                                float(self.inlier_threshold), float(self.nms_radius), float(refine_thr),
                                ATTENTION_PRECISIONS[self.attention_precision], COMPAT_FORMATS[self.compat_format],

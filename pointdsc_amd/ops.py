@@ -424,6 +424,20 @@ def normalize_confidence(feat, h2, w3, b3) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 @_on_device
+def normalize_confidence_pf(feat, h2, w3, b3):
+    """feat [bs,N,128], h2 [bs,N,32] -> (normed [bs,N,128], normed_pf [bs,ceil(N/32)*32,128] point-fragment order, conf [bs,N])."""
+    lib = _lib.load()
+    feat, h2, w3, b3 = _chk(feat, "feat"), _chk(h2, "h2"), _chk(w3.reshape(-1), "w3"), _chk(b3.reshape(-1), "b3")
+    bs, n = feat.shape[0], feat.shape[1]
+    normed = torch.empty_like(feat)
+    normed_pf = torch.empty(bs, (n + 31) // 32 * 32, 128, device=feat.device, dtype=torch.float32)
+    conf = torch.empty(bs, n, device=feat.device, dtype=torch.float32)
+    _lib.check(lib.pdsc_normalize_confidence_pf(_p(feat), _p(h2), _p(w3), _p(b3), _p(normed), _p(normed_pf), _p(conf), bs, n, _stream()),
+               "pdsc_normalize_confidence_pf")
+    return normed, normed_pf, conf
+
+
+@_on_device
 def nms_keys(src_keypts, conf, radius: float) -> torch.Tensor:
     lib = _lib.load()
     src, conf = _chk(src_keypts, "src_keypts"), _chk(conf, "conf")
@@ -463,9 +477,10 @@ def pick_seeds(src_keypts, scores, R: float, max_num: int) -> torch.Tensor:
 
 
 @_on_device
-def knn_seeds(normed, seeds, k: int, return_dist: bool = False, form: str = "auto"):
+def knn_seeds(normed, seeds, k: int, return_dist: bool = False, form: str = "auto", normed_pf=None):
     """normed [bs,N,128], seeds [bs,S] int32 -> knn_idx [bs,S,k] int32.  form: "auto" (the library's choice), "matrix" (Gram rows
-    written to HBM, then a selection launch) or "fused" (one launch, no S x N matrix; the returned distances are then undefined)."""
+    written to HBM, then a selection launch) or "fused" (one launch, no S x N matrix; the returned distances are then undefined).
+    normed_pf: the rows in point-fragment order (ops.normalize_confidence_pf), the fused form's fast column operand."""
     forms = {"auto": 0, "matrix": 1, "fused": 2}
     lib = _lib.load()
     normed, seeds = _chk(normed, "normed"), _chk(seeds, "seeds", torch.int32)
@@ -474,7 +489,8 @@ def knn_seeds(normed, seeds, k: int, return_dist: bool = False, form: str = "aut
     ld = compat_ld(n)
     dist = torch.empty(bs, s, ld, device=normed.device, dtype=torch.float32)
     idx = torch.empty(bs, s, k, device=normed.device, dtype=torch.int32)
-    _lib.check(lib.pdsc_knn_seeds_form(_p(normed), _p(seeds), _p(dist), _p(idx), bs, n, s, k, forms[form], _stream()), "pdsc_knn_seeds")
+    _lib.check(lib.pdsc_knn_seeds_form(_p(normed), _p(normed_pf) if normed_pf is not None else None, _p(seeds), _p(dist), _p(idx), bs, n, s, k,
+                                       forms[form], _stream()), "pdsc_knn_seeds")
     return (idx, dist[..., :n]) if return_dist else idx
 
 

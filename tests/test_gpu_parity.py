@@ -1515,6 +1515,19 @@ def test_knn_fused_form_equals_the_matrix_form(bs, n, s, k, dup):
     got = ops.knn_seeds(normed, seeds, k, form="fused")
     torch.cuda.synchronize()
     assert torch.equal(got, want), (int((got != want).sum()), got.shape)
+    # ... and with the column operand in point-fragment order, as the forward feeds it (pdsc_normalize_confidence_pf: the same
+    # normalised rows -- here re-normalising unit rows changes nothing beyond the last bit, so the distances are re-derived from ITS rows)
+    h2 = g(torch.zeros(bs, n, 32))
+    rows, rows_pf, conf = ops.normalize_confidence_pf(normed, h2, g(torch.zeros(32)), g(torch.zeros(1)))
+    rows2, conf2 = ops.normalize_confidence(normed.reshape(bs * n, 128), h2.reshape(bs * n, 32), g(torch.zeros(32)), g(torch.zeros(1)))
+    assert torch.equal(rows.reshape(bs * n, 128), rows2) and torch.equal(conf.reshape(-1), conf2)
+    tiles = (n + 31) // 32
+    img = rows_pf.reshape(bs, tiles, 16, 2, 32, 4)                     # [pair][tile][q][h][l31][e] -> row l31, channel 8q + 4h + e
+    back = img.permute(0, 1, 4, 2, 3, 5).reshape(bs, tiles * 32, 128)[:, :n]
+    assert torch.equal(back, rows)
+    want_pf = ops.knn_seeds(rows, seeds, k, form="matrix")
+    got_pf = ops.knn_seeds(rows, seeds, k, form="fused", normed_pf=rows_pf)
+    assert torch.equal(got_pf, want_pf), int((got_pf != want_pf).sum())
     auto = ops.knn_seeds(normed, seeds, k)
     assert torch.equal(auto, want)
     for _ in range(3):                                       # repeated launches: nothing carried over between them
@@ -1532,28 +1545,31 @@ def test_knn_fused_form_rejections():
     assert ops.knn_seeds(normed, seeds, 60).shape == (1, 20, 60)         # the library's choice falls back
 
 
-LEAVES_DEFAULT = "canonical"
+LEAVES_DEFAULT = PointDSC().att_leaves
 
 
 @pytest.mark.parametrize("name,sizes", [("n1000_b1", (32, 16, 8, 4, 2, 1)), ("n5000_b32", (32, 16, 8, 4, 2, 1)),
                                         ("kitti_n5000_b16", (16, 8, 4, 2, 1)), ("lomatch_n10000_b8", (8, 4, 2, 1)),
                                         ("kitti_n12000_b4", (4, 2, 1)), ("multiway_n20000_b1", (2, 1))])
 def test_canonical_leaves_make_a_pair_independent_of_its_batch(name, sizes):
-    """r05: with att_leaves = "canonical" (the module's default) the attention sums a query's keys over a leaf
+    """r05: with att_leaves = "canonical" the attention sums a query's keys over a leaf
     structure that depends on N alone -- the launch plan only decides which workgroup computes a leaf -- so the whole forward
     returns BITWISE the same pose and mask for a pair whether it runs alone or with 1 .. 31 others: 32 pairs on one GPU and 4 pairs on
     each of 8 GPUs are the same numbers (reference semantics: one pair per call, models/PointDSC.py:210,414)."""
     model, _ = _bench_model(name)
-    assert model.att_leaves == LEAVES_DEFAULT
     big = sizes[0]
     batch = workloads.batch(name, 0, big)
-    full = _forward(model, batch)
-    T, L = full["final_trans"].clone(), full["final_labels"].clone()
-    for bs in sizes[1:]:
-        for first in range(0, big, bs):
-            part = _forward(model, {k: batch[k][first:first + bs] for k in batch})
-            assert torch.equal(part["final_trans"].view(torch.int32), T[first:first + bs].view(torch.int32)), (name, bs, first)
-            assert torch.equal(part["final_labels"], L[first:first + bs]), (name, bs, first)
+    try:
+        model.att_leaves = "canonical"
+        full = _forward(model, batch)
+        T, L = full["final_trans"].clone(), full["final_labels"].clone()
+        for bs in sizes[1:]:
+            for first in range(0, big, bs):
+                part = _forward(model, {k: batch[k][first:first + bs] for k in batch})
+                assert torch.equal(part["final_trans"].view(torch.int32), T[first:first + bs].view(torch.int32)), (name, bs, first)
+                assert torch.equal(part["final_labels"], L[first:first + bs]), (name, bs, first)
+    finally:
+        model.att_leaves = LEAVES_DEFAULT
 
 
 @pytest.mark.parametrize("n,bs_list", [(1000, (1, 3, 8)), (2053, (1, 2, 5)), (700, (1, 4))])
@@ -1562,93 +1578,107 @@ def test_canonical_leaves_features_independent_of_the_batch(n, bs_list):
     feature channel of every correspondence, models/PointDSC.py:158-163) and the logits, bit for bit across batch sizes."""
     c = case(n)
     model = c["model"]
-    assert model.att_leaves == LEAVES_DEFAULT
     big = max(bs_list)
     batch = synthetic.make_batch(big, n, seed=520 + n, inlier_ratio=0.3)
     outs = {}
-    for bs in bs_list:
-        data = {k: g(batch[k][:bs]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
-        with torch.no_grad():
-            outs[bs] = model(data)
-        torch.cuda.synchronize()
+    try:
+        model.att_leaves = "canonical"
+        for bs in bs_list:
+            data = {k: g(batch[k][:bs]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+            with torch.no_grad():
+                outs[bs] = model(data)
+            torch.cuda.synchronize()
+    finally:
+        model.att_leaves = LEAVES_DEFAULT
     ref = outs[big]
     for bs in bs_list:
         assert torch.equal(outs[bs]["M"].view(torch.int32), ref["M"][:bs].view(torch.int32)), (n, bs)
         assert torch.equal(outs[bs]["final_labels"].view(torch.int32), ref["final_labels"][:bs].view(torch.int32)), (n, bs)
 
 
-@pytest.mark.parametrize("name,bs", [("n1000_b1", 1), ("n1000_b1", 16), ("n5000_b32", 1), ("n5000_b32", 2), ("n5000_b32", 4), ("n5000_b32", 32),
+@pytest.mark.parametrize("name,bs", [("n1000_b1", 1), ("n1000_b1", 16), ("n5000_b32", 2), ("n5000_b32", 4), ("n5000_b32", 16), ("n5000_b32", 32),
                                      ("kitti_n5000_b16", 16), ("lomatch_n10000_b8", 1), ("lomatch_n10000_b8", 8)])
-def test_in_kernel_merge_with_per_launch_leaves_equals_the_legacy_handoff_bitwise(name, bs):
-    """att_leaves = "per_launch" is the r01-r04 arithmetic (one leaf per key split of the launch plan) with the r05 plumbing: the
-    last wavefront to finish a query tile merges the partials inside the attention launch (tickets, loads past the caches) and the
-    layer kernel reads one message.  "legacy" leaves the partials to the layer kernel (or, above 8 splits, to the combine launch).
-    Same operations in the same order: the forwards agree bit for bit -- which also pins the ticket protocol (a partial read before
-    it was visible, or a lost arrival, would show here)."""
+def test_leaf_form_with_as_many_leaves_as_key_splits_reproduces_the_per_launch_bits(name, bs):
+    """The leaf form (a workgroup streams through several leaves, each from a fresh online-softmax state, and leaves one partial per
+    leaf) against the key-split form (one partial per workgroup): with att_leaves forced to the per-launch plan's key split the leaves
+    ARE that plan's key ranges, whichever divisor of the leaf count the leaf plan gives to a workgroup -- so the two forwards agree bit
+    for bit.  Pins the in-loop leaf boundary (raw logits, fresh row maximum, accumulators re-zeroed in place, deferred partial store)
+    against the code path that has been parity-clean since r01."""
+    lib = _lib.load()
     model, _ = _bench_model(name)
+    n = workloads.WORKLOADS[name]["num_corr"]
+    ns = int(lib.pdsc_attention_split_default_split(bs, n))
+    if not 2 <= ns <= 8:
+        pytest.skip(f"per-launch key split {ns} outside the leaf form's 2..8")
     batch = workloads.batch(name, 0, bs)
     try:
-        model.att_leaves = "legacy"
-        want = _forward(model, batch)
         model.att_leaves = "per_launch"
-        for rep in range(3):
+        want = _forward(model, batch)
+        model.att_leaves = ns
+        for rep in range(2):
             got = _forward(model, batch)
-            assert torch.equal(got["final_trans"].view(torch.int32), want["final_trans"].view(torch.int32)), (name, bs, rep)
-            assert torch.equal(got["final_labels"], want["final_labels"]), (name, bs, rep)
+            assert torch.equal(got["final_trans"].view(torch.int32), want["final_trans"].view(torch.int32)), (name, bs, ns, rep)
+            assert torch.equal(got["final_labels"], want["final_labels"]), (name, bs, ns, rep)
     finally:
         model.att_leaves = LEAVES_DEFAULT
 
 
-def test_in_kernel_merge_validation_matrix_equals_the_legacy_handoff_bitwise():
+def test_leaf_form_validation_matrix_reproduces_the_per_launch_bits():
+    """Same property on the validation forward's N x N feature-similarity matrix (every feature of every correspondence)."""
+    lib = _lib.load()
     c = case(1000)
     model = c["model"]
     batch = synthetic.make_batch(3, 1000, seed=610, inlier_ratio=0.3)
     data = {k: g(batch[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    ns = int(lib.pdsc_attention_split_default_split(3, 1000))
+    assert 2 <= ns <= 8
     try:
         outs = {}
-        for mode in ("legacy", "per_launch"):
+        for mode in ("per_launch", ns):
             model.att_leaves = mode
             with torch.no_grad():
                 outs[mode] = model(data)
             torch.cuda.synchronize()
-        assert torch.equal(outs["legacy"]["M"].view(torch.int32), outs["per_launch"]["M"].view(torch.int32))
-        assert torch.equal(outs["legacy"]["final_labels"].view(torch.int32), outs["per_launch"]["final_labels"].view(torch.int32))
+        assert torch.equal(outs["per_launch"]["M"].view(torch.int32), outs[ns]["M"].view(torch.int32))
+        assert torch.equal(outs["per_launch"]["final_labels"].view(torch.int32), outs[ns]["final_labels"].view(torch.int32))
     finally:
         model.att_leaves = LEAVES_DEFAULT
 
 
 @pytest.mark.parametrize("name,bs,reps", [("n1000_b1", 1, 300), ("n5000_b32", 4, 40), ("n5000_b32", 32, 12), ("lomatch_n10000_b8", 2, 20)])
-def test_merged_attention_is_deterministic_over_repeated_launches(name, bs, reps):
-    """The merging wavefront is whichever finishes last; the merge order is the leaf order, whoever merges.  Hundreds of launches
-    (the first of every forward re-zeroes the tickets, the rest rely on the merging waves having left them zero) return one result."""
+def test_leaf_form_attention_is_deterministic_over_repeated_launches(name, bs, reps):
+    """Hundreds of launches of the canonical-leaf forward return one result."""
     model, _ = _bench_model(name)
     batch = workloads.batch(name, 0, bs)
     data = {k: g(batch[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     data["testing"] = True
-    with torch.no_grad():
-        first = model(data)
-        T, L = first["final_trans"].clone(), first["final_labels"].clone()
-        for rep in range(reps):
-            res = model(data)
-            assert torch.equal(res["final_trans"].view(torch.int32), T.view(torch.int32)), rep
-            assert torch.equal(res["final_labels"], L), rep
-    torch.cuda.synchronize()
+    try:
+        model.att_leaves = "canonical"
+        with torch.no_grad():
+            first = model(data)
+            T, L = first["final_trans"].clone(), first["final_labels"].clone()
+            for rep in range(reps):
+                res = model(data)
+                assert torch.equal(res["final_trans"].view(torch.int32), T.view(torch.int32)), rep
+                assert torch.equal(res["final_labels"], L), rep
+        torch.cuda.synchronize()
+    finally:
+        model.att_leaves = LEAVES_DEFAULT
 
 
 def test_attention_leaf_plan_properties():
-    """Host-side plan of the merged form: the canonical leaf count depends on N alone, the key split always divides it, every
-    leaf has at least one tile, and per-launch leaves reproduce the legacy planner's split."""
+    """Host-side plan of the leaf form: the canonical leaf count depends on N alone, never exceeds what the layer kernel merges
+    (8), leaves at least 4 tiles per leaf from 8 tiles on, and the key split of every batch size divides it."""
     import ctypes as C
     lib = _lib.load()
     ns, nl = C.c_int(), C.c_int()
     for n in (33, 257, 700, 1000, 1504, 1505, 2053, 5000, 10000, 12000, 20000, 36864):
         leaves = lib.pdsc_attention_leaf_count(n)
-        assert 1 <= leaves <= max(1, ((n + 31) // 32) // 4) or leaves == 1
+        tiles = (n + 31) // 32
+        assert 1 <= leaves <= 8 and (leaves == 1 or tiles // leaves >= 4), (n, leaves)
         for bs in (1, 2, 3, 4, 8, 16, 32):
-            _lib.check(lib.pdsc_attention_merged_plan(bs, n, 1, C.byref(ns), C.byref(nl)), "plan")
+            _lib.check(lib.pdsc_attention_leaf_plan(bs, n, 1, C.byref(ns), C.byref(nl)), "plan")
             assert nl.value == leaves and leaves % ns.value == 0, (n, bs, ns.value, nl.value)
-            _lib.check(lib.pdsc_attention_merged_plan(bs, n, 0, C.byref(ns), C.byref(nl)), "plan")
-            assert ns.value == nl.value == lib.pdsc_attention_split_default_split(bs, n)
 
 
 def test_batched_forward_equals_per_pair_calls():

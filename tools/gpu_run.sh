@@ -5,13 +5,14 @@
 #   newtests        the r05 tests only (merged attention, canonical leaves, SM opt-in, trained census), fail-fast
 #   tests           pytest -m gpu, whole suite (tail of the log kept)
 #   smoke           __graft_entry__.smoke()
-#   ab_leaves       bench lines of n5000_b32 at 32 / 4 / 1 pairs for att_leaves = legacy | per_launch | canonical | 6 | 4
+#   ab_leaves       bench lines of n5000_b32 at 32 / 4 / 1 pairs for att_leaves = per_launch | canonical | 2 | 8
 #   ab_leaves_more  the same A/B on kitti_n5000_b16 (16, 2), lomatch_n10000_b8 (8, 1), n1000_b1 (1)
 #   latency         one pair per call, result read back (bench.py --latency): n5000 x1, n2000-like, n1000 x1
 #   census_trained  tools/parity_census.py on the trained-like families, every batch size, default and exact-fp32 arithmetic
 #   census          tools/parity_census.py on every family (default arithmetic), batches 0,1,2,4,8,16,32
 #   bundle          tools/gpu_profile_run.sh <tag> (the round's evidence bundle: bench lines, rocprof, PMC, micro-benches)
 #   knn_bench       kNN of the seeds: two-launch (S x N matrix) form against the fused form
+#   match_bench     tools/match_bench.py (f-2 correspondence construction)
 #   kitti_stage     which arithmetic moves the KITTI pairs 60 / 21 / 26: one knob at a time
 set -u
 TAG=${1:?tag}
@@ -51,16 +52,16 @@ tests)
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -5 > "$OUT/smoke.txt"; cat "$OUT/smoke.txt" ;;
 ab_leaves)
-  for L in legacy per_launch canonical 6 4; do
+  for L in per_launch canonical 2 8; do
     line ab_n5000_b32_x32_$L --config n5000_b32 --att-leaves $L --no-cpu-baseline --sustain-seconds 1.5
   done
-  for L in legacy canonical 4; do
+  for L in per_launch canonical 8; do
     line ab_n5000_b32_x4_$L --config n5000_b32 --global-batch 4 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
     line ab_n5000_b32_x1_$L --config n5000_b32 --global-batch 1 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
   done
   summ | tee "$OUT/ab_leaves_summary.txt" ;;
 ab_leaves_more)
-  for L in legacy canonical; do
+  for L in per_launch canonical; do
     line ab_kitti_x16_$L --config kitti_n5000_b16 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
     line ab_kitti_x2_$L --config kitti_n5000_b16 --global-batch 2 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
     line ab_lomatch_x8_$L --config lomatch_n10000_b8 --att-leaves $L --no-cpu-baseline --sustain-seconds 1
@@ -69,7 +70,7 @@ ab_leaves_more)
   done
   summ | tee "$OUT/ab_leaves_more_summary.txt" ;;
 latency)
-  for L in legacy canonical; do
+  for L in per_launch canonical; do
     line lat_n5000_x1_$L --config n5000_b32 --global-batch 1 --latency --att-leaves $L --no-cpu-baseline --steps 200 --warmup 20 --sustain-seconds 1
     line lat_n1000_x1_$L --config n1000_b1 --latency --att-leaves $L --no-cpu-baseline --steps 400 --warmup 20 --sustain-seconds 1
     line lat_trained_n1000_x1_$L --config trained_n1000_b1 --latency --att-leaves $L --no-cpu-baseline --steps 400 --warmup 20 --sustain-seconds 1
@@ -101,19 +102,25 @@ for bs, n in ((32, 5000), (16, 5000), (8, 10000), (4, 5000)):
     normed = torch.from_numpy(x).cuda()
     seeds = torch.from_numpy(np.stack([rs.permutation(n)[:s] for _ in range(bs)]).astype(np.int32)).cuda()
     out = {}
-    for form in ("matrix", "fused"):
-        for _ in range(3): r = ops.knn_seeds(normed, seeds, 40, form=form)
+    h2 = torch.zeros(bs, n, 32, device="cuda")
+    rows, rows_pf, _ = ops.normalize_confidence_pf(normed, h2, torch.zeros(32, device="cuda"), torch.zeros(1, device="cuda"))
+    for form, kw in (("matrix", dict(form="matrix")), ("fused_gather", dict(form="fused")), ("fused_pf", dict(form="fused", normed_pf=rows_pf))):
+        for _ in range(3): r = ops.knn_seeds(rows, seeds, 40, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20): r = ops.knn_seeds(normed, seeds, 40, form=form)
+        for _ in range(20): r = ops.knn_seeds(rows, seeds, 40, **kw)
         e1.record(); torch.cuda.synchronize()
         out[form] = (e0.elapsed_time(e1) / 20 * 1e3, r)
     flops = 256.0 * bs * s * n
-    print(f"kNN of the seeds, {bs} pairs of N={n}, S={s}, k=40: matrix form {out['matrix'][0]:.1f} us, fused {out['fused'][0]:.1f} us "
-          f"({flops / out['fused'][0] / 1e6:.1f} TFLOP/s = {flops / out['fused'][0] / 1e6 / 157.3:.3f} of the fp32-MFMA peak); indices equal: {bool(torch.equal(out['matrix'][1], out['fused'][1]))}")
+    print(f"kNN of the seeds, {bs} pairs of N={n}, S={s}, k=40 (incl. the S x N scratch allocation of the wrapper): matrix form {out['matrix'][0]:.1f} us, "
+          f"fused (gathered columns) {out['fused_gather'][0]:.1f} us, fused (point-fragment columns) {out['fused_pf'][0]:.1f} us "
+          f"({flops / out['fused_pf'][0] / 1e6:.1f} TFLOP/s = {flops / out['fused_pf'][0] / 1e6 / 157.3:.3f} of the fp32-MFMA peak); indices equal: "
+          f"{bool(torch.equal(out['matrix'][1], out['fused_gather'][1]) and torch.equal(out['matrix'][1], out['fused_pf'][1]))}")
 PY
   cat "$OUT/knn_bench.txt" ;;
+match_bench)
+  timeout 300 python tools/match_bench.py > "$OUT/match_bench.txt" 2>&1; cat "$OUT/match_bench.txt" ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
