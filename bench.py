@@ -218,9 +218,11 @@ def parse():
                          "pairs of N=5000, -6 %% at 4 pairs, -13 %% for one pair of N=10000; not used on the hipGraph path)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay each in-flight slot's forward as a captured hipGraph (auto: only when a step is one small problem)")
-    ap.add_argument("--zero-copy", choices=["auto", "off"], default="auto",
-                    help="with --graphs: capture each slot's graph on the resident input tensors and hand out the graph's own output "
-                         "tensors (pipeline.InFlight(zero_copy=True): no staging copies / clones around a replay); off = copies as in r03")
+    ap.add_argument("--zero-copy", choices=["on", "off"], default="off",
+                    help="with --graphs, on: capture each slot's graph on the resident input tensors and hand out the graph's own output "
+                         "tensors (pipeline.InFlight(zero_copy=True): no staging copies / clones around a replay -- a STRICTER contract than the "
+                         "module call: results are overwritten `depth` calls later and the inputs must not change while a replay runs); "
+                         "off (default, ADVICE r04): staged copies in, clones out, the drop-in call's contract")
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed load before the timed region so that it does not sit on the clock ramp (0 = exactly W warm-up steps)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed on the CPU baseline (0 = sized for ~10-20 s)")
@@ -311,7 +313,7 @@ def main():
     use_graphs = in_flight > 1 and (args.graphs == "on" or (args.graphs == "auto" and small))
     use_tail = args.tail_streams == "on"
     # captured forwards read the bench's resident input tensors in place and hand out the graphs' own output tensors
-    zero_copy = use_graphs and args.zero_copy != "off"
+    zero_copy = use_graphs and args.zero_copy == "on"
     runners = {d: InFlight(model, depth=d, graphs=use_graphs and d > 1, tail_streams=use_tail, zero_copy=zero_copy and d > 1)
                for d in sorted({1, in_flight})}
     depth = {"d": in_flight}
@@ -390,6 +392,10 @@ def main():
     # the parity check below judges THIS result: the last forward of the timed region, produced with the schedule `value` was
     # measured with (forwards in flight, tail streams / replayed hipGraphs); the single-stream leg's result is compared with it
     timed_res = {k: last["res"][k].clone() for k in ("final_trans", "final_labels")}
+    # fingerprint of the GATHERED poses of that step (all pairs of all ranks, in pair order): with att_leaves = "canonical" a run
+    # sharded over 8 GPUs must print the same fingerprint as the one-GPU run of the same pairs (tests/test_sharding_gloo.py)
+    import hashlib
+    poses_sha = hashlib.sha256(out["final_trans"].detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16] if isinstance(out, dict) else None
     # ... and the discrete decisions of that forward (seeds, votes, chosen hypothesis, refinement trace, neighbour sets), read from
     # its workspace before the next leg overwrites it: what tools/parity_census.py:explain needs should a pair leave the contract
     timed_dec = None
@@ -547,7 +553,7 @@ def main():
                    "compat_format": "f32" if fp32 else model.compat_format, "layer_gemm": model.layer_gemm,
                    "att_leaves": None if fp32 else model.att_leaves,
                    "attention_plan": None if fp32 else attention_plan(lib, B, N, model.att_leaves),
-                   "latency_mode": bool(args.latency),
+                   "latency_mode": bool(args.latency), "gathered_poses_sha256_16": poses_sha,
                    "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s); %d forward(s) in flight per GPU "
                                   "(consecutive steps alternate between HIP streams%s)"
                                   % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU", depth["d"],

@@ -456,7 +456,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         const bool pf_ok = frag && gemm == PDSC_LAYER_GEMM_H3 && env_int("PDSC_LAYER_PF", 1) != 0 && env_int("PDSC_LAYER_H3_VARIANT", 1) != 0;
         int lf_ns = 0, lf_leaves = 0, lf_nw = 0;
         if (cfg->att_leaves >= PDSC_LEAVES_CANONICAL) leaf_plan(bs, N, cfg->att_leaves, &lf_nw, &lf_ns, &lf_leaves);
-        const bool leaves = pf_ok && cfg->att_leaves >= PDSC_LEAVES_CANONICAL && (!nvalid || (n_min + 31) / 32 >= lf_leaves);
+        const bool leaves = pf_ok && cfg->att_leaves >= PDSC_LEAVES_CANONICAL && (!nvalid || (n_min + 31) / 32 >= 2 * lf_leaves);
         if (nvalid && !leaves)
             PDSC_REQUIRE((n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
                          "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "

@@ -439,8 +439,17 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     // kt + 1, no logits, no run-ahead loads: r01-r03 ran the same straight-line body there and threw the 24 MFMAs away (0.6 % of a
     // launch's MFMAs at 32 pairs of N = 5000, 1-2.4 % with the finer key splits of 1-4 pairs); peeled AFTER the loop the tail is
     // straight-line code of its own, the accumulators flow loop -> tail -> epilogue and nothing is copied.
-    auto tile_iteration = [&](const int kt, auto last_c) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_c)::value;
+    // kind_c: 0 = an ordinary tile, 1 = LAST (see above).  Leaf form (MG) only: 2 = BOUNDARY, the last tile of a leaf that ends inside
+    // the workgroup's range -- tile kt + 1 starts a new leaf, so its logits are formed against a fresh reference (raw products, then
+    // their row maximum: bit for bit what the first-tile code above does for a workgroup that STARTS at that leaf) and the finished
+    // leaf's state is parked; 3 = the first tile of such a later leaf: the parked partial is stored after the barrier (a whole tile of
+    // time before the next s_waitcnt vmcnt(0) meets the stores) and the accumulators restart from zero.  The ordinary iteration is
+    // the key-split form's, instruction for instruction: r05c measured +7.5 % per launch when the two leaf cases were run-time
+    // branches inside it (profiles/r05_c_ab_leaves_layer_merge.txt, "2 leaves" against "per_launch": same arithmetic).
+    auto tile_iteration = [&](const int kt, auto kind_c) __attribute__((always_inline)) {
+        constexpr int KIND = (int)decltype(kind_c)::value;
+        constexpr bool LAST = KIND == 1, BOUNDARY = KIND == 2, RESTART = KIND == 3;
+        static_assert(MG || KIND <= 1, "leaf boundaries exist in the leaf form only");
         const int st = (PS ? u0 + kt - kt0 : kt - kt0) & 1;           // stage of V_kt; K_{kt+1} and compat_{kt+1} live in stage st ^ 1
         const bool has_next = !LAST && kt + 1 < kt1;
         if constexpr (PS) {
@@ -466,26 +475,20 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         if constexpr (PS) {
             if (pend) { store_pending(); pend = false; }      // (phase A does not touch the accumulators)
         }
-        if constexpr (MG) {
-            if (pend) {                                        // (workgroup-uniform) the leaf that ended with the previous tile
-                leaf_store(leaf_prev, m_prev, l_prev);
-                // zero IN PLACE (one asm statement per register, as scale_acc: a plain `o[c][r] = 0.f` inside this branch made the
-                // register allocator keep two copies of O and move one per tile -- 280 v_mov per iteration, +15 % per launch, r05a)
+        if constexpr (RESTART) {
+            leaf_store(leaf_prev, m_prev, l_prev);              // the leaf that ended with the previous tile
+            // zero IN PLACE (one asm statement per register, as scale_acc: plain assignments made the register allocator keep two
+            // copies of O and move one per tile when this sat behind a run-time branch, r05a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = o[c][r];
-                        asm volatile("v_mov_b32 %0, 0" : "+v"(v));
-                        o[c][r] = v;
-                    }
-                pend = false;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    float v = o[c][r];
+                    asm volatile("v_mov_b32 %0, 0" : "+v"(v));
+                    o[c][r] = v;
+                }
         }
-        // MG: tile kt + 1 starts a new leaf -> its logits are formed against a fresh reference (raw products, then their row maximum:
-        // bit for bit what the first-tile code above does for a workgroup that STARTS at that leaf)
-        const bool leaf_last = MG && !LAST && kt + 1 == leaf_end;
-        const float m_sub = leaf_last ? 0.f : m_run;
+        const float m_sub = BOUNDARY ? 0.f : m_run;
         if (CREG) {
             if (kt != kt0) {                     // (the loads issued one iteration ago have landed: vmcnt(0) above)
 #pragma unroll
@@ -603,12 +606,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 
         PDSC_TRACE_STAMP(6)                      // 6: phase B
         // ---- does tile kt+1 move the reference exponent of any query?  (rare after the first tiles) -------------
-        if (leaf_last) {
+        if constexpr (BOUNDARY) {
             // the finished leaf's state waits for the next iteration's barrier (leaf_store); the next leaf starts from nothing
             m_prev = m_run;
             l_prev = l_run + __shfl_xor(l_run, 32, 64);
             leaf_prev = leaf;
-            pend = true;
             if ((kt + 2) * SPL_BK > N) mask_tail(kt + 1, tl);
             m_run = row_max(tl);
 #pragma unroll
@@ -636,11 +638,27 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         }
         PDSC_TRACE_STAMP(7)
     };
-    if constexpr (PS || !PEEL) {
-        for (int kt = kt0; kt < kt1; ++kt) tile_iteration(kt, std::false_type{});
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    if constexpr (MG) {
+        // leaf by leaf (every leaf has at least two tiles: leaf_plan): [restart] ordinary ... ordinary, then boundary or last
+        int kt = kt0;
+        bool later = false;
+        for (;;) {
+            const bool final_leaf = leaf_end == kt1;
+            const int tail = (final_leaf ? kt1 : leaf_end) - 1;          // the tile the boundary / last iteration handles
+            if (later) { tile_iteration(kt, std::integral_constant<int, 3>{}); ++kt; }
+            for (; kt < tail; ++kt) tile_iteration(kt, K0{});
+            if (final_leaf) { tile_iteration(kt, K1{}); break; }
+            tile_iteration(kt, std::integral_constant<int, 2>{});
+            ++kt;
+            later = true;
+        }
+    } else if constexpr (PS || !PEEL) {
+        for (int kt = kt0; kt < kt1; ++kt) tile_iteration(kt, K0{});
     } else {
-        for (int kt = kt0; kt + 1 < kt1; ++kt) tile_iteration(kt, std::false_type{});
-        tile_iteration(kt1 - 1, std::true_type{});
+        for (int kt = kt0; kt + 1 < kt1; ++kt) tile_iteration(kt, K0{});
+        tile_iteration(kt1 - 1, K1{});
     }
 
     if constexpr (!PS) break;
@@ -843,7 +861,7 @@ void leaf_plan(int bs, int N, int leaves_mode, int* nw_out, int* nsplit_out, int
     split_plan(bs, N, &nw, &ns);
     const int tiles = spl_num_tiles(N);
     int C = leaves_mode == PDSC_LEAVES_CANONICAL ? attention_leaf_count(N) : leaves_mode;
-    if (C > tiles) C = tiles;
+    if (C > tiles / 2) C = tiles / 2;            // every leaf at least two tiles (the kernel's boundary and restart iterations are distinct)
     if (C > PDSC_ATT_MAX_LEAVES) C = PDSC_ATT_MAX_LEAVES;
     if (C < 1) C = 1;
     // the per-launch cost model over the divisors of C; a leaf that ends inside a workgroup's range costs about a third of a tile
@@ -895,8 +913,8 @@ int pdsc::launch_attention_leaves(const void* q_split, const void* kv_tiles, con
     int nw, ns, C;
     leaf_plan(bs, N, leaves_mode, &nw, &ns, &C);
     // ragged batches: every pair cuts ITS OWN tiles into C leaves -- the shortest pair needs at least C of them
-    PDSC_REQUIRE(!nvalid || (n_min + 31) / 32 >= C, "pdsc_sc_attention_leaves: the shortest pair (%d correspondences) has fewer 32-key tiles "
-                 "than the %d leaves planned for bs=%d, N=%d", n_min, C, bs, N);
+    PDSC_REQUIRE(!nvalid || (n_min + 31) / 32 >= 2 * C, "pdsc_sc_attention_leaves: the shortest pair (%d correspondences) has fewer than two "
+                 "32-key tiles for each of the %d leaves planned for bs=%d, N=%d", n_min, C, bs, N);
     const size_t need = (size_t)bs * C * round_up(N, 256) * (PDSC_CHANNELS + 2) * sizeof(float);
     if (scratch_bytes < need) {
         set_error("pdsc_sc_attention_leaves: scratch %zu < %zu bytes", scratch_bytes, need);

@@ -21,19 +21,7 @@
 
 namespace pdsc {
 
-// ---- exact fp32 sqrt / divide-by-invariant without the compiler's special-case scaffolding --------------
-// sqrt: hipcc lowers a correctly rounded sqrtf to v_sqrt_f32 followed by exactly this one-ulp test (plus input
-// scaling below 2^-96 and a zero/inf class check).  For x == 0 both residual tests fail and 0 is returned.
-__device__ __forceinline__ float sqrt_rn(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
-    const float su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rd = fmaf(-sd, s, x);
-    const float ru = fmaf(-su, s, x);
-    s = rd <= 0.0f ? sd : s;
-    s = ru > 0.0f ? su : s;
-    return s;
-}
+// (sqrt_rn: pdsc_common.h)
 struct InvariantDivisor {   // divide by the same b many times: hipcc's v_rcp + refinement, hoisted
     float b, y;
     __device__ __forceinline__ explicit InvariantDivisor(float b_) : b(b_) {

@@ -64,7 +64,6 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
         }
     }
     float best = MODE == 0 ? INFINITY : -INFINITY;
-    float best_lo = INFINITY;        // MODE 0: smallest radicand whose square root is `best`
     int best_j = 0x7fffffff;
     bool best_nan = false;
 
@@ -107,43 +106,32 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
             }
             // lane = source point l31; register r = target j0 + 32 sub + (r&3) + 8 (r>>2) + 4 h.  Ascending target order
             // within a lane is r = 0..15; the other half of the targets lives in lane + 32 (merged at the end).
-            // r05: the comparison runs on the RADICAND (2 - 2 dot + 1e-6: three fp32 operations instead of a correctly rounded
-            // square root per element -- the launch was bound by that vector work, not by its MFMAs).  sqrt is monotone, but two
-            // neighbouring radicands may share one square root, and the reference's arg-min takes the FIRST index among equal
-            // DISTANCES: so the lane keeps `best_lo` = the smallest radicand whose square root equals its best distance; a
-            // candidate at or above it cannot win (same distance, later index -- a lane walks its targets in ascending order),
-            // one below it is a strictly smaller distance.  The square root is taken only on that rare path (~ln N times per
-            // lane), and the result -- (distance, index) -- is the same pair the per-element form found.
+            // r05: the launch is bound by this vector work, not by its 16 MFMAs per block.  MODE 0: the correctly rounded square root
+            // without the library call's special-case scaffolding (sqrt_rn, pdsc_common.h: v_sqrt_f32 + the one-ulp residual test hipcc
+            // itself emits; radicands here are 1e-6 .. 4, or negative / NaN -> NaN like sqrtf), and a branch-free update: a NaN
+            // distance becomes -inf, which nothing beats afterwards (np.argmin: the first NaN wins) and is mapped back at the end.
+            // (Measured and dropped, profiles/r05_c_match_bench_radicand_branch.txt: comparing radicands and taking the square root
+            //  only on a new minimum -- with ~250 targets per workgroup some lane of the wave has a new minimum in nearly every step.)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float x = MODE == 0 ? (2.0f - 2.0f * acc[r]) + 1e-6f : acc[r];                  // reference arithmetic, fp32
-                const bool maybe = MODE == 0 ? !(x >= best_lo) : !(x <= best);                         // (a NaN always takes the slow path)
-                if (j < j_end && maybe) {
-                    const float d = MODE == 0 ? sqrtf(x) : x;
+                if (MODE == 0) {
+                    float d = sqrt_rn((2.0f - 2.0f * acc[r]) + 1e-6f);                                  // reference arithmetic, fp32
+                    d = d != d ? -INFINITY : d;
+                    const bool take = j < j_end && d < best;                                           // strict: the first index among equal distances
+                    best = take ? d : best;
+                    best_j = take ? j : best_j;
+                } else {
+                    const float d = acc[r];
                     const bool dn = d != d;
-                    const bool better = MODE == 0 ? d < best : d > best;
-                    const bool take = !best_nan && (dn || better || (d == best && j < best_j));
-                    if (take) {
-                        best = d; best_j = j; best_nan = dn;
-                        if (MODE == 0) {
-                            float lo = x;
-                            if (!dn) {
-                                for (;;) {                               // at most a few steps: sqrt maps ~2 neighbouring floats to one
-                                    if (!(lo > 0.f)) break;
-                                    const float p = __uint_as_float(__float_as_uint(lo) - 1u);
-                                    if (sqrtf(p) != d) break;
-                                    lo = p;
-                                }
-                            }
-                            best_lo = dn ? -INFINITY : lo;               // after a NaN nothing wins any more (np.argmin: the first NaN)
-                        }
-                    }
+                    const bool take = j < j_end && !best_nan && (dn || d > best || (d == best && j < best_j));
+                    if (take) { best = d; best_j = j; best_nan = dn; }
                 }
             }
         }
     }
     // merge the two halves of the targets, then the splits
+    if (MODE == 0) best_nan = best == -INFINITY;
     unsigned long long key = MODE == 0 ? match_key(best_nan ? NAN : best, best_j)
                                        : (((unsigned long long)ip_bits(best_nan ? NAN : best) << 32) | (unsigned int)best_j);
     const unsigned long long other = __shfl_xor(key, 32, 64);

@@ -254,4 +254,18 @@ __device__ inline void kabsch_from_covariance(const float* H32, const float* cA,
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
 }
 
+// ---- exact fp32 sqrt / divide-by-invariant without the compiler's special-case scaffolding --------------
+// sqrt: hipcc lowers a correctly rounded sqrtf to v_sqrt_f32 followed by exactly this one-ulp test (plus input
+// scaling below 2^-96 and a zero/inf class check).  For x == 0 both residual tests fail and 0 is returned.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+    const float su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x);
+    const float ru = fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    return s;
+}
+
 }  // namespace pdsc

@@ -637,7 +637,7 @@ struct KnnFusedArgs {
 __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long kf_dyn[];
     unsigned long long (*list)[KF_CAP] = reinterpret_cast<unsigned long long (*)[KF_CAP]>(kf_dyn);       // [KF_ROWS][KF_CAP]: 64 KiB (dynamic: past the static limit)
-    __shared__ unsigned long long tau[KF_ROWS];
+    __shared__ float tau[KF_ROWS];          // upper bound of the seed's (k+1)-th smallest DISTANCE (the distance part of the bound composite)
     __shared__ int cnt[KF_ROWS];
     __shared__ unsigned long long gmin[4][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
     const float* X = a.X + (size_t)b * a.NS * PDSC_CHANNELS;
     const int want = a.k + 1;
     const unsigned long long idx_mask = (1ULL << a.idx_bits) - 1ULL;
-    if (t < KF_ROWS) { tau[t] = ~0ULL; cnt[t] = 0; }
+    if (t < KF_ROWS) { tau[t] = INFINITY; cnt[t] = 0; }
 
     // A fragments of this lane's seed row (k-slot (4q+e, half h) <-> channel 8q+4h+e): identical in the four waves
     f32x4 af[16];
@@ -692,8 +692,10 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v = 2.0f - 2.0f * acc[r];                 // == reference `2 - 2*matmul` (gram_rows_kernel MODE 1)
-                const unsigned long long key = ((unsigned long long)float_order_bits(v) << a.idx_bits) | (unsigned)col;
-                if (r0 + row < a.S && key < tau[row]) {
+                // one float compare per element (a composite at or below the bound has a distance at or below the bound's: a
+                // superset passes, a NaN never does); the 64-bit composite is only built for what enters the list
+                if (v <= tau[row] && r0 + row < a.S) {
+                    const unsigned long long key = ((unsigned long long)float_order_bits(v) << a.idx_bits) | (unsigned)col;
                     const int slot = atomicAdd(&cnt[row], 1);
                     list[row][slot] = key;                            // slot < KF_CAP: a round adds at most 128 to a list of at most KF_CAP - 128
                 }
@@ -762,7 +764,11 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
                      (unsigned)__builtin_amdgcn_readlane((int)(cand & 0xffffffffULL), sl);
                 kept = want;
             }
-            if (lane == 0) { cnt[row] = kept; tau[row] = ub; }             // later composites enter only below the bound (they cannot equal it)
+            if (lane == 0) {
+                cnt[row] = kept;
+                const unsigned int ob = (unsigned int)(ub >> a.idx_bits);                          // float_order_bits of the bound's distance, inverted:
+                tau[row] = __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob);
+            }
         }
         __syncthreads();
     }

@@ -2159,6 +2159,36 @@ def test_ragged_batch_other_arithmetic_modes(sizes, gemm, fmt):
         model.layer_gemm, model.compat_format = LAYER_GEMM_DEFAULT, COMPAT_FORMAT_DEFAULT
 
 
+@pytest.mark.parametrize("leaves", ["canonical", "per_launch"])
+def test_forward_does_not_read_workspace_rows_it_did_not_write(leaves):
+    """ADVICE r04 (attention_split.hip: waves whose 32 queries all lie past a pair's last row return without writing their
+    partial rows): every consumer must stay inside the rows the producers wrote.  The whole workspace is filled with NaN bit
+    patterns between two identical forwards -- uniform batch with a ragged last tile, and a ragged batch -- and the results must
+    not move by a bit (a stale-row read would now ingest NaN instead of last launch's plausible numbers)."""
+    model, _ = _bench_model("n5000_b32")
+    try:
+        model.att_leaves = leaves
+        for data in ({k: g(v) for k, v in synthetic.make_batch(3, 4999, seed=812, inlier_ratio=0.3).items() if k in ("corr_pos", "src_keypts", "tgt_keypts")},
+                     _as_lists(_ragged_pairs((5000, 4777, 4100), 813, inlier_ratio=0.3))):
+            data["testing"] = True
+            with torch.no_grad():
+                first = model(data)
+                T = first["final_trans"].clone()
+                L = [x.clone() for x in first["final_labels"]] if isinstance(first["final_labels"], list) else first["final_labels"].clone()
+                torch.cuda.synchronize()
+                for ws in model._workspaces.values():
+                    ws[: ws.numel() // 4 * 4].view(torch.int32).fill_(0x7fc00001)          # quiet-NaN patterns everywhere
+                again = model(data)
+                torch.cuda.synchronize()
+            assert torch.equal(again["final_trans"].view(torch.int32), T.view(torch.int32))
+            if isinstance(L, list):
+                assert all(torch.equal(a, b) for a, b in zip(again["final_labels"], L))
+            else:
+                assert torch.equal(again["final_labels"], L)
+    finally:
+        model.att_leaves = LEAVES_DEFAULT
+
+
 def test_ragged_batch_padded_tensors_and_count_list():
     """The other calling form: tensors padded to the longest pair + data['num_corr']; padding rows hold garbage on purpose
     (NaN): nothing of a pair's result may depend on them; labels past a pair's count are zero.  Bit-identical to the list form."""

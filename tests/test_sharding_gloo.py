@@ -162,6 +162,37 @@ def test_eight_rank_bench_rehearsal_on_one_gpu(config, expect_per_rank):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config", ["n5000_b32", "kitti_n5000_b16"])
+def test_eight_rank_run_returns_the_one_rank_run_bit_for_bit_with_canonical_leaves(config):
+    """strong scaling must not change answers.  With att_leaves = "canonical" the attention's summation tree
+    depends on N alone, so the gathered poses of `bench.py --gpus 8` (4 or 2 pairs per rank, gloo rehearsal: 8 ranks on the one
+    visible GPU) carry the same SHA-256 as the one-process run of the same 32 / 16 pairs; with the per-launch key split the two
+    runs plan different splits and the fingerprints differ (both inside the contract)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    common = ["--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline", "--sustain-seconds", "0", "--settle-seconds", "0",
+              "--no-check"]
+    sha = {}
+    for leaves in ("canonical", "per_launch"):
+        one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--att-leaves", leaves] + common,
+                             capture_output=True, text=True, timeout=600, cwd=str(root))
+        assert one.returncode == 0, one.stderr[-3000:]
+        eight = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                                "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "8", "--backend", "gloo",
+                                "--att-leaves", leaves] + common, capture_output=True, text=True, timeout=600, cwd=str(root))
+        assert eight.returncode == 0, eight.stderr[-3000:]
+        lines = [json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) for r in (one, eight)]
+        assert lines[1]["n_gpus"] == 8 and lines[0]["config"]["global_batch"] == lines[1]["config"]["global_batch"]
+        sha[leaves] = [ln["config"]["gathered_poses_sha256_16"] for ln in lines]
+        assert all(sha[leaves])
+    assert sha["canonical"][0] == sha["canonical"][1], sha
+    assert sha["per_launch"][0] != sha["per_launch"][1], sha          # (what the canonical leaves are for)
+
+
+@pytest.mark.gpu
 def test_one_rank_bench_through_rccl():
     """`bench.py --gpus 1` launched the way the driver launches the N > 1 runs (torch.distributed.run, --backend nccl = RCCL) with ONE
     rank: the RCCL bring-up the multi-GPU runs depend on -- init_process_group(device_id=...), the barriers of the timing fence, the
