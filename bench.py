@@ -661,7 +661,8 @@ def main():
                         flipped = np.flatnonzero((got_lab[i].numpy() > 0) != (l32 > 0))
                         okx, why = census_mod.explain(f0 + i, {k: v[i] for k, v in timed_dec.items()}, ix,
                                                       {k: batch[k][i] for k in ("src_keypts", "tgt_keypts")}, float(kw["inlier_threshold"]),
-                                                      float(w["pair"]["scale"]), flipped if float(per["ref32"][0][i]) < 1e-4 else None)
+                                                      float(w["pair"]["scale"]), flipped if float(per["ref32"][0][i]) < 1e-4 else None,
+                                                      nms_radius=float(kw["nms_radius"]))
                         excused = (excused or bool(okx)) and bool(finite[i])
                     except Exception as e:  # noqa: BLE001
                         why = f"explain failed: {e!r}"

@@ -6,7 +6,7 @@ Run in the BUILD container only (imports the unmodified reference from /root/ref
     python oracle/make_census_internals.py n5000_b32 256 [--threads 4]    # -> tests/golden/census_internals_n5000_b32.npz
 
 For every pair of tests/golden/census_<name>.npz (oracle/make_census_goldens.py) the reference forward runs again, fp32 and
-fp64, with taps around three of its callables (wrappers installed at run time; no reference line is copied or edited):
+fp64, with taps around four of its callables (wrappers installed at run time; no reference line is copied or edited):
 
   * ``PointDSC.cal_seed_trans`` (models/PointDSC.py:234-336): its argument ``seeds`` and its return values
     ``seedwise_fitness`` (-> integer inlier counts ``round(fitness * N)``, :328) and the chosen hypothesis (:329-332);
@@ -14,6 +14,9 @@ fp64, with taps around three of its callables (wrappers installed at run time; n
     neighbour set, and -- recomputed by the tap with knn's own expression ``2 - 2 x x^T`` (models/common.py:60-61) on the seed rows,
     in the run's dtype -- the gap between the last neighbour kept and the first one left out (``topk`` boundary, :68): a seed
     whose gap is at round-off level has a neighbour set, hence a hypothesis, that round-off decides;
+  * ``PointDSC.pick_seeds`` (:199-217, r05): its argument ``scores`` -- the confidence logits.  When fewer than ``max_num`` keys
+    (logit x is_local_max) are positive the rest of the seed list comes from the keys tied at 0 in the order ``torch.argsort``
+    happens to leave them; the census recognises that regime from the recorded logits;
   * ``models.PointDSC.transform`` (the module-global bound at :6, called once per post-refinement iteration, :422): the warped
     source points, from which the tap recomputes ``L2_dis`` with the reference's own expression (:423) in the run's dtype and
     stores per iteration the inlier count (:424-425) and how close the nearest correspondence sits to the threshold
@@ -103,9 +106,18 @@ class Taps:
             self.knn_out = None
             return out
 
+        def pick_tap(dists, scores, R, max_num):
+            # models/PointDSC.py:174,199-217: the confidence logits the seeds are picked from (r05).  With fewer than max_num POSITIVE
+            # keys (key = logit x is_local_max, :211-216) the rest of the seed list is drawn from the keys tied at 0 in whatever order
+            # torch.argsort leaves them (probe 2): the census needs the logits to recognise that regime.
+            self.rec["conf"] = scores[0].double().numpy().astype(np.float32 if scores.dtype == torch.float32 else np.float64)
+            return self._orig_pick(dists, scores, R, max_num)
+
+        self._orig_pick = model.pick_seeds
         ref_module.transform = transform_tap
         ref_module.knn = knn_tap
         model.cal_seed_trans = cst_tap
+        model.pick_seeds = pick_tap
 
     def run(self, data):
         self.rec = {"refine_counts": [], "refine_margin": []}
@@ -118,6 +130,7 @@ class Taps:
         self.rp.transform = self._orig_transform
         self.rp.knn = self._orig_knn
         del self.model.cal_seed_trans
+        del self.model.pick_seeds
 
 
 def main():
@@ -148,7 +161,7 @@ def main():
     refine_thr = 0.10 if kw["inlier_threshold"] == 0.10 else 1.2           # models/PointDSC.py:415-418
 
     census = np.load(GOLDEN / f"census_{name}.npz", allow_pickle=False)
-    cache = Path("/tmp") / f"census_internals_cache_v2_{name}"
+    cache = Path("/tmp") / f"census_internals_cache_v3_{name}"
     cache.mkdir(exist_ok=True)
     n = w["num_corr"]
     S = int(n * kw["ratio"])
@@ -176,7 +189,7 @@ def main():
             k = len(rec["refine_counts"])
             rc[:k], rm[:k] = rec["refine_counts"], rec["refine_margin"]
             assert rec["seeds"].shape == (S,) and rec["counts"].shape == (S,)
-            out.update({f"knn_hash{tag}": rec["knn_hash"], f"knn_gap{tag}": rec["knn_gap"]})
+            out.update({f"knn_hash{tag}": rec["knn_hash"], f"knn_gap{tag}": rec["knn_gap"], f"conf{tag}": rec["conf"].astype(np.float32)})
             out.update({f"seeds{tag}": rec["seeds"], f"counts{tag}": rec["counts"], f"best{tag}": np.int32(rec["best"]),
                         f"initial_trans{tag}": rec["initial_trans"], f"refine_counts{tag}": rc, f"refine_margin{tag}": rm})
         np.savez(f, **out)
@@ -189,6 +202,7 @@ def main():
     total = census["ref32_final_trans"].shape[0]
     rows = [np.load(cache / f"{i}.npz") for i in range(total)]
     keys = [f"{k}{t}" for t in ("32", "64") for k in ("seeds", "counts", "best", "initial_trans", "refine_counts", "refine_margin", "knn_hash", "knn_gap")]
+    keys.append("conf32")                  # (fp32 logits only: 4 N bytes per pair)
     np.savez_compressed(GOLDEN / f"census_internals_{name}.npz", num_corr=np.int64(n), refine_threshold=np.float64(refine_thr),
                         input_checksum=census["input_checksum"], **{k: np.stack([r[k] for r in rows]) for k in keys})
     # summary for CENSUS_PINNING.json: how many pairs the reference itself decides by one vote

@@ -1295,7 +1295,8 @@ def test_bench_workload_matches_reference_golden(name, bs):
         for i in np.flatnonzero(~strict.numpy()).tolist():
             flipped = np.flatnonzero((res["final_labels"][i].cpu().numpy() > 0) != (l32[i] > 0))
             okx, why = mod.explain(i, {k: v[i] for k, v in dec.items()}, ix, {k: batch[k][i] for k in ("src_keypts", "tgt_keypts")},
-                                   float(w["model"]["inlier_threshold"]), float(w["pair"]["scale"]), flipped if float(d32[i]) < 1e-4 else None)
+                                   float(w["model"]["inlier_threshold"]), float(w["pair"]["scale"]), flipped if float(d32[i]) < 1e-4 else None,
+                                   nms_radius=float(w["model"]["nms_radius"]))
             assert okx or ill[i], (i, float(d32[i]), int(f32[i]), why)
     # every pair of the batch, golden or not, must register (well-conditioned workload) and be a rigid motion
     T = res["final_trans"].cpu().double()
