@@ -7,11 +7,23 @@
  * point per reference stage (so each stage can be parity-checked on its own) plus one whole-path call.
  * Every entry point cites the reference lines it replaces.
  *
+ * Two tiers (r05):
+ *   PRODUCT BOUNDARY -- what a caller of the reference's module needs: pdsc_forward_testing (+ _ragged, _streams),
+ *     pdsc_forward_validation; the weight packers pdsc_wpack_floats / _offset, pdsc_wsplit_bytes / _offset / _build; the workspace
+ *     queries pdsc_workspace_bytes / _offset; pdsc_encoder_range_probe; pdsc_version / pdsc_last_error; and, for the callers either
+ *     side of the path (SURVEY.md section 8 f-2 .. f-4), pdsc_match_* / pdsc_select_correspondences / pdsc_build_corr_pos,
+ *     pdsc_sm_baseline*, pdsc_cal_confidence, pdsc_eval_stats.
+ *   STAGE LEVEL -- one entry point per reference stage (sections a-1 .. a-11 below), the plan / size queries that go with them,
+ *     pdsc_selftest_* and the diagnostic hooks.  The forward does not go through them (it calls the same launchers directly); they
+ *     exist so that every stage can be parity-checked on its own (tests/test_gpu_parity.py), for the tools, and for a maintainer
+ *     who keeps the reference's module and swaps single stages.
+ *
  * Conventions
  *   - all pointers are DEVICE pointers (HIP, fp32 unless stated), caller-owned, never retained;
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it: no host
  *     synchronisation, no allocation (graph-capturable).  Results depend on the arguments only.  Process-global
- *     state is limited to: the per-(kernel, device) dynamic-LDS opt-in table (mutex-protected), the error string
+ *     state is limited to: the per-(kernel, device) dynamic-LDS opt-in table (mutex-protected), the per-device event that orders
+ *     opt-in register-resident spectral-matching launches (mutex-protected), the error string
  *     (thread-local), and the opt-in DIAGNOSTIC hooks -- pdsc_profile_* event timing, pdsc_attention_trace,
  *     pdsc_layer_trace -- which are process-wide switches and not thread-safe: use them from one thread.
  *     The product library reads NO environment variable: everything that selects a kernel or changes arithmetic is a field
@@ -33,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 5
+#define PDSC_VERSION 6
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32

@@ -1667,21 +1667,6 @@ def test_leaf_form_attention_is_deterministic_over_repeated_launches(name, bs, r
         model.att_leaves = LEAVES_DEFAULT
 
 
-def test_attention_leaf_plan_properties():
-    """Host-side plan of the leaf form: the canonical leaf count depends on N alone, never exceeds what the layer kernel merges
-    (8), leaves at least 4 tiles per leaf from 8 tiles on, and the key split of every batch size divides it."""
-    import ctypes as C
-    lib = _lib.load()
-    ns, nl = C.c_int(), C.c_int()
-    for n in (33, 257, 700, 1000, 1504, 1505, 2053, 5000, 10000, 12000, 20000, 36864):
-        leaves = lib.pdsc_attention_leaf_count(n)
-        tiles = (n + 31) // 32
-        assert 1 <= leaves <= 8 and (leaves == 1 or tiles // leaves >= 4), (n, leaves)
-        for bs in (1, 2, 3, 4, 8, 16, 32):
-            _lib.check(lib.pdsc_attention_leaf_plan(bs, n, 1, C.byref(ns), C.byref(nl)), "plan")
-            assert nl.value == leaves and leaves % ns.value == 0, (n, bs, ns.value, nl.value)
-
-
 def test_batched_forward_equals_per_pair_calls():
     c = case(1000)
     batch = synthetic.make_batch(3, 1000, seed=300, inlier_ratio=0.3)

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 cd /tmp
 SUMMARY=$OUT/${TAG}_summary.txt
 : > "$SUMMARY"
-FILTER="sc_attention compat layer_ knn_select seed_solve nms_ gram_rows"
+FILTER="sc_attention compat layer_ knn_select knn_fused normalize_conf seed_solve nms_ gram_rows"
 i=0
 for pass in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \

@@ -26,8 +26,16 @@ if [ -z "$QUICK" ]; then
   cp profiles/traffic.json "$OUT/${TAG}_traffic.json"
   cd "$ROOT"
 fi
-for c in $CONFIGS kitti_n12000_b4 multiway_n20000_b1; do      # (the last two: the reference's real evaluation sizes, r04)
+for c in $CONFIGS kitti_n12000_b4 multiway_n20000_b1 trained_n5000_b32 trained_n1000_b1 trained_kitti_n5000_b16; do      # (r04: the reference's real evaluation sizes; r05: trained-like weights)
+  [ -f "$ROOT/tests/golden/bench_$c.npz" ] || continue
   timeout 400 python bench.py --config $c > "$OUT/${TAG}_bench_$c.log" 2>&1; tail -1 "$OUT/${TAG}_bench_$c.log" > "$OUT/${TAG}_bench_line_$c.json"
+done
+# r05: the same headline configuration with the per-launch key split (the fastest form: a pair's bits then depend on its batch), and the
+# number an unchanged caller sees: one pair per call, result read back (bench.py --latency)
+timeout 300 python bench.py --config n5000_b32 --att-leaves per_launch --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_n5000_b32_per_launch_leaves.json"
+for s in n5000_b32:1 n1000_b1:1 trained_n1000_b1:1 lomatch_n10000_b8:1; do
+  c=${s%%:*}
+  timeout 300 python bench.py --config $c --global-batch 1 --latency --no-cpu-baseline --steps 200 --warmup 20 --sustain-seconds 1 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_${c}_latency_1pair.json"
 done
 SHARES="n5000_b32:16 n5000_b32:8 n5000_b32:4 kitti_n5000_b16:8 kitti_n5000_b16:4 kitti_n5000_b16:2 lomatch_n10000_b8:4 lomatch_n10000_b8:2 lomatch_n10000_b8:1"
 if [ -z "$QUICK" ]; then
@@ -35,7 +43,8 @@ if [ -z "$QUICK" ]; then
     c=${s%%:*}; B=${s##*:}
     timeout 300 python bench.py --config $c --global-batch $B --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_${c}_${B}pairs.json"
   done
-  timeout 900 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
+  timeout 1200 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
+  timeout 900 python tools/parity_census.py --batches 0 --att-leaves per_launch > "$OUT/${TAG}_parity_census_per_launch_leaves.txt" 2>&1
   timeout 900 python tools/parity_census.py --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
   timeout 300 tools/pk_f32_repro.bin 5000 pointdsc_amd/libpointdsc_hip.so none,att,att32,mfma > "$OUT/${TAG}_pk_f32_repro.txt" 2>&1
   timeout 300 python tools/attention_power.py --seconds 5 > "$OUT/${TAG}_attention_power.txt" 2>&1
@@ -57,6 +66,7 @@ if [ -z "$QUICK" ]; then
   timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_probe.py > "$OUT/${TAG}_rccl_probe.txt" 2>&1
   timeout 300 python tools/graph_probe.py --config n1000_b1 --iters 1000 > "$OUT/${TAG}_graph_probe.txt" 2>&1
   timeout 200 python tools/match_bench.py > "$OUT/${TAG}_match_bench.txt" 2>&1
+  bash tools/gpu_run.sh ${TAG}_x knn_bench > /dev/null 2>&1; cp "$OUT/${TAG}_x/knn_bench.txt" "$OUT/${TAG}_knn_bench.txt" 2>/dev/null
   timeout 200 python tools/sm_bench.py > "$OUT/${TAG}_sm_bench.txt" 2>&1
   timeout 200 python tools/overlap_probe.py --n 5000 --bs 32 --steps 40 > "$OUT/${TAG}_overlap_probe.txt" 2>&1
   timeout 200 python tools/overlap_probe.py --n 5000 --bs 4 --steps 200 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1

@@ -16,7 +16,8 @@ from pathlib import Path
 SHORT = {"sc_attention_split_kernel": "sc_attention_split_kernel", "compat_sym_u16_kernel": "compat_sym_u16_kernel",
          "compat_sym_kernel": "compat_sym_kernel", "layer_h3_kernel<true, true": "layer_h3_kernel", "layer_h3_coop_kernel<true, true": "layer_h3_coop_kernel",
          "layer_wave_kernel<true, true": "layer_wave_kernel", "layer_fused_kernel<true, true": "layer_fused_kernel",
-         "gram_rows_kernel": "gram_rows_kernel", "knn_select_kernel": "knn_select_kernel", "seed_solve_kernel": "seed_solve_kernel"}
+         "gram_rows_kernel": "gram_rows_kernel", "knn_select_kernel": "knn_select_kernel", "knn_fused_kernel": "knn_fused_kernel",
+         "seed_solve_kernel": "seed_solve_kernel"}
 
 
 def main():
