@@ -1384,7 +1384,7 @@ def test_parity_census_trained_like_weights(name, step, arith):
     +-0.02 of seeded weights), inlier ratios cycling 5 / 10 / 20 / 40 %.  Same rules as test_parity_census with one more: in this regime
     top-k boundary gaps are not at round-off level, so NO pair may need the `knn-tie` rule.  Also checked: the Registration-Recall
     surrogate -- the reference's success / RE / TE columns (libs/loss.py:44-51) and this run's agree on every pair (success equal,
-    RE within 0.01 deg, TE within 0.01 cm x scale) -- with the shipped arithmetic and with the exact-fp32 mode."""
+    RE within 0.1 deg, TE within 0.01 cm x scale) -- with the shipped arithmetic and with the exact-fp32 mode."""
     if not (GOLDEN / f"census_{name}.npz").exists():
         pytest.skip(f"tests/golden/census_{name}.npz not generated")
     model, _ = _bench_model(name)
@@ -1409,7 +1409,10 @@ def test_parity_census_trained_like_weights(name, step, arith):
     scale = float(workloads.WORKLOADS[name]["pair"]["scale"]) / 3.0
     strict_idx = set(range(r["pairs"])) - set(r["outside_fp32_contract"])
     if len(strict_idx) == r["pairs"]:
-        assert reg["max_abs_RE_diff_deg"] < 0.01 and reg["max_abs_TE_diff_cm"] < 0.01 * scale * 3.0, reg
+        # (RE = acos((tr - 1) / 2) at angles of 0.01 .. 0.05 deg: d(angle) = d(trace) / (2 sin(angle)) turns an fp32 ulp of the trace
+        #  into several 1e-2 deg in the reference's number and in this one alike -- the column is compared at the 0.1 deg the
+        #  reference's evaluation tables print)
+        assert reg["max_abs_RE_diff_deg"] < 0.1 and reg["max_abs_TE_diff_cm"] < 0.01 * scale * 3.0, reg
 
 
 @pytest.mark.parametrize("fmt", ["f32", "u16"])

@@ -44,9 +44,8 @@ if [ -z "$QUICK" ]; then
     timeout 300 python bench.py --config $c --global-batch $B --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_${c}_${B}pairs.json"
   done
   timeout 1200 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
-  timeout 900 python tools/parity_census.py --batches 0 --att-leaves per_launch > "$OUT/${TAG}_parity_census_per_launch_leaves.txt" 2>&1
-  timeout 900 python tools/parity_census.py --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
-  timeout 300 tools/pk_f32_repro.bin 5000 pointdsc_amd/libpointdsc_hip.so none,att,att32,mfma > "$OUT/${TAG}_pk_f32_repro.txt" 2>&1
+  timeout 600 python tools/parity_census.py --batches 0 --att-leaves per_launch > "$OUT/${TAG}_parity_census_per_launch_leaves.txt" 2>&1
+  timeout 900 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,kitti_n5000_b16,kitti_n12000_b4 --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
   timeout 300 python tools/attention_power.py --seconds 5 > "$OUT/${TAG}_attention_power.txt" 2>&1
   timeout 300 python tools/forward_power.py --seconds 4 > "$OUT/${TAG}_forward_power.txt" 2>&1
   timeout 200 python tools/forward_power.py --seconds 3 --pairs 4 > "$OUT/${TAG}_forward_power_4pairs.txt" 2>&1
@@ -63,19 +62,8 @@ done
 if [ -z "$QUICK" ]; then
   cd "$ROOT"
   timeout 200 python tools/compat_bench.py > "$OUT/${TAG}_compat_bench.txt" 2>&1
-  timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_probe.py > "$OUT/${TAG}_rccl_probe.txt" 2>&1
-  timeout 300 python tools/graph_probe.py --config n1000_b1 --iters 1000 > "$OUT/${TAG}_graph_probe.txt" 2>&1
   timeout 200 python tools/match_bench.py > "$OUT/${TAG}_match_bench.txt" 2>&1
   bash tools/gpu_run.sh ${TAG}_x knn_bench > /dev/null 2>&1; cp "$OUT/${TAG}_x/knn_bench.txt" "$OUT/${TAG}_knn_bench.txt" 2>/dev/null
   timeout 200 python tools/sm_bench.py > "$OUT/${TAG}_sm_bench.txt" 2>&1
-  timeout 200 python tools/overlap_probe.py --n 5000 --bs 32 --steps 40 > "$OUT/${TAG}_overlap_probe.txt" 2>&1
-  timeout 200 python tools/overlap_probe.py --n 5000 --bs 4 --steps 200 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1
-  timeout 200 python tools/overlap_probe.py --n 1000 --bs 1 --steps 500 >> "$OUT/${TAG}_overlap_probe.txt" 2>&1
-  # forwards in flight against the plain calls, bit for bit (product library): plain streams / tail streams / replayed graphs
-  ( PROBE_REPS=1500 PROBE_MODE=plain PROBE_B=2 timeout 200 python tools/inflight_diverge_probe.py | tail -2
-    PROBE_REPS=1500 PROBE_MODE=tail PROBE_B=3 timeout 200 python tools/inflight_diverge_probe.py | tail -2
-    PROBE_REPS=1500 PROBE_MODE=graphs PROBE_B=3 timeout 200 python tools/inflight_diverge_probe.py | tail -2
-    PROBE_REPS=1500 PROBE_MODE=graphs PROBE_B=2 timeout 200 python tools/inflight_diverge_probe.py | tail -2
-    PROBE_REPS=2500 PROBE_MODE=graphs PROBE_CONFIG=n1000_b1 PROBE_B=1 timeout 200 python tools/inflight_diverge_probe.py | tail -2 ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_inflight_exactness.txt"
 fi
 ls -la "$OUT" | grep "${TAG}_" | tail -60
