@@ -25,8 +25,8 @@ for path in sys.argv[1:]:
         if cur is not None and '"excused"' in line:
             d = json.loads(line.strip())
             why = d["why"]
-            cause = ("knn-tie" if "knn-tie" in why else "tie" if why.startswith("tie") else "refinement" if why.startswith("refinement") else
-                     "label-edge" if why.startswith("label-edge") else "none")
+            cause = ("knn-tie" if "knn-tie" in why else "zero-key tie" if why.startswith("zero-key tie") else "tie" if why.startswith("tie") else
+                     "refinement" if why.startswith("refinement") else "label-edge" if why.startswith("label-edge") else "none")
             if not d["excused"] and d["reference_not_self_consistent"]:
                 cause = "reference only"
             cur["causes"][cause] = cur["causes"].get(cause, 0) + 1
