@@ -151,6 +151,14 @@ def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None,
     if g_corr != r_corr:
         pos = np.flatnonzero(seeds_r == g_corr)
         gpos = np.flatnonzero(dec["seeds"] == r_corr)
+        if nms_radius is not None and "conf32" in getattr(ix, "files", ()):
+            # named first when it applies: with keys tied at zero the ORDER of the reference's seed list -- hence which of several
+            # equally supported hypotheses its first-maximum rule picks -- is torch.argsort's, whether or not both lists happen to
+            # contain both correspondences
+            applies, text = zero_key_tie(ix, i, dec, batch_row, nms_radius)
+            gmax, rmax = int(dec["counts"].max()), int(counts_r.max())
+            if applies and gmax >= rmax - 1:
+                return True, text + f"; votes here {gmax}, reference {rmax}"
         if len(pos) == 0 or len(gpos) == 0:
             # the two seed LISTS differ.  Legitimate only in the regime where the reference's own list is backend-defined (keys tied at 0)
             # AND the hypothesis found here is as well supported as the reference's: its vote count within one of the reference's maximum
