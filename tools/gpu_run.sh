@@ -121,6 +121,31 @@ PY
   cat "$OUT/knn_bench.txt" ;;
 match_bench)
   timeout 300 python tools/match_bench.py > "$OUT/match_bench.txt" 2>&1; cat "$OUT/match_bench.txt" ;;
+kitti_stage_trained)
+  for K in "" "--compat-format f32" "--layer-gemm f32" "--compat-format f32 --layer-gemm f32" "--attention-precision fp32 --compat-format f32"; do
+    echo "== overrides: [$K]" >> "$OUT/kitti_stage_trained.txt"
+    timeout 600 python tools/parity_census.py --families trained_kitti_n5000_b16 --batches 16 $K 2>&1 | grep -E "^trained|outside the fp32|\"pair\"" | cut -c1-520 >> "$OUT/kitti_stage_trained.txt"
+  done
+  python - >> "$OUT/kitti_stage_trained.txt" 2>&1 <<'PY'
+# logits of pair 50 under each arithmetic against the reference's recorded fp32 logits (census_internals conf32)
+import numpy as np, torch
+from pointdsc_amd import PointDSC, workloads
+name = "trained_kitti_n5000_b16"; w = workloads.WORKLOADS[name]
+ix = np.load(f"tests/golden/census_internals_{name}.npz")
+model = PointDSC(**w["model"]); model.load_state_dict(workloads.state_dict(name, model.state_dict())); model = model.eval().cuda()
+for i in (50, 0, 7):
+    one = workloads.batch(name, i, 1)
+    data = {k: one[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}; data["testing"] = True
+    ref = ix["conf32"][i]
+    for att, cf, lg in (("bf16x3", "u16", "h3"), ("bf16x3", "f32", "h3"), ("bf16x3", "u16", "f32"), ("bf16x3", "f32", "f32"), ("fp32", "f32", "f32")):
+        model.attention_precision, model.compat_format, model.layer_gemm = att, cf, lg
+        with torch.no_grad(): model(data)
+        conf = model.workspace_view("conf", 1, w["num_corr"]).cpu().numpy()[: w["num_corr"]]
+        top = np.argsort(-ref)[:8]
+        print(f"pair {i} attention {att} compat {cf} layer {lg}: max |logit - reference| {np.abs(conf - ref).max():.3e} (relative to max |logit| {np.abs(ref).max():.1f}: {np.abs(conf - ref).max() / np.abs(ref).max():.1e}); "
+              f"top-8 by the reference {top.tolist()} here {np.argsort(-conf)[:8].tolist()}")
+PY
+  cat "$OUT/kitti_stage_trained.txt" | cut -c1-330 ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
