@@ -631,6 +631,7 @@ struct KnnFusedArgs {
     const int* seeds;        // [bs][S]
     int* knn_idx;            // [bs][S][k]
     int NS, S, k, idx_bits;
+    int bs, nrb;             // pairs, seed blocks of KF_ROWS per pair (grid = bs * nrb workgroups, see the block map in the kernel)
     const int* nvalid;       // ragged batches: [bs] rows per pair, or NULL
 };
 
@@ -641,7 +642,23 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(KnnFusedArgs a) {
     __shared__ int cnt[KF_ROWS];
     __shared__ unsigned long long gmin[4][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, r0 = blockIdx.x * KF_ROWS;
+    // block -> (pair, seed block).  Consecutive workgroup ids go round the eight XCDs (each with its own L2), and every workgroup of
+    // a pair streams that pair's whole 2.5 MB of normalised rows: with the plain (x, y) grid each XCD fetched every pair (PMC, r05
+    // bundle: 815 MB of HBM traffic against 82 MB of operands).  With a batch that is a multiple of 8, XCD x takes the pairs
+    // x, x + 8, ...: a pair's seed blocks share one L2 and walk the columns in step.
+    int b, rb;
+    {
+        const int nrb = a.nrb, L = blockIdx.x;
+        if ((a.bs & 7) == 0) {
+            const int xcd = L & 7, idx = L >> 3;
+            b = xcd + 8 * (idx / nrb);
+            rb = idx % nrb;
+        } else {
+            b = L / nrb;
+            rb = L % nrb;
+        }
+    }
+    const int r0 = rb * KF_ROWS;
     const int N = a.nvalid ? a.nvalid[b] : a.NS;
     const float* X = a.X + (size_t)b * a.NS * PDSC_CHANNELS;
     const int want = a.k + 1;
@@ -822,7 +839,8 @@ int launch_knn_seeds_form(const float* normed, const float* normed_pf, const int
         const size_t lds_bytes = (size_t)KF_ROWS * KF_CAP * sizeof(unsigned long long);
         const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_fused_kernel), lds_bytes, "pdsc_knn_seeds(fused, dynamic LDS)");
         if (rc_lds != PDSC_OK) return rc_lds;
-        hipLaunchKernelGGL(knn_fused_kernel, dim3(ceil_div(S, KF_ROWS), bs), dim3(256), lds_bytes, st, a);
+        a.bs = bs; a.nrb = ceil_div(S, KF_ROWS);
+        hipLaunchKernelGGL(knn_fused_kernel, dim3((unsigned)(a.nrb * bs)), dim3(256), lds_bytes, st, a);
         return check_launch("pdsc_knn_seeds(fused)");
     }
 
