@@ -14,7 +14,7 @@ struct AttArgs {
     int N, Npad, nsplit, num_tiles;
 };
 
-// arguments of the split-precision kernels (attention_split.hip, attention_wide.hip)
+// arguments of the split-precision kernels (attention_split.hip)
 struct AttSplitArgs {
     const __bf16* qs;             // [bs*N][256]  (hi | lo), q pre-scaled by log2(e)/sqrt(C)
     const unsigned char* kv;     // [bs][num_tiles][32 KiB]
@@ -35,7 +35,6 @@ struct AttSplitArgs {
     int nleaf;                   // leaves per pair (a multiple of nsplit; <= the tile count of the shortest pair)
 };
 
-int launch_attention_wide(const AttSplitArgs& a, unsigned grid, hipStream_t st);
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

@@ -1039,21 +1039,6 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
     int rc = PDSC_OK;
     const bool trace = nw == 8 && a.trace;
     (void)trace;
-#ifdef PDSC_EXPERIMENTS
-    // A/B knob PDSC_ATT_WIDE = 1: the one-wave-per-SIMD, 64-queries-per-wave variant (attention_wide.hip) where the plan
-    // picks the 8-wave kernel
-    if (nw == 8 && !c16 && !creg && !trace && !a.part_frag && !nvalid && env_int("PDSC_ATT_WIDE", 0)) {
-        rc = launch_attention_wide(a, grid, st);
-        if (rc != PDSC_OK) return rc;
-        if (nsplit > 1 && msg) {
-            AttArgs c{};
-            c.msg = msg; c.part_o = a.part_o; c.part_ml = a.part_ml;
-            c.N = N; c.Npad = a.Npad; c.nsplit = nsplit; c.num_tiles = tiles;
-            rc = launch_attention_combine(c, bs, st);
-        }
-        return rc;
-    }
-#endif
     a.items = (int)grid;
 #ifdef PDSC_EXPERIMENTS
     // A/B knob PDSC_ATT_PERSIST = 1: one workgroup per CU walking its items (point-fragment partials, 8-wave plan, whole

@@ -1423,7 +1423,8 @@ def test_forward_is_bit_identical_with_row_order_and_point_fragment_hand_offs(na
     labels agree bit for bit, with either storage format of the spatial-consistency matrix."""
     model, _ = _bench_model(name)
     batch = workloads.batch(name, 0, bs)
-    model.compat_format, model.layer_gemm = fmt, "h3"
+    # (the per-launch key split: the row-order hand-off exists in that form only -- the leaf form is point-fragment by construction)
+    model.compat_format, model.layer_gemm, model.att_leaves = fmt, "h3", "per_launch"
     out = []
     try:
         envs = ({}, {"PDSC_LAYER_PF": "0"}, {"PDSC_LAYER_H3_VARIANT": "0"}) if _lib.load().pdsc_experiments_enabled() else ({}, {})
@@ -1435,7 +1436,7 @@ def test_forward_is_bit_identical_with_row_order_and_point_fragment_hand_offs(na
             for k in env:
                 monkeypatch.delenv(k)
     finally:
-        model.compat_format, model.layer_gemm = COMPAT_FORMAT_DEFAULT, LAYER_GEMM_DEFAULT
+        model.compat_format, model.layer_gemm, model.att_leaves = COMPAT_FORMAT_DEFAULT, LAYER_GEMM_DEFAULT, LEAVES_DEFAULT
     for T, L in out[1:]:
         assert torch.equal(T, out[0][0]) and torch.equal(L, out[0][1])
     for i in range(bs):

@@ -5,7 +5,7 @@
 
 Runs the split-precision attention launch back to back for --seconds on (a) random operands, (b) all-zero operands (same
 instruction stream, no data toggling: MI355X_MICROARCH.md "DVFS give-back"), optionally (c) the 64-queries-per-wave record kernel
-(experiments library, PDSC_ATT_WIDE=1), while a sampler thread reads the socket power and the shader clock every ~20 ms from
+(the r01-r04 record kernel `sc_attention_wide_kernel` was removed in r05: profiles/HISTORY.md), while a sampler thread reads the socket power and the shader clock every ~20 ms from
 sysfs (hwmon power1_average / power1_input, freq1_input) or, failing that, `amd-smi metric` / `rocm-smi`.  For every arm it
 prints launches/s, executed TFLOP/s (3 bf16 MFMAs per algorithmic product), mean / max power, mean shader clock, and the
 ENERGY PER EXECUTED MFMA (joules per v_mfma_f32_32x32x16_bf16 wave-instruction) -- the figure that says whether two forms of the
@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--n", type=int, default=5000)
     ap.add_argument("--bs", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=3.0)
-    ap.add_argument("--wide", action="store_true", help="also the 64-queries-per-wave record kernel (experiments library)")
+    ap.add_argument("--wide", action="store_true", help="also the split kernel on the fp32 matrix")
     a = ap.parse_args()
     if a.wide:
         os.environ.setdefault("POINTDSC_HIP_LIB", str(ROOT / "pointdsc_amd" / "libpointdsc_hip_exp.so"))
@@ -189,11 +189,7 @@ def main():
             calibrate(lambda: ops.sc_attention_split(qs, kv, c16, bs, n))
         out.append(arm(f"split kernel, unorm16 matrix, {label} operands", lambda: ops.sc_attention_split(qs, kv, c16, bs, n), a.seconds, flops_exec, mfma))
         if a.wide:
-            os.environ["PDSC_ATT_WIDE"] = "0"
             out.append(arm(f"split kernel, fp32 matrix, {label} operands", lambda: ops.sc_attention_split(qs, kv, c32, bs, n), a.seconds, flops_exec, mfma))
-            os.environ["PDSC_ATT_WIDE"] = "1"
-            out.append(arm(f"64-query (wide) kernel, fp32 matrix, {label} operands", lambda: ops.sc_attention_split(qs, kv, c32, bs, n), a.seconds, flops_exec, mfma))
-            os.environ["PDSC_ATT_WIDE"] = "0"
     idle = Sampler()
     time.sleep(0.5)
     pw, ck = idle.read_once()
