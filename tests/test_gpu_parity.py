@@ -2125,6 +2125,27 @@ def test_ragged_batch_equals_the_single_pair_calls(sizes):
         assert loose <= 1, loose
 
 
+def test_large_ragged_batch_is_bitwise_the_single_pair_calls_with_canonical_leaves():
+    """24 pairs of 4100 .. 5333 correspondences in one ragged call: the batch takes the fused kNN (24 x 17 workgroups of 32 seeds) and
+    the leaf-form attention with every pair cutting ITS OWN tiles into the leaf count of the longest pair; the single-pair calls take
+    the two-launch kNN and their own plan.  With canonical leaves (same leaf count on both sides: all sizes > 1504) every pair's
+    pose and mask are BIT-IDENTICAL to its own call -- the reference's semantics (one pair per call) at batch throughput."""
+    model, _ = _bench_model("n5000_b32")
+    sizes = [5333, 5000, 4999, 4100] + [4100 + 53 * i for i in range(20)]
+    pairs = _ragged_pairs(sizes, 1700, inlier_ratio=0.3)
+    try:
+        model.att_leaves = "canonical"
+        with torch.no_grad():
+            got = model(_as_lists(pairs))
+            torch.cuda.synchronize()
+            for i, p in enumerate(pairs):
+                one = _forward(model, p)
+                assert torch.equal(got["final_trans"][i].view(torch.int32), one["final_trans"][0].view(torch.int32)), (i, sizes[i])
+                assert torch.equal(got["final_labels"][i], one["final_labels"][0]), (i, sizes[i])
+    finally:
+        model.att_leaves = LEAVES_DEFAULT
+
+
 @pytest.mark.parametrize("sizes,gemm,fmt", [((1000, 777, 640, 999), "f32", "f32"), ((3000, 4100, 5000, 5333), "f32", "u16"),
                                             ((2053, 2600), "h3", "f32")])
 def test_ragged_batch_other_arithmetic_modes(sizes, gemm, fmt):

@@ -44,7 +44,7 @@ PY
 for STEP in "$@"; do
 case $STEP in
 newtests)
-  timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q --tb=short -k "leaves or leaf or resident or trained or knn_fused or did_not_write" 2>&1 | tail -40 > "$OUT/newtests.txt"
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q --tb=short -k "leaves or leaf or resident or trained or knn_fused or did_not_write or large_ragged" 2>&1 | tail -40 > "$OUT/newtests.txt"
   tail -5 "$OUT/newtests.txt" ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60 > "$OUT/pytest_gpu.txt"
