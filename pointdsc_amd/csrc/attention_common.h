@@ -16,7 +16,7 @@ struct AttArgs {
 
 // arguments of the split-precision kernels (attention_split.hip)
 struct AttSplitArgs {
-    const __bf16* qs;             // [bs*N][256]  (hi | lo), q pre-scaled by log2(e)/sqrt(C)
+    const sp16* qs;             // [bs*N][256]  (hi | lo), q pre-scaled by log2(e)/sqrt(C)
     const unsigned char* kv;     // [bs][num_tiles][32 KiB]
     const void* compat;          // [bs][N][ld] fp32, or (C16) unorm16 in the tile order of pdsc_spatial_compat_u16
     long long ld;

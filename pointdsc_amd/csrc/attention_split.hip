@@ -264,14 +264,14 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
     if (kt0 + 1 < kt1) { dma_k(kt0 + 1); dma_c(kt0 + 1); }
     if (CREG) creg_load(kt0 + 1, cnext);
     dma_v(kt0);
-    bf16x8 qh[8], ql[8];
+    sp16x8 qh[8], ql[8];
     auto load_q = [&](int pair, int qblock) {
         const int qrow = min(qblock * (NW * 32) + wave * 32 + l31, N - 1);
-        const __bf16* qsrc = a.qs + ((size_t)pair * NS + qrow) * SPL_Q_LD + 8 * h;
+        const sp16* qsrc = a.qs + ((size_t)pair * NS + qrow) * SPL_Q_LD + 8 * h;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            qh[j] = *reinterpret_cast<const bf16x8*>(qsrc + 16 * j);
-            ql[j] = *reinterpret_cast<const bf16x8*>(qsrc + PDSC_CHANNELS + 16 * j);
+            qh[j] = *reinterpret_cast<const sp16x8*>(qsrc + 16 * j);
+            ql[j] = *reinterpret_cast<const sp16x8*>(qsrc + PDSC_CHANNELS + 16 * j);
         }
     };
     load_q(b, qb);
@@ -394,11 +394,11 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         const unsigned char* C0 = PS ? Cs + (u0 & 1) * CSTAGE : Cs;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * j);
-            const bf16x8 fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * j);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
+            const sp16x8 fh = *reinterpret_cast<const sp16x8*>(K + SPL_KH + koff + 1024 * j);
+            const sp16x8 fl = *reinterpret_cast<const sp16x8*>(K + SPL_KL + koff + 1024 * j);
+            sacc = PDSC_MFMA_X3(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
+            sacc = PDSC_MFMA_X3(fh, ql[j], sacc, 0, 0, 0);
+            sacc = PDSC_MFMA_X3(fh, qh[j], sacc, 0, 0, 0);
         }
         if (C16) {
             unsigned w[8];
@@ -510,36 +510,33 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             // fragments one step ahead of their MFMAs, and the steps pinned in source order: with the chunk-major image every
             // read is `base + immediate`, and left to itself the scheduler hoists all sixteen to the top of the iteration and
             // clusters the MFMAs behind them (measured: +7 % per launch)
-            bf16x8 fh = {}, fl = {};
+            sp16x8 fh = {}, fl = {};
             if constexpr (!LAST) {
-                fh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff);
-                fl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff);
+                fh = *reinterpret_cast<const sp16x8*>(K + SPL_KH + koff);
+                fl = *reinterpret_cast<const sp16x8*>(K + SPL_KL + koff);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                bf16x8 nh = fh, nl = fl;
+                sp16x8 nh = fh, nl = fl;
                 if constexpr (!LAST) {
                     if (j + 1 < 8) {
-                        nh = *reinterpret_cast<const bf16x8*>(K + SPL_KH + koff + 1024 * (j + 1));
-                        nl = *reinterpret_cast<const bf16x8*>(K + SPL_KL + koff + 1024 * (j + 1));
+                        nh = *reinterpret_cast<const sp16x8*>(K + SPL_KH + koff + 1024 * (j + 1));
+                        nl = *reinterpret_cast<const sp16x8*>(K + SPL_KL + koff + 1024 * (j + 1));
                     }
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[j], sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[j], sacc, 0, 0, 0);
+                    sacc = PDSC_MFMA_X3(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
+                    sacc = PDSC_MFMA_X3(fh, ql[j], sacc, 0, 0, 0);
+                    sacc = PDSC_MFMA_X3(fh, qh[j], sacc, 0, 0, 0);
                     if (j < DMA_SLOTS) dma_slot(kt, st, j);
                 }
                 {
-                    // p values 2j, 2j+1 = one 32-bit word of the P operands: split as a PAIR (split_layout.h split_bf16 arithmetic:
+                    // p values 2j, 2j+1 = one 32-bit word of the P operands: split as a PAIR (split_layout.h split_sp16 arithmetic:
                     // hi = bf16(p), lo = bf16(p - hi), round to nearest even) -- one v_cvt_pk_bf16_f32 per plane and pair, where the
                     // element-wise form converted every hi twice (16 of the loop's ~130 vector instructions per tile)
                     const float p0 = __builtin_amdgcn_exp2f(tl[2 * j]), p1 = __builtin_amdgcn_exp2f(tl[2 * j + 1]);
                     psum += p0;
                     psum += p1;
-                    typedef float pf2 __attribute__((ext_vector_type(2)));
-                    typedef __bf16 pb2 __attribute__((ext_vector_type(2)));
-                    const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(pf2{p0, p1}, pb2));
-                    const float h0 = __builtin_bit_cast(float, hw << 16), h1 = __builtin_bit_cast(float, hw & 0xffff0000u);
-                    const unsigned lw = __builtin_bit_cast(unsigned, __builtin_convertvector(pf2{p0 - h0, p1 - h1}, pb2));
+                    unsigned hw, lw;
+                    split_sp16_pair(p0, p1, hw, lw);
                     phw[j >> 2][j & 3] = hw;
                     plw[j >> 2][j & 3] = lw;
                 }
@@ -556,21 +553,21 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             const unsigned char* Cn = Cs + (st ^ 1) * CSTAGE + crow_off;
             unsigned cw[8];
             mx_next = -INFINITY;                 // row maximum of tile kt+1's logits, gathered as they are formed
-            bf16x8 vh = *reinterpret_cast<const bf16x8*>(V + voff);
-            bf16x8 vl = *reinterpret_cast<const bf16x8*>(V + SPL_V_PLANE + voff);
+            sp16x8 vh = *reinterpret_cast<const sp16x8*>(V + voff);
+            sp16x8 vl = *reinterpret_cast<const sp16x8*>(V + SPL_V_PLANE + voff);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = u >> 1, j = u & 1;
-                bf16x8 nvh = vh, nvl = vl;
+                sp16x8 nvh = vh, nvl = vl;
                 if (u + 1 < 8) {
                     const int vo = ((u + 1) >> 1) * 512 + voff + 4096 * ((u + 1) & 1);
-                    nvh = *reinterpret_cast<const bf16x8*>(V + vo);
-                    nvl = *reinterpret_cast<const bf16x8*>(V + SPL_V_PLANE + vo);
+                    nvh = *reinterpret_cast<const sp16x8*>(V + vo);
+                    nvl = *reinterpret_cast<const sp16x8*>(V + SPL_V_PLANE + vo);
                 }
-                const bf16x8 phj = __builtin_bit_cast(bf16x8, phw[j]), plj = __builtin_bit_cast(bf16x8, plw[j]);
-                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, phj, o[c], 0, 0, 0);
-                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, plj, o[c], 0, 0, 0);
-                o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, phj, o[c], 0, 0, 0);
+                const sp16x8 phj = __builtin_bit_cast(sp16x8, phw[j]), plj = __builtin_bit_cast(sp16x8, plw[j]);
+                o[c] = PDSC_MFMA_X3(vl, phj, o[c], 0, 0, 0);
+                o[c] = PDSC_MFMA_X3(vh, plj, o[c], 0, 0, 0);
+                o[c] = PDSC_MFMA_X3(vh, phj, o[c], 0, 0, 0);
                 if (!LAST && 8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
                 if (LAST) {
                     // (no tile kt + 1: no logits to form)
@@ -770,7 +767,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
 
 // ---- fp32 (q|k|v) rows -> split streams (the layer kernel's head epilogue does this in place; this stand-alone
 //      packer serves the stage tests and callers that bring their own projections) ---------------------------
-__global__ __launch_bounds__(256) void pack_qkv_split_kernel(const float* __restrict__ qkv, __bf16* __restrict__ qs,
+__global__ __launch_bounds__(256) void pack_qkv_split_kernel(const float* __restrict__ qkv, sp16* __restrict__ qs,
                                                              unsigned char* __restrict__ kv, int N, int num_tiles) {
     const int tile = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const float* rows = qkv + (size_t)b * N * 3 * PDSC_CHANNELS;
@@ -782,40 +779,40 @@ __global__ __launch_bounds__(256) void pack_qkv_split_kernel(const float* __rest
         const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
         if (k0 + row < N) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(rows + (size_t)(k0 + row) * 3 * PDSC_CHANNELS + c4);
-            bf16x4 hi, lo;
+            sp16x4 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { __bf16 a, c; split_bf16(v[e], a, c); hi[e] = a; lo[e] = c; }
-            __bf16* dst = qs + ((size_t)b * N + k0 + row) * SPL_Q_LD + c4;
-            *reinterpret_cast<bf16x4*>(dst) = hi;
-            *reinterpret_cast<bf16x4*>(dst + PDSC_CHANNELS) = lo;
+            for (int e = 0; e < 4; ++e) { sp16 a, c; split_sp16(v[e], a, c); hi[e] = a; lo[e] = c; }
+            sp16* dst = qs + ((size_t)b * N + k0 + row) * SPL_Q_LD + c4;
+            *reinterpret_cast<sp16x4*>(dst) = hi;
+            *reinterpret_cast<sp16x4*>(dst + PDSC_CHANNELS) = lo;
         }
     }
     // K: thread -> (key, chunk of 8 channels)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int f = t + 256 * i, key = f >> 4, chunk = f & 15;
-        bf16x8 hi, lo;
+        sp16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = k0 + key < N ? rows[(size_t)(k0 + key) * 3 * PDSC_CHANNELS + PDSC_CHANNELS + 8 * chunk + e] : 0.f;
-            __bf16 a, c; split_bf16(v, a, c); hi[e] = a; lo[e] = c;
+            sp16 a, c; split_sp16(v, a, c); hi[e] = a; lo[e] = c;
         }
-        *reinterpret_cast<bf16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
-        *reinterpret_cast<bf16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
+        *reinterpret_cast<sp16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
+        *reinterpret_cast<sp16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
     }
     // V^T: thread -> (channel, key chunk jh)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int f = t + 256 * i, ch = f & 127, jh = f >> 7;
-        bf16x8 hi, lo;
+        sp16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int key = k0 + spl_v_key(jh, e);
             const float v = key < N ? rows[(size_t)key * 3 * PDSC_CHANNELS + 2 * PDSC_CHANNELS + ch] : 0.f;
-            __bf16 a, c; split_bf16(v, a, c); hi[e] = a; lo[e] = c;
+            sp16 a, c; split_sp16(v, a, c); hi[e] = a; lo[e] = c;
         }
-        *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
-        *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
+        *reinterpret_cast<sp16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
+        *reinterpret_cast<sp16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
     }
 }
 
@@ -922,7 +919,7 @@ int pdsc::launch_attention_leaves(const void* q_split, const void* kv_tiles, con
     }
     const int tiles = spl_num_tiles(N);
     AttSplitArgs a{};
-    a.qs = (const __bf16*)q_split; a.kv = (const unsigned char*)kv_tiles; a.compat = compat; a.ld = ld; a.msg = nullptr;
+    a.qs = (const sp16*)q_split; a.kv = (const unsigned char*)kv_tiles; a.compat = compat; a.ld = ld; a.msg = nullptr;
     a.N = N; a.Npad = (int)round_up(N, 256); a.nsplit = ns; a.num_tiles = tiles; a.bs = bs;
     a.nq = ceil_div(N, nw * 32);
     a.nleaf = C;
@@ -954,7 +951,7 @@ int pdsc::launch_attention_leaves(const void* q_split, const void* kv_tiles, con
 
 extern "C" size_t pdsc_split_q_bytes(int bs, int N) {
     if (bs <= 0 || N <= 0) return 0;
-    return (size_t)bs * N * SPL_Q_LD * sizeof(__bf16);
+    return (size_t)bs * N * SPL_Q_LD * sizeof(sp16);
 }
 extern "C" size_t pdsc_split_kv_bytes(int bs, int N) {
     if (bs <= 0 || N <= 0) return 0;
@@ -982,7 +979,7 @@ extern "C" int pdsc_pack_qkv_split(const float* qkv, void* q_split, void* kv_til
     PDSC_REQUIRE(qkv && q_split && kv_tiles, "pdsc_pack_qkv_split: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_pack_qkv_split: bs=%d N=%d", bs, N);
     const int tiles = spl_num_tiles(N);
-    hipLaunchKernelGGL(pack_qkv_split_kernel, dim3(tiles, bs), dim3(256), 0, (hipStream_t)stream, qkv, (__bf16*)q_split,
+    hipLaunchKernelGGL(pack_qkv_split_kernel, dim3(tiles, bs), dim3(256), 0, (hipStream_t)stream, qkv, (sp16*)q_split,
                        (unsigned char*)kv_tiles, N, tiles);
     return check_launch("pdsc_pack_qkv_split");
 }
@@ -1012,7 +1009,7 @@ static int launch_attention_split(const void* q_split, const void* kv_tiles, con
         return PDSC_ERR_WORKSPACE;
     }
     AttSplitArgs a{};
-    a.qs = (const __bf16*)q_split; a.kv = (const unsigned char*)kv_tiles; a.compat = compat; a.ld = ld; a.msg = msg;
+    a.qs = (const sp16*)q_split; a.kv = (const unsigned char*)kv_tiles; a.compat = compat; a.ld = ld; a.msg = msg;
     a.N = N; a.Npad = (int)round_up(N, 256); a.nsplit = nsplit; a.num_tiles = tiles; a.bs = bs;
     a.nq = ceil_div(N, nw * 32);
     a.part_o = (float*)scratch;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void global_to_tile(const float* __restrict__ src, fl
 // 32x128 fp32 LDS tile (one of q / k / v for 32 points = one key tile) -> bf16 hi/lo streams (split_layout.h).
 // WHICH: 0 = q rows, 1 = K image, 2 = V^T image.  `valid` = number of real points in the tile (the rest is zero).
 template <int WHICH>
-__device__ __forceinline__ void tile_to_split(const float* Xs, __bf16* __restrict__ qrows, unsigned char* __restrict__ img,
+__device__ __forceinline__ void tile_to_split(const float* Xs, sp16* __restrict__ qrows, unsigned char* __restrict__ img,
                                               int valid, int t) {
     if (WHICH == 0) {
 #pragma unroll
@@ -105,12 +105,12 @@ __device__ __forceinline__ void tile_to_split(const float* Xs, __bf16* __restric
             const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
             if (row < valid) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * LF_LD + c4);
-                bf16x4 hi, lo;
+                sp16x4 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 x, y; split_bf16(v[e], x, y); hi[e] = x; lo[e] = y; }
-                __bf16* dst = qrows + (size_t)row * SPL_Q_LD + c4;
-                *reinterpret_cast<bf16x4*>(dst) = hi;
-                *reinterpret_cast<bf16x4*>(dst + PDSC_CHANNELS) = lo;
+                for (int e = 0; e < 4; ++e) { sp16 x, y; split_sp16(v[e], x, y); hi[e] = x; lo[e] = y; }
+                sp16* dst = qrows + (size_t)row * SPL_Q_LD + c4;
+                *reinterpret_cast<sp16x4*>(dst) = hi;
+                *reinterpret_cast<sp16x4*>(dst + PDSC_CHANNELS) = lo;
             }
         }
     } else if (WHICH == 1) {
@@ -119,28 +119,28 @@ __device__ __forceinline__ void tile_to_split(const float* Xs, __bf16* __restric
             const int f = t + 256 * i, key = f >> 4, chunk = f & 15;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(Xs + key * LF_LD + 8 * chunk);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(Xs + key * LF_LD + 8 * chunk + 4);
-            bf16x8 hi, lo;
+            sp16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = key < valid ? (e < 4 ? v0[e & 3] : v1[e & 3]) : 0.f;
-                __bf16 x, y; split_bf16(v, x, y); hi[e] = x; lo[e] = y;
+                sp16 x, y; split_sp16(v, x, y); hi[e] = x; lo[e] = y;
             }
-            *reinterpret_cast<bf16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
-            *reinterpret_cast<bf16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
+            *reinterpret_cast<sp16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
+            *reinterpret_cast<sp16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = t + 256 * i, ch = f & 127, jh = f >> 7;
-            bf16x8 hi, lo;
+            sp16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int key = spl_v_key(jh, e);
                 const float v = key < valid ? Xs[key * LF_LD + ch] : 0.f;
-                __bf16 x, y; split_bf16(v, x, y); hi[e] = x; lo[e] = y;
+                sp16 x, y; split_sp16(v, x, y); hi[e] = x; lo[e] = y;
             }
-            *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
-            *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
+            *reinterpret_cast<sp16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
+            *reinterpret_cast<sp16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
         }
     }
 }
@@ -291,19 +291,19 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
     }
     if (HAS_HEAD && QKV_X3) {
         // ---- PointCN exactly as above (exact fp32: featB is the next residual) ... ----
-        __bf16* Xh = reinterpret_cast<__bf16*>(Xb);
-        __bf16* Xl = Xh + LF_ROWS * LF_XLD16;
-        bf16x8 wh[8], wl[8];
+        sp16* Xh = reinterpret_cast<sp16*>(Xb);
+        sp16* Xl = Xh + LF_ROWS * LF_XLD16;
+        sp16x8 wh[8], wl[8];
         {
             f32x4 x[16];
             load_x<128>(Xb, l31, h, x);
             // prefetch the first split qkv tile: lane (row l31, half h), step kk holds k = 16kk+8h..+7
             {
-                const __bf16* p = a.wq_split + (size_t)(32 * wave + l31) * PDSC_CHANNELS + 8 * h;
+                const sp16* p = a.wq_split + (size_t)(32 * wave + l31) * PDSC_CHANNELS + 8 * h;
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    wh[kk] = *reinterpret_cast<const bf16x8*>(p + 16 * kk);
-                    wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
+                    wh[kk] = *reinterpret_cast<const sp16x8*>(p + 16 * kk);
+                    wl[kk] = *reinterpret_cast<const sp16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
                 }
             }
             const f32x16 acc = mma_tile<128>(wpre, x);
@@ -316,15 +316,15 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
                 const int col = 32 * wave + 8 * g + 4 * h;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bp + col);
                 f32x4 v;
-                bf16x4 hi, lo;
+                sp16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = fmaxf(acc[4 * g + e] + bv[e], 0.f);
-                    __bf16 xh, xl; split_bf16(v[e], xh, xl); hi[e] = xh; lo[e] = xl;
+                    sp16 xh, xl; split_sp16(v[e], xh, xl); hi[e] = xh; lo[e] = xl;
                 }
                 *reinterpret_cast<f32x4*>(Xa + l31 * LF_LD + col) = v;
-                *reinterpret_cast<bf16x4*>(Xh + l31 * LF_XLD16 + col) = hi;
-                *reinterpret_cast<bf16x4*>(Xl + l31 * LF_XLD16 + col) = lo;
+                *reinterpret_cast<sp16x4*>(Xh + l31 * LF_XLD16 + col) = hi;
+                *reinterpret_cast<sp16x4*>(Xl + l31 * LF_XLD16 + col) = lo;
             }
         }
         LF_STAMP(8)
@@ -342,18 +342,18 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
             f32x16 acc = zero;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(Xh + xo + 16 * kk);
-                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(Xl + xo + 16 * kk);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kk], xh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kk], xl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kk], xh, acc, 0, 0, 0);
+                const sp16x8 xh = *reinterpret_cast<const sp16x8*>(Xh + xo + 16 * kk);
+                const sp16x8 xl = *reinterpret_cast<const sp16x8*>(Xl + xo + 16 * kk);
+                acc = PDSC_MFMA_X3(wl[kk], xh, acc, 0, 0, 0);
+                acc = PDSC_MFMA_X3(wh[kk], xl, acc, 0, 0, 0);
+                acc = PDSC_MFMA_X3(wh[kk], xh, acc, 0, 0, 0);
             }
             if (c < 2) {                                              // prefetch next chunk's tile
-                const __bf16* p = a.wq_split + (size_t)(n0 + 128 + l31) * PDSC_CHANNELS + 8 * h;
+                const sp16* p = a.wq_split + (size_t)(n0 + 128 + l31) * PDSC_CHANNELS + 8 * h;
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    wh[kk] = *reinterpret_cast<const bf16x8*>(p + 16 * kk);
-                    wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
+                    wh[kk] = *reinterpret_cast<const sp16x8*>(p + 16 * kk);
+                    wl[kk] = *reinterpret_cast<const sp16x8*>(p + (size_t)3 * PDSC_CHANNELS * PDSC_CHANNELS + 16 * kk);
                 }
             }
             if (c == 0) { LF_STAMP(10) }
@@ -420,7 +420,7 @@ extern "C" int pdsc_layer_fused_split(const float* msg, const float* part_o, con
     else PDSC_REQUIRE(feat_out, "pdsc_layer_fused: tail-only needs feat_out");
     PDSC_REQUIRE((q_split == nullptr) == (kv_tiles == nullptr), "pdsc_layer_fused: q_split and kv_tiles go together");
     pdsc::LayerArgs a{msg, part_o, part_ml, nsplit, Npad, res, feat_in, feat_out, featB_out, qkv_out, w1, b1, w2, b2, w3, b3,
-                      wp, bp, wq, bq, (const __bf16*)wq_split, (__bf16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, PDSC_LAYER_GEMM_F32, 0, 0, 0, g_layer_trace};
+                      wp, bp, wq, bq, (const sp16*)wq_split, (sp16*)q_split, (unsigned char*)kv_tiles, N, bs, nullptr, nullptr, PDSC_LAYER_GEMM_F32, 0, 0, 0, g_layer_trace};
     a.nvalid = pdsc::layer_nvalid_slot();
     hipStream_t st = (hipStream_t)stream;
     // Two implementations.  layer_wave.hip (one wavefront per 32-point tile) wins once the tiles fill the chip; with few

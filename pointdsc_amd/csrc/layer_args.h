@@ -17,10 +17,10 @@ struct LayerArgs {
     float* qkv_out;          // [M][384]  head
     const float *w1, *b1, *w2, *b2, *w3, *b3;      // fc1 [64][128], fc2 [64][64], fc3 [128][64]
     const float *wp, *bp, *wq, *bq;                // pcn [128][128], qkv [384][128]
-    const __bf16* wq_split;  // optional: qkv weights as bf16 hi [384][128] | lo [384][128] -> the q|k|v projection runs in
+    const sp16* wq_split;  // optional: qkv weights as bf16 hi [384][128] | lo [384][128] -> the q|k|v projection runs in
                              // split precision (three bf16 MFMAs per operand pair); its error is of the order the attention's
                              // operand split already has, and q, k, v never touch the residual stream
-    __bf16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
+    sp16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
     unsigned char* kv;       // head, optional: K/V tile stream  [bs][tiles][32 KiB]  (split_layout.h)
     int N, bs;               // rows are bs pairs of N points; a workgroup's 32-point tile never straddles two pairs
     // optional (layer_wave.hip): the weights in MFMA-fragment order, one 8 KiB chunk per WChunk in the order the kernel

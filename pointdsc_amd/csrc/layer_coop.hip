@@ -31,11 +31,11 @@ __device__ __forceinline__ void coop_chunk(f32x16& acc, f32x16& cross, const WCh
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if constexpr (QKV) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, wc.v[2 * g]), wl = __builtin_bit_cast(bf16x8, wc.v[2 * g + 1]);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, oh[g]), bl = __builtin_bit_cast(bf16x8, ol[g]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc, 0, 0, 0);
+            const sp16x8 wh = __builtin_bit_cast(sp16x8, wc.v[2 * g]), wl = __builtin_bit_cast(sp16x8, wc.v[2 * g + 1]);
+            const sp16x8 bh = __builtin_bit_cast(sp16x8, oh[g]), bl = __builtin_bit_cast(sp16x8, ol[g]);
+            acc = PDSC_MFMA_X3(wl, bh, acc, 0, 0, 0);
+            acc = PDSC_MFMA_X3(wh, bl, acc, 0, 0, 0);
+            acc = PDSC_MFMA_X3(wh, bh, acc, 0, 0, 0);
         } else {
             const f16x8 wh = __builtin_bit_cast(f16x8, wc.v[2 * g]), wl = __builtin_bit_cast(f16x8, wc.v[2 * g + 1]);
             const f16x8 bh = __builtin_bit_cast(f16x8, oh[g]), bl = __builtin_bit_cast(f16x8, ol[g]);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         for (int it = 0; it < 4; ++it) {
             const int pt = 8 * it + (lane >> 3), piece = lane & 7;
             const u32x4 ev = *reinterpret_cast<const u32x4*>(patch + pt * LW_PROW + 16 * piece);
-            __bf16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
+            sp16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
             *reinterpret_cast<u32x4*>(dst) = ev;
         }
 

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                     if constexpr (s == 3) wave_lds_sync();
                     if constexpr (s >= 4) {
                         const int pt = 8 * (s - 4) + (lane >> 3), piece = lane & 7;
-                        __bf16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
+                        sp16* dst = a.qs + ((size_t)m0 + min(pt, valid - 1)) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
                         if constexpr (!(EXP & (2 | 8))) *reinterpret_cast<u32x4*>(dst) = ev;
                         else asm volatile("" :: "v"(ev), "v"(dst));
                     }
@@ -313,11 +313,11 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
         static_for<0, 4>([&](auto gc) {
             constexpr int g = decltype(gc)::value;                   // k-step g of this chunk: three MFMAs
             if constexpr (d.stage == ST_QKV) {
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, wc.v[2 * g]), wl = __builtin_bit_cast(bf16x8, wc.v[2 * g + 1]);
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, xqh[4 * d.chunk + g]), bl = __builtin_bit_cast(bf16x8, xql[4 * d.chunk + g]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc, 0, 0, 0);
+                const sp16x8 wh = __builtin_bit_cast(sp16x8, wc.v[2 * g]), wl = __builtin_bit_cast(sp16x8, wc.v[2 * g + 1]);
+                const sp16x8 bh = __builtin_bit_cast(sp16x8, xqh[4 * d.chunk + g]), bl = __builtin_bit_cast(sp16x8, xql[4 * d.chunk + g]);
+                acc = PDSC_MFMA_X3(wl, bh, acc, 0, 0, 0);
+                acc = PDSC_MFMA_X3(wh, bl, acc, 0, 0, 0);
+                acc = PDSC_MFMA_X3(wh, bh, acc, 0, 0, 0);
             } else {
                 const u32x4* oh = d.stage == ST_FC1 ? a0h : d.stage == ST_FC2 ? a1h : d.stage == ST_FC3 ? a2h : ayh;
                 const u32x4* ol = d.stage == ST_FC1 ? a0l : d.stage == ST_FC2 ? a1l : d.stage == ST_FC3 ? a2l : ayl;
@@ -486,7 +486,7 @@ extern "C" int pdsc_layer_fused_frag_io(const float* msg, const float* part_o, c
     LayerArgs a{};
     a.msg = msg; a.part_o = part_o; a.part_ml = part_ml; a.nsplit = nsplit; a.Npad = Npad;
     a.res = res; a.feat_in = feat_in; a.feat_out = feat_out; a.featB_out = featB_out;
-    a.qs = (__bf16*)q_split; a.kv = (unsigned char*)kv_tiles;
+    a.qs = (sp16*)q_split; a.kv = (unsigned char*)kv_tiles;
     a.N = N; a.bs = bs;
     a.wf_tail = (const unsigned char*)wfrag_tail; a.wf_head = (const unsigned char*)wfrag_head;
     a.gemm_format = gemm_format;

@@ -35,39 +35,39 @@ struct LayerX3Args {
     float* feat_out;         // [M][128] tail result (optional)
     float* featB_out;        // [M][128] head
     float* qkv_out;          // [M][384] head, optional fp32 copy of q|k|v
-    __bf16* qs;              // head: Q split stream
+    sp16* qs;              // head: Q split stream
     unsigned char* kv;       // head: K/V tile stream
-    const __bf16 *w1, *w2, *w3, *wp, *wq;          // split weights (hi block, then lo block)
+    const sp16 *w1, *w2, *w3, *wp, *wq;          // split weights (hi block, then lo block)
     const float *b1, *b2, *b3, *bp, *bq;
     int N, bs;
 };
 
 // A operand: rows n0..n0+31 of a split weight matrix [Nout][K]; lane (row l31, half h), step kk holds k = 16kk+8h..+7
 template <int K>
-__device__ __forceinline__ void load_w(const __bf16* __restrict__ W, int nout, int n0, int l31, int h, bf16x8 (&wh)[K / 16],
-                                       bf16x8 (&wl)[K / 16]) {
-    const __bf16* p = W + (size_t)(n0 + l31) * K + 8 * h;
+__device__ __forceinline__ void load_w(const sp16* __restrict__ W, int nout, int n0, int l31, int h, sp16x8 (&wh)[K / 16],
+                                       sp16x8 (&wl)[K / 16]) {
+    const sp16* p = W + (size_t)(n0 + l31) * K + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < K / 16; ++kk) {
-        wh[kk] = *reinterpret_cast<const bf16x8*>(p + 16 * kk);
-        wl[kk] = *reinterpret_cast<const bf16x8*>(p + (size_t)nout * K + 16 * kk);
+        wh[kk] = *reinterpret_cast<const sp16x8*>(p + 16 * kk);
+        wl[kk] = *reinterpret_cast<const sp16x8*>(p + (size_t)nout * K + 16 * kk);
     }
 }
 
 // D[32 channels][32 points] = W_tile . X^T with X = Xh + Xl in LDS; small terms first
 template <int K>
-__device__ __forceinline__ f32x16 mma_tile(const bf16x8 (&wh)[K / 16], const bf16x8 (&wl)[K / 16], const __bf16* Xh,
-                                           const __bf16* Xl, int l31, int h) {
+__device__ __forceinline__ f32x16 mma_tile(const sp16x8 (&wh)[K / 16], const sp16x8 (&wl)[K / 16], const sp16* Xh,
+                                           const sp16* Xl, int l31, int h) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc = zero;
     const int xo = l31 * LX_XLD + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < K / 16; ++kk) {
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(Xh + xo + 16 * kk);
-        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(Xl + xo + 16 * kk);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kk], xh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kk], xl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kk], xh, acc, 0, 0, 0);
+        const sp16x8 xh = *reinterpret_cast<const sp16x8*>(Xh + xo + 16 * kk);
+        const sp16x8 xl = *reinterpret_cast<const sp16x8*>(Xl + xo + 16 * kk);
+        acc = PDSC_MFMA_X3(wl[kk], xh, acc, 0, 0, 0);
+        acc = PDSC_MFMA_X3(wh[kk], xl, acc, 0, 0, 0);
+        acc = PDSC_MFMA_X3(wh[kk], xh, acc, 0, 0, 0);
     }
     return acc;
 }
@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x16 mma_tile(const bf16x8 (&wh)[K / 16], const bf1
 // col0 + 8g+4h .. +3 of row = point l31
 template <bool RELU, bool RESID, bool TO_F, bool TO_X>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias, int n0, int col0, int l31, int h,
-                                           const float* __restrict__ res_row, float* F, __bf16* Xh, __bf16* Xl) {
+                                           const float* __restrict__ res_row, float* F, sp16* Xh, sp16* Xl) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 8 * g + 4 * h);
@@ -95,11 +95,11 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
         const int col = col0 + 8 * g + 4 * h;
         if (TO_F) *reinterpret_cast<f32x4*>(F + l31 * LX_FLD + col) = v;
         if (TO_X) {
-            bf16x4 hi, lo;
+            sp16x4 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { __bf16 x, y; split_bf16(v[e], x, y); hi[e] = x; lo[e] = y; }
-            *reinterpret_cast<bf16x4*>(Xh + l31 * LX_XLD + col) = hi;
-            *reinterpret_cast<bf16x4*>(Xl + l31 * LX_XLD + col) = lo;
+            for (int e = 0; e < 4; ++e) { sp16 x, y; split_sp16(v[e], x, y); hi[e] = x; lo[e] = y; }
+            *reinterpret_cast<sp16x4*>(Xh + l31 * LX_XLD + col) = hi;
+            *reinterpret_cast<sp16x4*>(Xl + l31 * LX_XLD + col) = lo;
         }
     }
 }
@@ -116,7 +116,7 @@ __device__ __forceinline__ void tile_to_global(const float* F, float* __restrict
 
 // fp32 rows (already merged, or merged here from the attention's key-split partials) -> bf16 hi/lo activation tile
 __device__ __forceinline__ void rows_to_x(const LayerX3Args& a, const float* __restrict__ src, bool merge, int b, int m0, int M,
-                                          __bf16* Xh, __bf16* Xl, int t) {
+                                          sp16* Xh, sp16* Xl, int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
@@ -128,17 +128,17 @@ __device__ __forceinline__ void rows_to_x(const LayerX3Args& a, const float* __r
             const size_t slot0 = (size_t)b * a.nsplit * a.Npad + (size_t)(m - b * a.N);
             v = merge_partials_chunk(a.part_o, a.part_ml, slot0, (size_t)a.Npad, a.nsplit, c4);
         }
-        bf16x4 hi, lo;
+        sp16x4 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { __bf16 x, y; split_bf16(v[e], x, y); hi[e] = x; lo[e] = y; }
-        *reinterpret_cast<bf16x4*>(Xh + row * LX_XLD + c4) = hi;
-        *reinterpret_cast<bf16x4*>(Xl + row * LX_XLD + c4) = lo;
+        for (int e = 0; e < 4; ++e) { sp16 x, y; split_sp16(v[e], x, y); hi[e] = x; lo[e] = y; }
+        *reinterpret_cast<sp16x4*>(Xh + row * LX_XLD + c4) = hi;
+        *reinterpret_cast<sp16x4*>(Xl + row * LX_XLD + c4) = lo;
     }
 }
 
 // 32x128 fp32 staging tile (one of q / k / v for 32 points = one key tile) -> bf16 hi/lo streams (split_layout.h)
 template <int WHICH>
-__device__ __forceinline__ void stage_to_split(const float* F, __bf16* __restrict__ qrows, unsigned char* __restrict__ img,
+__device__ __forceinline__ void stage_to_split(const float* F, sp16* __restrict__ qrows, unsigned char* __restrict__ img,
                                                int valid, int t) {
     if (WHICH == 0) {
 #pragma unroll
@@ -146,12 +146,12 @@ __device__ __forceinline__ void stage_to_split(const float* F, __bf16* __restric
             const int f = t + 256 * i, row = f >> 5, c4 = (f & 31) * 4;
             if (row < valid) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(F + row * LX_FLD + c4);
-                bf16x4 hi, lo;
+                sp16x4 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 x, y; split_bf16(v[e], x, y); hi[e] = x; lo[e] = y; }
-                __bf16* dst = qrows + (size_t)row * SPL_Q_LD + c4;
-                *reinterpret_cast<bf16x4*>(dst) = hi;
-                *reinterpret_cast<bf16x4*>(dst + PDSC_CHANNELS) = lo;
+                for (int e = 0; e < 4; ++e) { sp16 x, y; split_sp16(v[e], x, y); hi[e] = x; lo[e] = y; }
+                sp16* dst = qrows + (size_t)row * SPL_Q_LD + c4;
+                *reinterpret_cast<sp16x4*>(dst) = hi;
+                *reinterpret_cast<sp16x4*>(dst + PDSC_CHANNELS) = lo;
             }
         }
     } else if (WHICH == 1) {
@@ -160,38 +160,38 @@ __device__ __forceinline__ void stage_to_split(const float* F, __bf16* __restric
             const int f = t + 256 * i, key = f >> 4, chunk = f & 15;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(F + key * LX_FLD + 8 * chunk);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(F + key * LX_FLD + 8 * chunk + 4);
-            bf16x8 hi, lo;
+            sp16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = key < valid ? (e < 4 ? v0[e & 3] : v1[e & 3]) : 0.f;
-                __bf16 x, y; split_bf16(v, x, y); hi[e] = x; lo[e] = y;
+                sp16 x, y; split_sp16(v, x, y); hi[e] = x; lo[e] = y;
             }
-            *reinterpret_cast<bf16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
-            *reinterpret_cast<bf16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
+            *reinterpret_cast<sp16x8*>(img + SPL_KH + spl_k_offset(key, chunk)) = hi;
+            *reinterpret_cast<sp16x8*>(img + SPL_KL + spl_k_offset(key, chunk)) = lo;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = t + 256 * i, ch = f & 127, jh = f >> 7;
-            bf16x8 hi, lo;
+            sp16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int key = spl_v_key(jh, e);
                 const float v = key < valid ? F[key * LX_FLD + ch] : 0.f;
-                __bf16 x, y; split_bf16(v, x, y); hi[e] = x; lo[e] = y;
+                sp16 x, y; split_sp16(v, x, y); hi[e] = x; lo[e] = y;
             }
-            *reinterpret_cast<bf16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
-            *reinterpret_cast<bf16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
+            *reinterpret_cast<sp16x8*>(img + SPL_VH + spl_v_offset(ch, jh)) = hi;
+            *reinterpret_cast<sp16x8*>(img + SPL_VL + spl_v_offset(ch, jh)) = lo;
         }
     }
 }
 
 template <bool HAS_TAIL, bool HAS_HEAD>
 __global__ __launch_bounds__(256, 3) void layer_x3_kernel(LayerX3Args a) {
-    __shared__ __attribute__((aligned(16))) __bf16 Xa[2 * LX_XTILE];     // hi | lo
-    __shared__ __attribute__((aligned(16))) __bf16 Xb[2 * LX_XTILE];
+    __shared__ __attribute__((aligned(16))) sp16 Xa[2 * LX_XTILE];     // hi | lo
+    __shared__ __attribute__((aligned(16))) sp16 Xb[2 * LX_XTILE];
     __shared__ __attribute__((aligned(16))) float F[LX_ROWS * LX_FLD];
-    __bf16 *Xah = Xa, *Xal = Xa + LX_XTILE, *Xbh = Xb, *Xbl = Xb + LX_XTILE;
+    sp16 *Xah = Xa, *Xal = Xa + LX_XTILE, *Xbh = Xb, *Xbl = Xb + LX_XTILE;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void layer_x3_kernel(LayerX3Args a) {
     constexpr int C = PDSC_CHANNELS, H = PDSC_CHANNELS / 2;
 
     if (HAS_TAIL) {
-        bf16x8 w1h[8], w1l[8], w2h[4], w2l[4], w3h[4], w3l[4];
+        sp16x8 w1h[8], w1l[8], w2h[4], w2l[4], w3h[4], w3l[4];
         // ---- fc1: 128 -> 64 (+BN, ReLU): tiles {0,1} on waves {0,1} ----
         if (wave < 2) load_w<C>(a.w1, H, 32 * wave, l31, h, w1h, w1l);
         rows_to_x(a, a.msg, a.msg == nullptr, b, m0, M, Xah, Xal, t);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 3) void layer_x3_kernel(LayerX3Args a) {
 
     if (HAS_HEAD) {
         // ---- PointCN: 128 -> 128 (+BN, ReLU): tile = wave; input Xb, output Xa (+ fp32 copy for featB_out) ----
-        bf16x8 wh[8], wl[8];
+        sp16x8 wh[8], wl[8];
         load_w<C>(a.wp, C, 32 * wave, l31, h, wh, wl);
         {
             const f32x16 acc = mma_tile<C>(wh, wl, Xbh, Xbl, l31, h);
@@ -279,11 +279,11 @@ static int launch_layer_x3(const LayerX3Args& a, hipStream_t st) {
 #endif  // PDSC_EXPERIMENTS
 
 // fp32 weight matrix [n] -> bf16 hi [n] | bf16 lo [n]
-__global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+__global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ src, sp16* __restrict__ dst, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
-        __bf16 hi, lo;
-        split_bf16(src[i], hi, lo);
+        sp16 hi, lo;
+        split_sp16(src[i], hi, lo);
         dst[i] = hi;
         dst[n + i] = lo;
     }
@@ -327,7 +327,7 @@ extern "C" long long pdsc_wsplit_offset(const pdsc_config* cfg, int section, int
 
 extern "C" size_t pdsc_wsplit_bytes(const pdsc_config* cfg) {
     if (!cfg || cfg->num_layers < 0) return 0;
-    return (size_t)cfg->num_layers * (wsplit_layer_elems() + wsplit_frag_layer_elems()) * sizeof(__bf16);
+    return (size_t)cfg->num_layers * (wsplit_layer_elems() + wsplit_frag_layer_elems()) * sizeof(sp16);
 }
 
 extern "C" int pdsc_wsplit_build(const pdsc_config* cfg, const float* wpack, void* wsplit, void* stream) {
@@ -338,17 +338,17 @@ extern "C" int pdsc_wsplit_build(const pdsc_config* cfg, const float* wpack, voi
             PDSC_REQUIRE(src >= 0 && dst >= 0, "pdsc_wsplit_build: bad section");
             const long long n = kWsplitElems[i] / 2;
             hipLaunchKernelGGL(wsplit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wpack + src,
-                               (__bf16*)wsplit + dst, n);
+                               (sp16*)wsplit + dst, n);
         }
         auto W = [&](int section) { return wpack + pdsc_wpack_offset(cfg, section, layer); };
         for (int fmt = PDSC_LAYER_GEMM_F32; fmt <= PDSC_LAYER_GEMM_H3; ++fmt) {
             const bool h3 = fmt == PDSC_LAYER_GEMM_H3;
             int rc = pdsc_wfrag_build_tail_fmt(W(PDSC_W_FC1_W), W(PDSC_W_FC1_B), W(PDSC_W_FC2_W), W(PDSC_W_FC2_B), W(PDSC_W_FC3_W), W(PDSC_W_FC3_B),
-                                               (__bf16*)wsplit + pdsc_wsplit_offset(cfg, h3 ? PDSC_WS_FRAG_TAIL_H3 : PDSC_WS_FRAG_TAIL, layer),
+                                               (sp16*)wsplit + pdsc_wsplit_offset(cfg, h3 ? PDSC_WS_FRAG_TAIL_H3 : PDSC_WS_FRAG_TAIL, layer),
                                                fmt, stream);
             if (rc != PDSC_OK) return rc;
             rc = pdsc_wfrag_build_head_fmt(W(PDSC_W_PCN_W), W(PDSC_W_PCN_B), W(PDSC_W_QKV_W), W(PDSC_W_QKV_B),
-                                           (__bf16*)wsplit + pdsc_wsplit_offset(cfg, h3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD, layer),
+                                           (sp16*)wsplit + pdsc_wsplit_offset(cfg, h3 ? PDSC_WS_FRAG_HEAD_H3 : PDSC_WS_FRAG_HEAD, layer),
                                            fmt, stream);
             if (rc != PDSC_OK) return rc;
         }
@@ -383,8 +383,8 @@ extern "C" int pdsc_layer_fused_x3(const float* msg, const float* part_o, const 
     LayerX3Args a{};
     a.msg = msg; a.part_o = part_o; a.part_ml = part_ml; a.nsplit = nsplit; a.Npad = Npad;
     a.res = res; a.feat_in = feat_in; a.feat_out = feat_out; a.featB_out = featB_out; a.qkv_out = qkv_out;
-    a.qs = (__bf16*)q_split; a.kv = (unsigned char*)kv_tiles;
-    a.w1 = (const __bf16*)w1; a.w2 = (const __bf16*)w2; a.w3 = (const __bf16*)w3; a.wp = (const __bf16*)wp; a.wq = (const __bf16*)wq;
+    a.qs = (sp16*)q_split; a.kv = (unsigned char*)kv_tiles;
+    a.w1 = (const sp16*)w1; a.w2 = (const sp16*)w2; a.w3 = (const sp16*)w3; a.wp = (const sp16*)wp; a.wq = (const sp16*)wq;
     a.b1 = b1; a.b2 = b2; a.b3 = b3; a.bp = bp; a.bq = bq;
     a.N = N; a.bs = bs;
     hipStream_t st = (hipStream_t)stream;

@@ -98,7 +98,7 @@ __device__ __forceinline__ void load_chunk(WChunk& w, const LayerArgs& a, const 
         case ST_PCN: load_rows_f32(w, a.wp + (size_t)n * 128 + 64 * d.chunk + 4 * h); break;
         default:
             if (X3) {
-                const __bf16* p = a.wq_split + (size_t)n * PDSC_CHANNELS + 64 * d.chunk + 8 * h;
+                const sp16* p = a.wq_split + (size_t)n * PDSC_CHANNELS + 64 * d.chunk + 8 * h;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     w.v[2 * k] = *reinterpret_cast<const f32x4*>(p + 16 * k);
@@ -117,36 +117,28 @@ __device__ __forceinline__ void mma_f32(f32x16& acc, const WChunk& w, const f32x
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[q][e], x[q][e], acc, 0, 0, 0);
 }
 
-__device__ __forceinline__ void mma_x3(f32x16& acc, const WChunk& w, const bf16x8* xh, const bf16x8* xl) {
+__device__ __forceinline__ void mma_x3(f32x16& acc, const WChunk& w, const sp16x8* xh, const sp16x8* xl) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, w.v[2 * i]), wl = __builtin_bit_cast(bf16x8, w.v[2 * i + 1]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[i], acc, 0, 0, 0);
+        const sp16x8 wh = __builtin_bit_cast(sp16x8, w.v[2 * i]), wl = __builtin_bit_cast(sp16x8, w.v[2 * i + 1]);
+        acc = PDSC_MFMA_X3(wl, xh[i], acc, 0, 0, 0);
+        acc = PDSC_MFMA_X3(wh, xl[i], acc, 0, 0, 0);
+        acc = PDSC_MFMA_X3(wh, xh[i], acc, 0, 0, 0);
     }
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned pack2(__bf16 a, __bf16 b) {
+__device__ __forceinline__ unsigned pack2(sp16 a, sp16 b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// two fp32 -> packed bf16 hi pair and lo pair, the arithmetic of split_bf16 (split_layout.h) with packed conversions:
-// 6 VALU operations per pair
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const bf16x2 hv = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
-    hi = __builtin_bit_cast(unsigned, hv);
-    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
-    const bf16x2 lv = __builtin_convertvector(f32x2{x0 - h0, x1 - h1}, bf16x2);
-    lo = __builtin_bit_cast(unsigned, lv);
-}
+// two fp32 -> packed hi pair and lo pair of the x3 split (split_layout.h: split_sp16_pair)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) { split_sp16_pair(x0, x1, hi, lo); }
 
-// fp32 x4 -> packed bf16 hi (2 registers) and lo (2 registers)
+// fp32 x4 -> packed hi (2 registers) and lo (2 registers)
 __device__ __forceinline__ void split4(const f32x4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
     split2(v[0], v[1], hi[0], lo[0]);
     split2(v[2], v[3], hi[1], lo[1]);

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
     load_chunk<T, X3, FRAG>(w[0], a, 0, lane);
 
     f32x4 x0[16], x1[8], x2[8], y3[16], x4[16];
-    bf16x8 xh[8], xl[8];
+    sp16x8 xh[8], xl[8];
     u32x4 a0h[8], a0l[8], a1h[4], a1l[4], a2h[4], a2l[4], ayh[8], ayl[8];     // HX: B operands of fc1 / fc2 / fc3 / PointCN
     if (T) {
         if (a.msg) {
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
                         split4(x4[2 * kk + 1], hb, lb);          // channels 16kk + 8 + 4h + e
                         half_swap(ha[0], hb[0]); half_swap(ha[1], hb[1]);
                         half_swap(la[0], lb[0]); half_swap(la[1], lb[1]);
-                        xh[kk] = __builtin_bit_cast(bf16x8, u32x4{ha[0], ha[1], hb[0], hb[1]});
-                        xl[kk] = __builtin_bit_cast(bf16x8, u32x4{la[0], la[1], lb[0], lb[1]});
+                        xh[kk] = __builtin_bit_cast(sp16x8, u32x4{ha[0], ha[1], hb[0], hb[1]});
+                        xl[kk] = __builtin_bit_cast(sp16x8, u32x4{la[0], la[1], lb[0], lb[1]});
                     }
                 }
             } else {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
                         for (int it = 0; it < 4; ++it) {
                             const int pt = 8 * it + (lane >> 3), piece = lane & 7;
                             const u32x4 val = *reinterpret_cast<const u32x4*>(patch + pt * LW_PROW + 16 * piece);
-                            __bf16* dst = a.qs + ((size_t)m0 + pt) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
+                            sp16* dst = a.qs + ((size_t)m0 + pt) * SPL_Q_LD + (piece >> 2) * PDSC_CHANNELS + n0 + 8 * (piece & 3);
                             if (pt < valid) *reinterpret_cast<u32x4*>(dst) = val;
                         }
                         wave_lds_sync();
@@ -380,11 +380,11 @@ __global__ __launch_bounds__(256) void wfrag_head_kernel(const float* __restrict
         *reinterpret_cast<f32x4*>(out + (size_t)idx * 16) = *reinterpret_cast<const f32x4*>(wp + (size_t)n * 128 + 64 * d.chunk + 8 * s + 4 * h);
     } else {                                                         // slot 2k = hi, 2k+1 = lo of bf16 k-step 4*chunk + k
         const float* src = wq + (size_t)n * 128 + 64 * d.chunk + 16 * (s >> 1) + 8 * h;
-        __bf16 v[8];
+        sp16 v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            __bf16 hi, lo;
-            split_bf16(src[e], hi, lo);
+            sp16 hi, lo;
+            split_sp16(src[e], hi, lo);
             v[e] = (s & 1) ? lo : hi;
         }
         *reinterpret_cast<u32x4*>(out + (size_t)idx * 16) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
@@ -474,7 +474,7 @@ extern "C" int pdsc_layer_fused_frag_fmt(const float* msg, const float* part_o, 
     LayerArgs a{};
     a.msg = msg; a.part_o = part_o; a.part_ml = part_ml; a.nsplit = nsplit; a.Npad = Npad;
     a.res = res; a.feat_in = feat_in; a.feat_out = feat_out; a.featB_out = featB_out; a.qkv_out = qkv_out;
-    a.qs = (__bf16*)q_split; a.kv = (unsigned char*)kv_tiles;
+    a.qs = (sp16*)q_split; a.kv = (unsigned char*)kv_tiles;
     a.N = N; a.bs = bs;
     a.wf_tail = (const unsigned char*)wfrag_tail; a.wf_head = (const unsigned char*)wfrag_head;
     a.gemm_format = gemm_format;

@@ -9,6 +9,14 @@
 
 #define PDSC_WAVE 64
 
+// the 16-bit element of every split-precision ("x3") operand -- hi or lo part of an fp32 value, split_layout.h -- and the matrix
+// instruction that multiplies them
+typedef _Float16 sp16;
+typedef sp16 sp16x2 __attribute__((ext_vector_type(2)));
+typedef sp16 sp16x4 __attribute__((ext_vector_type(4)));
+typedef sp16 sp16x8 __attribute__((ext_vector_type(8)));
+#define PDSC_MFMA_X3 __builtin_amdgcn_mfma_f32_32x32x16_f16
+
 namespace pdsc {
 
 // ---- host-side error plumbing ---------------------------------------------------------------

@@ -1,12 +1,16 @@
-// bf16x3 operand streams of the split-precision attention (attention_split.hip), produced by layer.hip's head
-// epilogue or by pdsc_pack_qkv_split.
+// x3 operand streams of the split-precision attention (attention_split.hip), produced by the layer kernels' head epilogues or by
+// pdsc_pack_qkv_split.
 //
-// An fp32 value x is carried as two bf16 numbers  hi = bf16(x), lo = bf16(x - hi)  (round to nearest even both
-// times; hi + lo reproduces x to 2^-17 relative).  A product a*b is evaluated on the bf16 matrix cores as
-// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation (the dropped a_lo*b_lo term is 2^-16 relative), i.e.
-// three v_mfma_f32_32x32x16_bf16 per operand pair = 3/16 of the cost of the exact fp32 MFMA.
+// An fp32 value x is carried as two fp16 numbers  hi = f16(x), lo = f16(x - hi)  (round to nearest even both times; lo is NOT
+// scaled: hi carries 11 significant bits, lo the next 11 down to fp16's denormal floor of 6e-8 -- gfx950's f16 MFMA takes denormal
+// inputs exactly, tools/f16_mfma_denorm_probe.hip -- so hi + lo reproduces x to max(2^-22 |x|, 3e-8)).  A product a*b is evaluated
+// on the f16 matrix cores as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation (11 x 11 bits: every partial product is exact
+// in fp32; the dropped a_lo*b_lo term is 2^-22 relative), i.e. three v_mfma_f32_32x32x16_f16 per operand pair = 3/16 of the cost of
+// the exact fp32 MFMA, ONE accumulator.  (r01-r04 carried bf16 hi/lo -- 8 + 8 bits, 2^-17 per operand: on trained KITTI-scale
+// weights that left the logits 6e-3 off, profiles/r05_f_kitti_stage_trained.txt; fp16 costs the same MFMAs and conversions and
+// needs |x| < 65504, which pdsc_encoder_range_probe checks for every activation that becomes such an operand.)
 //
-//   Q stream : [bs*N][256] bf16   row = (hi[0..127] | lo[0..127]), natural channel order
+//   Q stream : [bs*N][256] fp16   row = (hi[0..127] | lo[0..127]), natural channel order
 //   KV stream: [bs][ntiles][SPL_TILE_STRIDE]  one 32 KiB block (SPL_TILE_BYTES) per tile of 32 keys, laid out as the exact LDS image
 //              the attention kernel wants, so that the LDS-DMA copy is linear and fully coalesced.  Both operands are
 //              CHUNK-MAJOR (r02; r01 had key / channel rows with a pad chunk, 37 KiB):
@@ -26,8 +30,7 @@
 
 namespace pdsc {
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// (sp16, sp16x2/4/8, PDSC_MFMA_X3: pdsc_common.h)
 
 constexpr int SPL_BK = 32;                       // keys per tile
 constexpr int SPL_K_PLANE = 16 * 32 * 16, SPL_V_PLANE = 4 * 128 * 16;      // bytes per K / V^T plane (hi or lo): 8 KiB each
@@ -37,15 +40,25 @@ constexpr int SPL_TILE_BYTES = SPL_VL + SPL_V_PLANE;     // 32768 = 32 KiB
 // ranges in step, off a power-of-two address stride (precaution: with the un-pinned attention loop 32 and 37 KiB measured the
 // same; r01's image size kept).  The 5 KiB between images are never read or written.
 constexpr int SPL_TILE_STRIDE = 37 * 1024;
-constexpr int SPL_Q_LD = 2 * PDSC_CHANNELS;     // bf16 elements per row of the Q stream
+constexpr int SPL_Q_LD = 2 * PDSC_CHANNELS;     // 16-bit elements per row of the Q stream
 
 __host__ __device__ __forceinline__ int spl_k_offset(int key, int chunk) { return (chunk << 9) + (key << 4); }    // chunk 0..15
 __host__ __device__ __forceinline__ int spl_v_offset(int ch, int jh) { return (jh << 11) + (ch << 4); }            // jh 0..3
 __host__ __device__ __forceinline__ int spl_v_key(int jh, int e) { return 16 * (jh >> 1) + 8 * (e >> 2) + 4 * (jh & 1) + (e & 3); }
 
-__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
-    hi = (__bf16)x;
-    lo = (__bf16)(x - (float)hi);
+__device__ __forceinline__ void split_sp16(float x, sp16& hi, sp16& lo) {
+    hi = (sp16)x;
+    lo = (sp16)(x - (float)hi);
+}
+// the same for a pair, with packed conversions (v_cvt_pk_f16_f32, round to nearest even): 6 VALU operations per pair;
+// hi / lo = the two packed halves as one 32-bit register each
+typedef float spf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_sp16_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const sp16x2 hv = __builtin_convertvector(spf32x2{x0, x1}, sp16x2);
+    hi = __builtin_bit_cast(unsigned, hv);
+    const spf32x2 hf = __builtin_convertvector(hv, spf32x2);
+    const sp16x2 lv = __builtin_convertvector(spf32x2{x0 - hf[0], x1 - hf[1]}, sp16x2);
+    lo = __builtin_bit_cast(unsigned, lv);
 }
 
 static inline int spl_num_tiles(int N) { return ceil_div(N, SPL_BK); }

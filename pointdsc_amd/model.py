@@ -252,12 +252,14 @@ class PointDSC(nn.Module):
         # H3 (layer_gemm = "h3") carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo: |x| must stay below
         # 65504.  Checked once per packing: the folded weights here, the activations after the first forward (_run).
         self._h3_range_checked = False
-        if self.layer_gemm == "h3":
+        if self.layer_gemm == "h3" or self.attention_precision != "fp32":
+            # (r05: the split-precision attention and q|k|v projection carry their operands as fp16 hi + lo too)
             wmax = float(pack.abs().max())
             if not wmax < 3.0e4:
-                warnings.warn(f"pointdsc_amd: folded weights reach |w| = {wmax:.3g}, outside the fp16 range of layer_gemm='h3'; "
-                              "falling back to layer_gemm='f32' for this module", RuntimeWarning)
+                warnings.warn(f"pointdsc_amd: folded weights reach |w| = {wmax:.3g}, outside the fp16 range of the split-precision "
+                              "arithmetic; falling back to layer_gemm='f32' and attention_precision='fp32' for this module", RuntimeWarning)
                 self.layer_gemm = "f32"
+                self.attention_precision = "fp32"
         return pack
 
     def split_weights(self, device=None) -> torch.Tensor:
@@ -397,11 +399,11 @@ class PointDSC(nn.Module):
                     final_labels[idx, :ng] = r["final_labels"]
                 return {"final_trans": final_trans, "final_labels": final_labels, "M": None}
         num_seeds = int(n * self.ratio)                       # python double arithmetic, as the reference (:174)
-        if self.layer_gemm == "h3" and self.attention_precision != "fp32" and self.num_layers > 0:
+        if self.attention_precision != "fp32" and self.num_layers > 0:
             self.packed_weights(dev)                           # (re)packs if needed and resets the flag below
-            if not self._h3_range_checked and self.layer_gemm == "h3":
+            if not self._h3_range_checked and self.attention_precision != "fp32":
                 self._h3_range_checked = True
-                self._h3_range_probe(corr_pos, src_keypts, tgt_keypts, counts)      # first forward after packing: may switch to "f32"
+                self._h3_range_probe(corr_pos, src_keypts, tgt_keypts, counts)      # first forward after packing: may switch to "f32" / "fp32"
         cfg = self._config()
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
@@ -450,8 +452,8 @@ class PointDSC(nn.Module):
     RANGE_KINDS = ("layer0", "PointCN", "q|k|v", "message", "fc_message hidden 1", "fc_message hidden 2", "feature")
 
     def _h3_range_probe(self, corr_pos, src_keypts, tgt_keypts, counts=None) -> None:
-        """layer_gemm = "h3" carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo: EVERY activation of the chain,
-        hidden ones included, must stay below 65504.  Once per weight packing, before the first forward: the encoder with the fp32
+        """layer_gemm = "h3" carries every operand of the fc_message / PointCN GEMMs as fp16 hi + lo, and (r05) so do the split-precision
+        attention and q|k|v projection: EVERY activation of the chain, hidden ones included, must stay below 65504.  Once per weight packing, before the first forward: the encoder with the fp32
         GEMMs, one launch per conv, and the largest |value| of every activation kind over all layers (pdsc_encoder_range_probe;
         one device -> host copy of 8 floats).  Out of range (or NaN): warn and keep layer_gemm = "f32" for this module.
         A heuristic, not a proof: it sees the first input only -- a later input with much larger activations is not re-checked
@@ -468,7 +470,7 @@ class PointDSC(nn.Module):
             corr_pos, src_keypts, tgt_keypts = (torch.where(keep, t, torch.zeros_like(t)) for t in (corr_pos, src_keypts, tgt_keypts))
         with torch.cuda.device(dev):
             wpack = self.packed_weights(dev)
-            if self.layer_gemm != "h3":              # (the weight check at packing already fell back)
+            if self.attention_precision == "fp32":   # (the weight check at packing already fell back)
                 return
             wsplit = self.split_weights(dev)
             nbytes = int(lib.pdsc_workspace_bytes(C.byref(cfg), bs, n, num_seeds))
@@ -484,10 +486,16 @@ class PointDSC(nn.Module):
         vals = absmax[: len(self.RANGE_KINDS)].tolist()
         self.last_range_probe = dict(zip(self.RANGE_KINDS, vals))
         bad = [(k, v) for k, v in zip(self.RANGE_KINDS, vals) if not v < 3.0e4]
-        if bad:
+        if bad and self.layer_gemm == "h3":
             warnings.warn("pointdsc_amd: activations reach " + ", ".join(f"{v:.3g} ({k})" for k, v in bad) + ", outside the fp16 range of "
                           "layer_gemm='h3'; using layer_gemm='f32' (kept for this module)", RuntimeWarning)
             self.layer_gemm = "f32"
+        # r05: the attention's Q / K / V / P operands and the q|k|v projection's activations (= the PointCN output) are fp16 hi + lo
+        bad_att = [(k, v) for k, v in bad if k in ("PointCN", "q|k|v")] or [(k, v) for k, v in bad if not v == v]
+        if bad_att:
+            warnings.warn("pointdsc_amd: activations reach " + ", ".join(f"{v:.3g} ({k})" for k, v in bad_att) + ", outside the fp16 range of "
+                          "the split-precision attention; using attention_precision='fp32' (kept for this module)", RuntimeWarning)
+            self.attention_precision = "fp32"
 
     def workspace_view(self, name: str, bs: int, n: int, dtype=torch.float32) -> torch.Tensor:
         """Intermediate of the LAST forward (parity tests): flat view into the workspace from `name` on."""

@@ -332,10 +332,10 @@ def layer_fused_io(res, feat_in, tail_w, head_w, bs: int, n: int, io_flags: int,
 
 
 def split_weight(w: torch.Tensor) -> torch.Tensor:
-    """fp32 matrix [out,in] -> uint8 tensor holding bf16 hi [out,in] then bf16 lo [out,in] (layout of pdsc_wsplit_build)."""
+    """fp32 matrix [out,in] -> uint8 tensor holding fp16 hi [out,in] then fp16 lo [out,in] (layout of pdsc_wsplit_build)."""
     w = _chk(w, "weight")
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
     return torch.cat([hi.reshape(-1), lo.reshape(-1)]).view(torch.uint8)
 
 

@@ -280,11 +280,12 @@ def test_sc_attention_online_softmax_rescale_branch():
 
 
 # ------------------------------------------------------------------------------------------------------
-# a-3 split-precision attention (bf16 hi/lo operands, three MFMAs per operand pair) and its operand streams
+# a-3 split-precision attention (fp16 hi/lo operands, three MFMAs per operand pair) and its operand streams
 # ------------------------------------------------------------------------------------------------------
 def _split(x):
-    hi = x.float().bfloat16()
-    lo = (x.float() - hi.float()).bfloat16()
+    """split_layout.h: hi = f16(x), lo = f16(x - hi), round to nearest even, lo unscaled (r05: fp16 parts; bf16 in r01-r04)."""
+    hi = x.float().half()
+    lo = (x.float() - hi.float()).half()
     return hi, lo
 
 
