@@ -14,7 +14,7 @@ one the metric is quoted on (32 pairs at N=5000: 32 / N per GPU = strong scaling
 per-GPU batch instead).  n1000_b1, kitti_n5000_b16 and lomatch_n10000_b8 are configs[1], [3], [4].
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline        -- the dominant kernel (sc_attention_split_kernel, MFMA-bound: every fp32 product as three bf16
+  roofline        -- the dominant kernel (sc_attention_split_kernel, MFMA-bound: every fp32 product as three f16
                      MFMAs, fp32 accumulate): algorithmic flops per launch / average launch duration measured with
                      hipEvents on the launch stream over the timed region (pdsc_profile_* in include/pointdsc_hip.h);
   roofline_layer, roofline_compat -- the fused point-wise layer launch (matrix-pipe cycles) and the compat-matrix
@@ -54,7 +54,7 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak (one row of the guide)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
 MAX_CLOCK_GHZ = 2.4               # MI355X_MICROARCH.md: max shader clock
@@ -195,8 +195,8 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0, help="override the configuration's pairs per step over ALL GPUs")
     ap.add_argument("--pairs-per-gpu", type=int, default=0,
                     help="override: fixed batch per GPU per step (weak scaling); 0 = global-batch / gpus")
-    ap.add_argument("--attention-precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="arithmetic of the attention contractions: split-precision bf16 MFMA (default) or exact fp32 MFMA")
+    ap.add_argument("--attention-precision", choices=["fp16x3", "fp32"], default="fp16x3",
+                    help="arithmetic of the attention contractions: split-precision f16 MFMA, fp16 hi+lo operand pairs (default) or exact fp32 MFMA")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank; gloo = rehearsal of the N>1 path with CPU-tensor collectives")
     ap.add_argument("--att-leaves", default=None,
@@ -492,7 +492,7 @@ def main():
 
     # fused layer launch (tail of layer i + head of layer i+1).  With layer_gemm = "h3" on the wavefront-resident kernel (the
     # shipped default wherever pdsc_layer_prefers_block is 0) it is reported against HBM (`lay_bytes` below); the matrix-pipe
-    # figure (600 fp32 MFMAs x 64 + 288 bf16 MFMAs x 32 cycles per 32-point tile) is only reported for layer_gemm = "f32" /
+    # figure (600 fp32 MFMAs x 64 + 288 f16 MFMAs x 32 cycles per 32-point tile) is only reported for layer_gemm = "f32" /
     # the workgroup-per-tile kernel.  2 flop/MAC x (128*64 + 64*64 + 64*128 + 128*128 + 128*384) MACs per point
     lay_flops = 2.0 * 86016 * N * B
     lay_avg = lay_ms / max(lay_n, 1) * 1e-3
@@ -518,7 +518,7 @@ def main():
     cmp_avg = cmp_ms / max(cmp_n, 1) * 1e-3
     cmp_gbs = cmp_bytes / cmp_avg / 1e9 if cmp_n else None
     fp32 = args.attention_precision == "fp32"
-    att_peak = PEAK_FP32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS
+    att_peak = PEAK_FP32_MFMA_TFLOPS if fp32 else PEAK_F16_MFMA_TFLOPS
 
     value = total_pairs * args.steps / elapsed
     roof = {"kernel": "sc_attention_kernel" if fp32 else "sc_attention_split_kernel", "bound": "mfma",
@@ -531,8 +531,8 @@ def main():
                                               "the single-stream K steps right after the timed region (with forwards in flight the "
                                               "kernels of two streams overlap and an event pair no longer times one kernel)")}
     if not fp32:
-        # `achieved` counts ALGORITHMIC flops (4 C N^2 per pair per launch) against the dense bf16 MFMA peak; the kernel
-        # executes 3 bf16 MFMAs per algorithmic product (hi*hi, hi*lo, lo*hi): its matrix-pipe share is 3 x frac.
+        # `achieved` counts ALGORITHMIC flops (4 C N^2 per pair per launch) against the dense BF16/FP16 MFMA peak (one row of the guide); the kernel
+        # executes 3 f16 MFMAs per algorithmic product (hi*hi, hi*lo, lo*hi): its matrix-pipe share is 3 x frac.
         roof["executed_tflops"] = None if att_tflops is None else round(3 * att_tflops, 2)
         roof["executed_frac"] = None if att_tflops is None else round(3 * att_tflops / att_peak, 4)
     line = {
@@ -541,7 +541,7 @@ def main():
         "warmup_settle_steps": settle,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
-        "dtype": "f32" if fp32 else ("f32 (attention products as bf16x3 split, f32 accumulate" +
+        "dtype": "f32" if fp32 else ("f32 (attention products as fp16x3 split (fp16 hi+lo operand pairs, three f16 MFMAs per product), f32 accumulate" +
                                       ("; fc_message / PointCN products as fp16 hi+lo split" if lay_h3 else "") +
                                       ("; spatial-consistency matrix stored as unorm16" if c16 else "") + ")"),
         "data": "synthetic",

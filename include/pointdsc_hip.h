@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 6
+#define PDSC_VERSION 7
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32
@@ -93,8 +93,8 @@ enum pdsc_att_leaves { PDSC_LEAVES_PER_LAUNCH = 0, PDSC_LEAVES_CANONICAL = 1 };
  * (pdsc_layer_prefers_block(bs, N) == 1):
  *   F32: v_mfma_f32_32x32x2_f32, exact fp32 products (600 MFMAs x 64 matrix-pipe cycles per 32-point tile).
  *   H3 : every fp32 operand as fp16 hi + fp16 lo' (lo' = (x - hi) * 2048), product = hi*hi + (hi*lo' + lo'*hi) / 2048 on
- *        v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative error per product (the bf16 hi/lo split of the
- *        attention operands: 2^-16), 216 MFMAs x 32 cycles per tile.  Operands must stay inside the fp16 range
+ *        v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative error per product (as the fp16 hi/lo split of the
+ *        attention operands), 216 MFMAs x 32 cycles per tile.  Operands must stay inside the fp16 range
  *        (|x| < 65504); the network's activations and weights are O(1). */
 enum pdsc_layer_gemm { PDSC_LAYER_GEMM_F32 = 0, PDSC_LAYER_GEMM_H3 = 1 };
 
@@ -111,22 +111,30 @@ enum pdsc_layer_io { PDSC_IO_PARTIALS_PF = 1, PDSC_IO_RES_PF = 2, PDSC_IO_FEATB_
  * (the split-precision modes only; PDSC_ATT_FP32 always uses fp32 storage):
  *   U16: unorm16, value = round(c * 65535) / 65535 with c evaluated on the hardware's 1-ulp square root (r03: the exact
  *        sqrt / divide of the fp32 matrix made the build instruction-bound) -- within 2 units (3e-5) of the fp32 matrix,
- *        the diagonal exactly 1, symmetric bit for bit; the size of the 2^-16 product error of the bf16x3 arithmetic it
- *        feeds; half the HBM stream (2 N^2 instead of 4 N^2 bytes per layer per pair), half the workspace; +4.6 % pairs/s
+ *        the diagonal exactly 1, symmetric bit for bit (r05: with the attention operands as fp16 pairs this is the largest
+ *        arithmetic difference left between the default and the exact-fp32 configuration); half the HBM stream (2 N^2 instead of 4 N^2 bytes per layer per pair), half the workspace; +4.6 % pairs/s
  *        at N=5000 (tools/ab_forward.py).
  *   F32: the fp32 matrix of pdsc_spatial_compat, bit-identical to the reference's.
  * The Python module defaults to U16 (parity census equal to F32's); the C struct has no default. */
 enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
 
 /* Arithmetic of the attention contractions (models/PointDSC.py:39,42).  Softmax, accumulation, outputs: fp32 in both.
- *   BF16X3: every fp32 operand split into hi+lo bf16, three bf16 MFMAs per operand pair (hi*hi + hi*lo + lo*hi),
- *           ~2^-16 relative error per product; 12-layer features within 5e-6, R/t within 1e-5 of the fp32 path.
+ *   FP16X3: every fp32 operand split into fp16 hi + fp16 lo (lo = x - hi, unscaled: 22 significant bits down to fp16's
+ *           denormal floor, which the gfx950 f16 MFMA honours), three v_mfma_f32_32x32x16_f16 per operand pair
+ *           (hi*hi + hi*lo + lo*hi) into one fp32 accumulator: ~2^-21 relative error per product.  Operands must stay inside the
+ *           fp16 range (|q|, |k|, |v| < 65504; the softmax weights are kept in (0, 32768] by construction): the Python module
+ *           probes the first forward of a checkpoint and falls back to FP32 outside it (pdsc_encoder_range_probe).
  *           Also used for the q|k|v projection (its results only feed the attention); the GEMMs whose results
  *           land on the residual stream (PointCN, fc_message) follow pdsc_config.layer_gemm.           [default]
+ *           Rounds 1-4 split into bf16 pairs (2^-16 per product, fp32's range): on trained-like KITTI weights, whose
+ *           confidence logits reach 33, that left the logits up to 0.27 from the reference's; the fp16 pairs leave 0.04
+ *           (exact fp32: 0.017) for 1.7 % of the pairs/s (same-box A/B, profiles/r05_j_ab_split16_summary.txt).
  *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time.
- *   BF16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): their error lands on the residual stream un-averaged,
- *           12-layer features within 2e-5 of the fp32 path.  A/B record: accepted by experiments builds only. */
-enum pdsc_attention_precision { PDSC_ATT_BF16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_BF16X3_ALL = 2 };
+ *   FP16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): their error lands on the residual stream un-averaged.
+ *           A/B record: accepted by experiments builds only.
+ * (PDSC_ATT_BF16X3 / _ALL: the rounds 1-4 names of values 0 / 2, kept as aliases.) */
+enum pdsc_attention_precision { PDSC_ATT_FP16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_FP16X3_ALL = 2,
+                                PDSC_ATT_BF16X3 = PDSC_ATT_FP16X3, PDSC_ATT_BF16X3_ALL = PDSC_ATT_FP16X3_ALL };
 
 /* ---- packed weights --------------------------------------------------------------------------
  * One flat fp32 buffer holding the model with BatchNorm (eval) folded into the preceding conv and
@@ -228,15 +236,15 @@ int pdsc_layer_fused(const float* msg, const float* res, const float* feat_in, f
                      const float* w3, const float* b3, const float* wp, const float* bp,
                      const float* wq, const float* bq, int M, void* stream);
 
-/* Same chain, with the head additionally (or instead of qkv_out, which may then be NULL) emitting the bf16 hi/lo
+/* Same chain, with the head additionally (or instead of qkv_out, which may then be NULL) emitting the fp16 hi/lo
  * operand streams of the split-precision attention (layout: pointdsc_amd/csrc/split_layout.h):
- *   q_split  [bs*N][256] bf16 (hi | lo), pdsc_split_q_bytes(bs, N) bytes;
+ *   q_split  [bs*N][256] fp16 (hi | lo), pdsc_split_q_bytes(bs, N) bytes;
  *   kv_tiles [bs][ceil(N/32)][37 KiB] (a 32 KiB image per tile of 32 keys, images 37 KiB apart), pdsc_split_kv_bytes(bs, N) bytes.
  * Rows are bs pairs of N points (a 32-point tile never straddles two pairs).
  * The tail input is either `msg` (merged rows) or the un-merged key-split partials (`part_o`, `part_ml`, nsplit, Npad)
  * exactly as pdsc_sc_attention_split leaves them in its scratch when called with msg == NULL: the merge then happens
  * while the tile is loaded (no combine launch, no round trip of msg through HBM).
- * wq_split (optional): the q|k|v weights as bf16 hi [3C][C] | lo [3C][C] (section PDSC_W_QKV_W of the split-weight
+ * wq_split (optional): the q|k|v weights as fp16 hi [3C][C] | lo [3C][C] (section PDSC_W_QKV_W of the split-weight
  * buffer, pdsc_wsplit_build below) -> that one GEMM runs in split precision; q, k, v only feed the attention, whose
  * own operand split has an error of the same order, and never touch the residual stream. */
 int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* part_ml, int nsplit, int Npad,
@@ -247,10 +255,10 @@ int pdsc_layer_fused_split(const float* msg, const float* part_o, const float* p
                            const float* wq, const float* bq, const void* wq_split /* optional */, int bs, int N,
                            void* stream);
 
-/* Split-precision variant of the whole chain (PDSC_ATT_BF16X3_ALL: every GEMM as three bf16 MFMAs per operand pair);
+/* Split-precision variant of the whole chain (PDSC_ATT_FP16X3_ALL: every GEMM as three f16 MFMAs per operand pair);
  * same tail-input convention.  Weights come from the split-weight buffer:
  *   pdsc_wsplit_bytes(cfg) bytes, filled once per model by pdsc_wsplit_build(cfg, wpack, wsplit, stream);
- *   matrix of `section` (PDSC_W_PCN_W, _QKV_W, _FC1_W, _FC2_W, _FC3_W) of `layer` starts at bf16 element
+ *   matrix of `section` (PDSC_W_PCN_W, _QKV_W, _FC1_W, _FC2_W, _FC3_W) of `layer` starts at 16-bit element
  *   pdsc_wsplit_offset(cfg, section, layer): [out][in] hi, then [out][in] lo.  Biases stay fp32 (packed buffer). */
 size_t    pdsc_wsplit_bytes(const pdsc_config* cfg);
 long long pdsc_wsplit_offset(const pdsc_config* cfg, int section, int layer);
@@ -265,9 +273,9 @@ int pdsc_layer_fused_x3(const float* msg, const float* part_o, const float* part
  * MFMA-fragment-ordered streams: 8 KiB chunks in exactly the order the wavefront-resident kernel consumes them, so every
  * weight load of a wave is 1 KiB of consecutive memory.  This is the entry pdsc_forward_* uses by default.
  *   tail stream: pdsc_wfrag_tail_bytes() bytes from (fc1 [C/2][C], fc2 [C/2][C/2], fc3 [C][C/2]) fp32 and their biases;
- *   head stream: pdsc_wfrag_head_bytes() bytes from (pcn [C][C] fp32 kept fp32, qkv [3C][C] fp32 -> bf16 hi / lo) and
+ *   head stream: pdsc_wfrag_head_bytes() bytes from (pcn [C][C] fp32 kept fp32, qkv [3C][C] fp32 -> fp16 hi / lo) and
  *                their biases (the bias of an output tile is one more k-step of its GEMM: A = bias, B = 1).
- * pdsc_wsplit_build also stores both per layer inside the split-weight buffer, at bf16 element
+ * pdsc_wsplit_build also stores both per layer inside the split-weight buffer, at 16-bit element
  * pdsc_wsplit_offset(cfg, PDSC_WS_FRAG_TAIL / PDSC_WS_FRAG_HEAD, layer). */
 #define PDSC_WS_FRAG_TAIL 100
 #define PDSC_WS_FRAG_HEAD 101
@@ -281,7 +289,7 @@ size_t pdsc_wfrag_head_bytes(void);
 int pdsc_wfrag_build_tail(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                           const float* b3, void* out, void* stream);
 int pdsc_wfrag_build_head(const float* wp, const float* bp, const float* wq, const float* bq, void* out, void* stream);
-/* ... with the format of the fc1..fc3 / pcn chunks chosen (enum pdsc_layer_gemm; the q|k|v chunks are bf16 hi / lo in
+/* ... with the format of the fc1..fc3 / pcn chunks chosen (enum pdsc_layer_gemm; the q|k|v chunks are fp16 hi / lo in
  * both; the un-suffixed entries build PDSC_LAYER_GEMM_F32 streams).  pdsc_layer_fused_frag_fmt must be told the format. */
 int pdsc_wfrag_build_tail_fmt(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                               const float* b3, void* out, int gemm_format, void* stream);
@@ -314,7 +322,7 @@ int    pdsc_attention_default_split(int bs, int N);
 int    pdsc_sc_attention(const float* qkv, const float* compat, long long ld, float* msg,
                          void* scratch, size_t scratch_bytes, int bs, int N, int nsplit, void* stream);
 
-/* Split-precision variant (PDSC_ATT_BF16X3): same contract, operands as bf16 hi/lo streams.
+/* Split-precision variant (PDSC_ATT_FP16X3): same contract, operands as fp16 hi/lo streams.
  * pdsc_pack_qkv_split converts fp32 (q|k|v) rows [bs*N][3C] into the two streams (the fused layer kernel emits
  * them directly; the packer serves stage tests and callers with their own projections). */
 size_t pdsc_split_q_bytes(int bs, int N);

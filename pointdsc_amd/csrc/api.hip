@@ -122,12 +122,12 @@ static bool config_ok(const pdsc_config* c) {
     if (c->num_iterations < 0 || c->num_iterations > PDSC_MAX_POWER_ITERS) { set_error("num_iterations=%d", c->num_iterations); return false; }
     if (c->k < 1 || c->k > PDSC_MAX_K) { set_error("k=%d must be in [1,%d]", c->k, PDSC_MAX_K); return false; }
     if (c->refine_iters < 0) { set_error("refine_iters=%d", c->refine_iters); return false; }
-    if (c->attention_precision < PDSC_ATT_BF16X3 || c->attention_precision > PDSC_ATT_BF16X3_ALL) {
+    if (c->attention_precision < PDSC_ATT_FP16X3 || c->attention_precision > PDSC_ATT_FP16X3_ALL) {
         set_error("attention_precision=%d", c->attention_precision); return false;
     }
 #ifndef PDSC_EXPERIMENTS
-    if (c->attention_precision == PDSC_ATT_BF16X3_ALL) {
-        set_error("attention_precision=PDSC_ATT_BF16X3_ALL (all-split layer GEMMs) exists in experiments builds only");
+    if (c->attention_precision == PDSC_ATT_FP16X3_ALL) {
+        set_error("attention_precision=PDSC_ATT_FP16X3_ALL (all-split layer GEMMs) exists in experiments builds only");
         return false;
     }
 #endif
@@ -400,7 +400,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     unsigned int* conv_mask = (unsigned int*)(ws + L.find("conv_mask"));
     void* att_scratch = ws + L.find("att_scratch");
     const bool split = cfg->attention_precision != PDSC_ATT_FP32;
-    const bool x3_gemm = cfg->attention_precision == PDSC_ATT_BF16X3_ALL;
+    const bool x3_gemm = cfg->attention_precision == PDSC_ATT_FP16X3_ALL;
     PDSC_REQUIRE(!split || wsplit, "pdsc_forward_testing: the split-precision modes need the split-weight buffer (pdsc_wsplit_build)");
     auto WS = [&](int section, int layer) { return (const void*)((const unsigned short*)wsplit + pdsc_wsplit_offset(cfg, section, layer)); };
     const size_t att_bytes = L.bytes_of("att_scratch");

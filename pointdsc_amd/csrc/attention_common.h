@@ -1,4 +1,4 @@
-// Shared between the two attention kernels (attention.hip: exact fp32 MFMA; attention_split.hip: bf16x3 split).
+// Shared between the two attention kernels (attention.hip: exact fp32 MFMA; attention_split.hip: fp16x3 split).
 #pragma once
 #include "pdsc_common.h"
 

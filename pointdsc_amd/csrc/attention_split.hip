@@ -1,12 +1,13 @@
 // a-3, split-precision variant: the same spatial-consistency guided attention as attention.hip
-// (reference models/PointDSC.py:39-42), but the two contractions run on the bf16 matrix cores with every fp32
-// operand carried as hi + lo bf16 parts and three MFMAs per operand pair (split_layout.h): 3/16 of the
-// matrix-pipe time of the exact fp32 MFMA at ~2^-16 relative error per product, which keeps the 12-layer
-// features within 5e-6 and R/t within 1e-5 of the fp32 path (SURVEY.md Appendix B measured that ONE bf16 term
-// is not enough: 6e-4 on R/t).  Softmax, accumulation and the output stay fp32.
+// (reference models/PointDSC.py:39-42), but the two contractions run on the f16 matrix cores with every fp32
+// operand carried as fp16 hi + fp16 lo parts and three MFMAs per operand pair (split_layout.h): 3/16 of the
+// matrix-pipe time of the exact fp32 MFMA at ~2^-21 relative error per product (rounds 1-4: bf16 pairs, 2^-16, which
+// held the seeded checkpoints' features within 5e-6 of the fp32 path but left trained-like KITTI logits 0.27 out;
+// SURVEY.md Appendix B measured that ONE 16-bit term is not enough: 6e-4 on R/t).  Softmax, accumulation and the
+// output stay fp32.
 //
-// Bound: MFMA (bf16) with the compat stream (4 N^2 bytes per layer per pair) close behind on HBM.
-//   executed flops = 3 x algorithmic (4 C N^2 per layer per pair) on v_mfma_f32_32x32x16_bf16.
+// Bound: MFMA (f16) with the compat stream (4 N^2 bytes per layer per pair) close behind on HBM.
+//   executed flops = 3 x algorithmic (4 C N^2 per layer per pair) on v_mfma_f32_32x32x16_f16.
 //
 // Decomposition: workgroup = NW waves (8, or 4 for small problems) = NW*32 queries x one contiguous range of
 // 32-key tiles.  One wave = 32 queries:
@@ -54,6 +55,12 @@ __device__ __forceinline__ f32x16 scale_acc(f32x16 o, float alpha) {
 }
 
 constexpr float ATT_RESCALE_THR = 8.0f;   // running max is only moved when a logit exceeds it by 2^8 (log2 domain)
+// The reference exponent m_run of a query sits ATT_P_BIAS BELOW its running row maximum: p = exp2(logit - m_run) then spans
+// (0, 2^(BIAS + THR)] = (0, 32768] instead of (0, 256].  p is split into fp16 hi + lo for the P V product (split_layout.h), and
+// fp16's denormal floor is absolute (2^-25 rounds to 0): with the maximum at 1 every key more than 17.3 nats below it would drop
+// out of the sum (up to N 2^-25 = 6e-4 of the row sum at N = 20000, which fp32 keeps); with the maximum at 2^7 the floor is
+// 2^-32 of the largest term.  The bias is a common factor of o and l (and of every leaf's partials) and cancels in o / l.
+constexpr float ATT_P_BIAS = 7.0f;
 constexpr int SPL_K_BYTES = 2 * SPL_K_PLANE;    // Kh | Kl   16 KiB
 constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
 
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             }
         }
         mask_tail(kt0, tl);
-        m_run = row_max(tl);
+        m_run = row_max(tl) - ATT_P_BIAS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) tl[r] -= m_run;
     }
@@ -499,12 +506,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         PDSC_TRACE_STAMP(4)                      // 4: (unused)
 
         // ---- phase A: S^T(kt+1) = K Q^T on the matrix pipe | P(kt) = exp2(tl), hi/lo split on the VALU ---------
-        // (24 MFMAs on one accumulator: dependent bf16 MFMAs issue back to back at full rate, tools/mfma_chain_probe.hip.
+        // (24 MFMAs on one accumulator: dependent fp16 MFMAs issue back to back at full rate, tools/mfma_chain_probe.hip.
         //  Straight-line on purpose: on the last tile the "next" K stage holds stale data and the 24 MFMAs + logits are
         //  wasted work that nothing reads -- cheaper than a second code path, which makes the register allocator keep
         //  copies of the 64 accumulator registers.)
         float psum = 0.f;
-        u32x4 phw[2], plw[2];                    // P hi / lo as packed bf16 pairs: word w of operand j = keys (2w, 2w+1) of its 8
+        u32x4 phw[2], plw[2];                    // P hi / lo as packed fp16 pairs: word w of operand j = keys (2w, 2w+1) of its 8
         {
             const unsigned char* K = Ks + (st ^ 1) * SPL_K_BYTES;
             // fragments one step ahead of their MFMAs, and the steps pinned in source order: with the chunk-major image every
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 }
                 {
                     // p values 2j, 2j+1 = one 32-bit word of the P operands: split as a PAIR (split_layout.h split_sp16 arithmetic:
-                    // hi = bf16(p), lo = bf16(p - hi), round to nearest even) -- one v_cvt_pk_bf16_f32 per plane and pair, where the
+                    // hi = fp16(p), lo = fp16(p - hi), round to nearest even) -- one v_cvt_pk_f16_f32 per plane and pair, where the
                     // element-wise form converted every hi twice (16 of the loop's ~130 vector instructions per tile)
                     const float p0 = __builtin_amdgcn_exp2f(tl[2 * j]), p1 = __builtin_amdgcn_exp2f(tl[2 * j + 1]);
                     psum += p0;
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
             l_prev = l_run + __shfl_xor(l_run, 32, 64);
             leaf_prev = leaf;
             if ((kt + 2) * SPL_BK > N) mask_tail(kt + 1, tl);
-            m_run = row_max(tl);
+            m_run = row_max(tl) - ATT_P_BIAS;
 #pragma unroll
             for (int r = 0; r < 16; ++r) tl[r] -= m_run;
             l_run = 0.f;
@@ -622,8 +629,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                 mloc = row_max(tl);
             } else
                 mloc = half_max(mx_next);
-            if (!__all(mloc <= ATT_RESCALE_THR)) {
-                const float delta = mloc > ATT_RESCALE_THR ? mloc : 0.f;      // per query; 0 = stays
+            if (!__all(mloc <= ATT_RESCALE_THR + ATT_P_BIAS)) {
+                const float delta = mloc > ATT_RESCALE_THR + ATT_P_BIAS ? mloc - ATT_P_BIAS : 0.f;      // per query; 0 = stays
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 l_run *= alpha;
                 m_run += delta;

@@ -94,7 +94,7 @@ __device__ __forceinline__ void global_to_tile(const float* __restrict__ src, fl
     }
 }
 
-// 32x128 fp32 LDS tile (one of q / k / v for 32 points = one key tile) -> bf16 hi/lo streams (split_layout.h).
+// 32x128 fp32 LDS tile (one of q / k / v for 32 points = one key tile) -> fp16 hi/lo streams (split_layout.h).
 // WHICH: 0 = q rows, 1 = K image, 2 = V^T image.  `valid` = number of real points in the tile (the rest is zero).
 template <int WHICH>
 __device__ __forceinline__ void tile_to_split(const float* Xs, sp16* __restrict__ qrows, unsigned char* __restrict__ img,
@@ -195,8 +195,8 @@ __device__ __forceinline__ void msg_to_tile(const LayerArgs& a, int b, float* Xs
     }
 }
 
-constexpr int LF_XLD16 = PDSC_CHANNELS + 8;          // bf16 elements per row of a hi / lo activation tile (272 B)
-constexpr int LF_XB_FLOATS = LF_ROWS * LF_XLD16;     // Xb doubles as the bf16 hi|lo image of featB: 2 * 32 * 136 * 2 B
+constexpr int LF_XLD16 = PDSC_CHANNELS + 8;          // fp16 elements per row of a hi / lo activation tile (272 B)
+constexpr int LF_XB_FLOATS = LF_ROWS * LF_XLD16;     // Xb doubles as the fp16 hi|lo image of featB: 2 * 32 * 136 * 2 B
 
 template <bool HAS_TAIL, bool HAS_HEAD, bool QKV_X3>
 __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
             // (the first split qkv tile was requested above, under these MFMAs)
             LF_STAMP(7)
             __syncthreads();                                          // every wave holds its copy of Xb: Xb may be rewritten
-            // ... stored twice: fp32 -> Xa (featB_out), bf16 hi|lo -> Xb (operand of the split-precision q|k|v GEMM)
+            // ... stored twice: fp32 -> Xa (featB_out), fp16 hi|lo -> Xb (operand of the split-precision q|k|v GEMM)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = 32 * wave + 8 * g + 4 * h;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 3) void layer_fused_kernel(LayerArgs a) {
         __syncthreads();
         tile_to_global(Xa, a.featB_out, PDSC_CHANNELS, m0, M, t);
         LF_STAMP(9)
-        // ---- q|k|v: 128 -> 384, three 128-column chunks, hi*hi + hi*lo + lo*hi on the bf16 matrix cores, staged via Xa ----
+        // ---- q|k|v: 128 -> 384, three 128-column chunks, hi*hi + hi*lo + lo*hi on the fp16 matrix cores, staged via Xa ----
         unsigned char* img = a.kv ? a.kv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPL_TILE_STRIDE : nullptr;
         const int valid = min(LF_ROWS, M - m0);
         const int xo = l31 * LF_XLD16 + 8 * h;

@@ -17,8 +17,8 @@ struct LayerArgs {
     float* qkv_out;          // [M][384]  head
     const float *w1, *b1, *w2, *b2, *w3, *b3;      // fc1 [64][128], fc2 [64][64], fc3 [128][64]
     const float *wp, *bp, *wq, *bq;                // pcn [128][128], qkv [384][128]
-    const sp16* wq_split;  // optional: qkv weights as bf16 hi [384][128] | lo [384][128] -> the q|k|v projection runs in
-                             // split precision (three bf16 MFMAs per operand pair); its error is of the order the attention's
+    const sp16* wq_split;  // optional: qkv weights as fp16 hi [384][128] | lo [384][128] -> the q|k|v projection runs in
+                             // split precision (three fp16 MFMAs per operand pair); its error is of the order the attention's
                              // operand split already has, and q, k, v never touch the residual stream
     sp16* qs;              // head, optional: Q split stream   [bs*N][256]          (split_layout.h)
     unsigned char* kv;       // head, optional: K/V tile stream  [bs][tiles][32 KiB]  (split_layout.h)

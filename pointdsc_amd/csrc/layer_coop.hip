@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         unsigned char* img = a.kv + (size_t)gw * SPL_TILE_STRIDE;
         const int n0 = 32 * w;
 
-        // Q rows (hi[128] | lo[128]) bf16 through the patch: row = (hi 64 B | lo 64 B) of this tile's 32 channels
+        // Q rows (hi[128] | lo[128]) fp16 through the patch: row = (hi 64 B | lo 64 B) of this tile's 32 channels
         run_chunk(std::integral_constant<int, 6>{}, 0, 0, true, true_type{});
         run_chunk(std::integral_constant<int, 7>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
         if constexpr (j < NCH) load_chunk<T, true, true>(w[j], a, j, lane);
     });
 
-    // B operands (k-step kk: channels 16kk + 8h .. +7 of this lane's point) of fc1 | fc2 | fc3 | pcn (H3) and q|k|v (bf16)
+    // B operands (k-step kk: channels 16kk + 8h .. +7 of this lane's point) of fc1 | fc2 | fc3 | pcn (H3) and q|k|v (fp16)
     u32x4 a0h[8], a0l[8], a1h[4], a1l[4], a2h[4], a2l[4], ayh[8], ayl[8], xqh[8], xql[8];
     f32x4 y3[16];                                                    // residual rows, then feat (fp32)
     if (T) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                     make_kstep<true>(y3[4 * d.tile + s - 1], y3[4 * d.tile + s], ayh[2 * d.tile + (s >> 1)], ayl[2 * d.tile + (s >> 1)]);
             }
         } else if constexpr (d.stage == ST_PCN) {
-            // featB = relu: fp32 rows leave through the patch as whole 128-byte lines; bf16 hi / lo operands of q|k|v
+            // featB = relu: fp32 rows leave through the patch as whole 128-byte lines; fp16 hi / lo operands of q|k|v
             if constexpr (s < 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s][e] = fmaxf(v[s][e], 0.f);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                         else asm volatile("" :: "v"(ck));
                     }
                 } else if constexpr (d.tile < 4) {
-                    // Q rows (hi[128] | lo[128]) bf16 through the patch: row = (hi 64 B | lo 64 B) of this tile's 32 channels
+                    // Q rows (hi[128] | lo[128]) fp16 through the patch: row = (hi 64 B | lo 64 B) of this tile's 32 channels
                     if constexpr (s < 4) {
                         unsigned hi[2], lo[2];
                         split4(v[s], hi, lo);

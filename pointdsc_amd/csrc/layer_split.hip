@@ -1,13 +1,13 @@
 // a-2 fused, split-precision variant of layer.hip: the point-wise chain between two attention calls in ONE launch,
-// with every GEMM on the bf16 matrix cores in the hi/lo split arithmetic of split_layout.h (x = hi + lo, product =
+// with every GEMM on the fp16 matrix cores in the hi/lo split arithmetic of split_layout.h (x = hi + lo, product =
 // hi*hi + hi*lo + lo*hi, fp32 accumulate: 3/16 of the matrix-pipe time of the exact fp32 MFMA, ~2^-16 relative error
 // per product) and with the merge of the attention's key-split partials folded into the load of its input:
 //   tail of layer i   : msg   = merge(partials)                       (attention_combine_kernel's job, no extra launch)
 //                       feat  = featB + fc3( relu(fc2'( relu(fc1'(msg)) )) )        (reference models/PointDSC.py:43-45)
 //   head of layer i+1 : featB = relu(pcn'(feat)) ; (q|k|v) = Wqkv featB + b          (models/PointDSC.py:75, :36-38)
-//                       q, k, v leave as the bf16 hi/lo operand streams of attention_split.hip
-// Weights are split once on the device (pdsc_wsplit_build): per matrix [out][in] bf16 hi, then [out][in] bf16 lo.
-// Workgroup = 4 waves = one 32-point tile (never straddling two pairs); activations stay in LDS as bf16 hi/lo tiles
+//                       q, k, v leave as the fp16 hi/lo operand streams of attention_split.hip
+// Weights are split once on the device (pdsc_wsplit_build): per matrix [out][in] fp16 hi, then [out][in] fp16 lo.
+// Workgroup = 4 waves = one 32-point tile (never straddling two pairs); activations stay in LDS as fp16 hi/lo tiles
 // [32 points][K] with a 272-byte row stride (17 chunks of 16 B: consecutive points rotate by one bank slot, every
 // ds_read_b128 of a lane is base + immediate); fp32 results that leave the CU are staged through one fp32 tile.
 // MFMA orientation: D = W_tile (A, rows = 32 output channels) x X^T (B, columns = points): the accumulator lane is a
@@ -21,9 +21,9 @@ namespace pdsc {
 
 #ifdef PDSC_EXPERIMENTS      // the all-split layer kernel is an A/B record (r01: +3 % pairs/s at 3e-5 feature error): experiments builds only
 constexpr int LX_ROWS = 32;                         // points per workgroup
-constexpr int LX_XLD = PDSC_CHANNELS + 8;           // bf16 elements per activation row (272 B)
+constexpr int LX_XLD = PDSC_CHANNELS + 8;           // fp16 elements per activation row (272 B)
 constexpr int LX_FLD = PDSC_CHANNELS + 4;           // floats per staging row
-constexpr int LX_XTILE = LX_ROWS * LX_XLD;          // bf16 elements per hi (or lo) tile
+constexpr int LX_XTILE = LX_ROWS * LX_XLD;          // fp16 elements per hi (or lo) tile
 
 struct LayerX3Args {
     const float* msg;        // [M][128] tail input (already merged), or NULL when the partials below are given
@@ -72,7 +72,7 @@ __device__ __forceinline__ f32x16 mma_tile(const sp16x8 (&wh)[K / 16], const sp1
     return acc;
 }
 
-// acc -> (+bias)(relu)(+residual row from HBM) -> fp32 staging tile F and/or bf16 hi/lo activation tile, at columns
+// acc -> (+bias)(relu)(+residual row from HBM) -> fp32 staging tile F and/or fp16 hi/lo activation tile, at columns
 // col0 + 8g+4h .. +3 of row = point l31
 template <bool RELU, bool RESID, bool TO_F, bool TO_X>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias, int n0, int col0, int l31, int h,
@@ -114,7 +114,7 @@ __device__ __forceinline__ void tile_to_global(const float* F, float* __restrict
     }
 }
 
-// fp32 rows (already merged, or merged here from the attention's key-split partials) -> bf16 hi/lo activation tile
+// fp32 rows (already merged, or merged here from the attention's key-split partials) -> fp16 hi/lo activation tile
 __device__ __forceinline__ void rows_to_x(const LayerX3Args& a, const float* __restrict__ src, bool merge, int b, int m0, int M,
                                           sp16* Xh, sp16* Xl, int t) {
 #pragma unroll
@@ -136,7 +136,7 @@ __device__ __forceinline__ void rows_to_x(const LayerX3Args& a, const float* __r
     }
 }
 
-// 32x128 fp32 staging tile (one of q / k / v for 32 points = one key tile) -> bf16 hi/lo streams (split_layout.h)
+// 32x128 fp32 staging tile (one of q / k / v for 32 points = one key tile) -> fp16 hi/lo streams (split_layout.h)
 template <int WHICH>
 __device__ __forceinline__ void stage_to_split(const float* F, sp16* __restrict__ qrows, unsigned char* __restrict__ img,
                                                int valid, int t) {
@@ -278,7 +278,7 @@ static int launch_layer_x3(const LayerX3Args& a, hipStream_t st) {
 
 #endif  // PDSC_EXPERIMENTS
 
-// fp32 weight matrix [n] -> bf16 hi [n] | bf16 lo [n]
+// fp32 weight matrix [n] -> fp16 hi [n] | fp16 lo [n]
 __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ src, sp16* __restrict__ dst, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ s
 
 using namespace pdsc;
 
-// element (bf16) offsets inside one layer's block of the split-weight buffer: pcn | qkv | fc1 | fc2 | fc3, each hi then lo
+// element (fp16) offsets inside one layer's block of the split-weight buffer: pcn | qkv | fc1 | fc2 | fc3, each hi then lo
 static const long long kWsplitElems[5] = {2LL * PDSC_CHANNELS * PDSC_CHANNELS, 2LL * 3 * PDSC_CHANNELS * PDSC_CHANNELS,
                                           2LL * (PDSC_CHANNELS / 2) * PDSC_CHANNELS, 2LL * (PDSC_CHANNELS / 2) * (PDSC_CHANNELS / 2),
                                           2LL * PDSC_CHANNELS * (PDSC_CHANNELS / 2)};

@@ -1,5 +1,5 @@
 // Building blocks of the wavefront-resident fused layer kernel (layer_wave.hip): weight-chunk streams, MFMA steps,
-// bf16 hi/lo splitting, the wave-private LDS patch.
+// fp16 hi/lo splitting, the wave-private LDS patch.
 #pragma once
 #include <type_traits>
 #include "pdsc_common.h"
@@ -17,7 +17,7 @@ constexpr int LW_QKV_BUFS = 4;   // weight-chunk buffers (32 registers each) dur
 #endif
 
 struct WChunk {
-    f32x4 v[8];      // 8 fp32 k-steps (q) of a weight tile, or 4 bf16 k-steps as (hi, lo) pairs
+    f32x4 v[8];      // 8 fp32 k-steps (q) of a weight tile, or 4 fp16 k-steps as (hi, lo) pairs
     float bias;      // first chunk of a tile only: bias of output channel n0 + l31 in lane-half 0, zero in lane-half 1
 };
 
@@ -147,10 +147,10 @@ __device__ __forceinline__ void split4(const f32x4& v, unsigned (&hi)[2], unsign
 // ---- fp16 hi / scaled-lo split (the H3 arithmetic of the fc1..fc3 / PointCN GEMMs) -----------------------------------
 // x = hi + lo' / 2048 with hi = f16(x), lo' = f16((x - hi) * 2048), both round-to-nearest-even.  hi carries 11
 // significant bits, lo' the next 11: a product a*b evaluated as  a_hi*b_hi + (a_hi*b_lo' + a_lo'*b_hi) / 2048  on
-// v_mfma_f32_32x32x16_f16 (fp32 accumulate, the two cross terms in their own accumulator) is exact to ~2^-21 relative --
-// 32x tighter than the bf16 hi/lo split of split_layout.h at the same three MFMAs per operand pair, which is what lets the
-// GEMMs that land on the residual stream leave the fp32 MFMA (1/16 of the f16 rate).  The scale keeps lo' in the normal
-// range of fp16 whenever hi is.  Range: |x| < 65504 (fp16); activations and weights of this network are O(1).
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate, the two cross terms in their own accumulator) is exact to ~2^-21 relative,
+// which is what lets the GEMMs that land on the residual stream leave the fp32 MFMA (1/16 of the f16 rate).  The scale keeps
+// lo' in the normal range of fp16 whenever hi is (the attention operands' split, split_layout.h, is the same pair WITHOUT the
+// scale -- one accumulator for all three terms -- and therefore has an absolute floor of 2^-25 on lo).  Range: |x| < 65504 (fp16); activations and weights of this network are O(1).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
@@ -188,7 +188,7 @@ __device__ __forceinline__ u32x4 chunk_for_store(const unsigned (&hi)[2], const 
 
 // B operand of one 16-wide k-step kk from the fp32 accumulator layout: lane-half h holds `a` = channels 16kk + 4h + e and
 // `b` = channels 16kk + 8 + 4h + e of its point; the k-step wants channels 16kk + 8h .. +7 in lane-half h.  F16 selects the
-// fp16 hi / scaled-lo split (H3) instead of the bf16 hi / lo split.
+// fp16 hi / scaled-lo split (H3) instead of the unscaled fp16 hi / lo split.
 template <bool F16>
 __device__ __forceinline__ void make_kstep(const f32x4& a, const f32x4& b, u32x4& oh, u32x4& ol) {
     unsigned ha[2], la[2], hb[2], lb[2];

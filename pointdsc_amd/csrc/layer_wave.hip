@@ -10,7 +10,7 @@
 // independent chains (2 per SIMD) that hide each other's weight-fetch latency.  (layer.hip, the previous design, spreads
 // the tiles of a stage over 4 waves and pays 13 workgroup barriers per tile; it measured 3 x the MFMA time.)
 // Weights stream from L2 straight into registers in 32-register chunks (8 k-steps), one chunk ahead of the MFMAs.
-// The q|k|v projection runs in split precision (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16) when wq_split is
+// The q|k|v projection runs in split precision (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16) when wq_split is
 // given; its 16-wide k-step takes channels 16kk+8h..+7 from lane-half h, i.e. two lanes' worth of the fp32 layout, which
 // one v_permlane32_swap per register pair rearranges.  The same swap turns the (4 channels per lane-half) accumulator
 // layout into the 16-byte (8 channels) chunks of the Q rows / K image (split_layout.h); only V^T needs a transpose
@@ -33,7 +33,7 @@ namespace pdsc {
     if (TRACE && lane == 0) a.trace[(size_t)gw * 64 + (k)] = __builtin_readcyclecounter();
 
 // HX: fc1..fc3 and PointCN in the fp16 hi / scaled-lo arithmetic (H3, layer_wave.h) on fragment streams built with
-// format PDSC_LAYER_GEMM_H3 -- 504 f16/bf16 MFMAs (16.1 k matrix-pipe cycles) per tile instead of 600 fp32 + 288 bf16 (46 k).
+// format PDSC_LAYER_GEMM_H3 -- 504 f16 MFMAs (16.1 k matrix-pipe cycles) per tile instead of 600 fp32 + 288 f16 (46 k).
 template <bool T, bool H, bool X3, bool FRAG, bool TRACE = false, bool HX = false>
 __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs a) {
     static_assert(!HX || (FRAG && (X3 || !H)), "H3 GEMMs read fragment streams");
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 2) void layer_wave_kernel(LayerArgs 
                 }
                 wave_lds_sync();
                 if constexpr (X3 && d.tile == 3) {
-                    // featB -> bf16 hi / lo operands of the 16-wide k-steps: step kk, lane-half h <- channels 16kk+8h..+7
+                    // featB -> fp16 hi / lo operands of the 16-wide k-steps: step kk, lane-half h <- channels 16kk+8h..+7
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         unsigned ha[2], la[2], hb[2], lb[2];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void wfrag_head_kernel(const float* __restrict
         *reinterpret_cast<u32x4*>(out + (size_t)idx * 16) = wfrag_h3_slot(wp + (size_t)n * 128 + 64 * d.chunk + 16 * (s >> 1) + 8 * h, s & 1);
     } else if (d.stage == ST_PCN) {
         *reinterpret_cast<f32x4*>(out + (size_t)idx * 16) = *reinterpret_cast<const f32x4*>(wp + (size_t)n * 128 + 64 * d.chunk + 8 * s + 4 * h);
-    } else {                                                         // slot 2k = hi, 2k+1 = lo of bf16 k-step 4*chunk + k
+    } else {                                                         // slot 2k = hi, 2k+1 = lo of fp16 k-step 4*chunk + k
         const float* src = wq + (size_t)n * 128 + 64 * d.chunk + 16 * (s >> 1) + 8 * h;
         sp16 v[8];
 #pragma unroll

@@ -30,7 +30,8 @@ from . import _lib
 
 _NUM_CHANNELS = 128
 # enum pdsc_attention_precision (include/pointdsc_hip.h)
-ATTENTION_PRECISIONS = {"bf16x3": 0, "fp32": 1, "bf16x3_all": 2}
+ATTENTION_PRECISIONS = {"fp16x3": 0, "fp32": 1, "fp16x3_all": 2,
+                        "bf16x3": 0, "bf16x3_all": 2}      # (the rounds 1-4 names of the same modes: the operand pairs were bf16 then)
 # enum pdsc_compat_format
 COMPAT_FORMATS = {"f32": 0, "u16": 1}
 # enum pdsc_layer_gemm
@@ -116,11 +117,12 @@ class PointDSC(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         # Not a reference constructor argument (the signature stays the reference's): arithmetic of the two
-        # attention contractions.  "bf16x3" = split-precision bf16 MFMA (default; features within 5e-6 of fp32),
-        # "fp32" = exact fp32 MFMA.  (Experiments builds of the library also take "bf16x3_all": the point-wise GEMMs in split
-        # precision too, features within 2e-5 -- an A/B record, rejected by the product library.)
+        # attention contractions.  "fp16x3" = split-precision f16 MFMA, every operand as an fp16 hi + lo pair (default; ~2^-21
+        # per product), "fp32" = exact fp32 MFMA.  "bf16x3" is accepted as the old name of "fp16x3".  (Experiments builds of the
+        # library also take "fp16x3_all": the point-wise GEMMs in split precision too -- an A/B record, rejected by the product
+        # library.)
         # Module attributes only -- neither the module nor the library reads the environment.  Set before calling forward.
-        self.attention_precision = "bf16x3"
+        self.attention_precision = "fp16x3"
         # storage of the N x N spatial-consistency matrix between its build and the attention launches (split-precision
         # modes): "u16" = unorm16 (|error| <= 7.6e-6; default): half the workspace and HBM stream, 4.6 % more pairs/s at
         # N=5000 (tools/ab_forward.py), features as close to the exact-fp32 path as with "f32" (2e-6), parity census
@@ -152,10 +154,10 @@ class PointDSC(nn.Module):
         # reference post_refinement picks its threshold by exact equality with 0.10 (:415-418)
         refine_thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
         if self.attention_precision not in ATTENTION_PRECISIONS:
-            raise ValueError(f"attention_precision must be one of ['bf16x3', 'fp32'], got {self.attention_precision!r}")
-        if self.attention_precision == "bf16x3_all" and not _lib.load().pdsc_experiments_enabled():
-            raise ValueError('attention_precision "bf16x3_all" (all-split layer GEMMs, an A/B record) exists in experiments builds of the '
-                             "library only (python -m pointdsc_amd.build --experiments); the product accepts 'bf16x3' and 'fp32'")
+            raise ValueError(f"attention_precision must be one of ['fp16x3', 'fp32'], got {self.attention_precision!r}")
+        if self.attention_precision in ("fp16x3_all", "bf16x3_all") and not _lib.load().pdsc_experiments_enabled():
+            raise ValueError('attention_precision "fp16x3_all" (all-split layer GEMMs, an A/B record) exists in experiments builds of the '
+                             "library only (python -m pointdsc_amd.build --experiments); the product accepts 'fp16x3' and 'fp32'")
         if self.compat_format not in COMPAT_FORMATS:
             raise ValueError(f"compat_format must be one of {sorted(COMPAT_FORMATS)}, got {self.compat_format!r}")
         if self.layer_gemm not in LAYER_GEMMS:
@@ -263,7 +265,7 @@ class PointDSC(nn.Module):
         return pack
 
     def split_weights(self, device=None) -> torch.Tensor:
-        """bf16 hi/lo split of the per-layer matrices for the split-precision GEMMs (pdsc_wsplit_build): built on the
+        """fp16 hi/lo split of the per-layer matrices for the split-precision GEMMs (pdsc_wsplit_build): built on the
         GPU from the packed buffer, once per packing."""
         pack = self.packed_weights(device)
         if self._wsplit is None:
@@ -384,7 +386,7 @@ class PointDSC(nn.Module):
             if not testing:
                 raise NotImplementedError("ragged batches are supported in testing mode only (the validation forward returns an N x N matrix per pair)")
             if self.attention_precision == "fp32":
-                raise NotImplementedError('ragged batches need a split-precision attention mode (attention_precision = "bf16x3")')
+                raise NotImplementedError('ragged batches need a split-precision attention mode (attention_precision = "fp16x3")')
             groups = self._ragged_groups(counts)
             if len(groups) > 1 or min(counts) <= self.k:      # too heterogeneous for one launch plan (or pairs of at most k rows): one call per group
                 final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)

@@ -181,7 +181,7 @@ def pack_qkv_split(qkv: torch.Tensor, bs: int, n: int):
 @_on_device
 def sc_attention_split(q_split: torch.Tensor, kv_tiles: torch.Tensor, compat: torch.Tensor, bs: int, n: int,
                        nsplit: int = 0, merge: bool = True, layout: str = "rows"):
-    """Split-precision (bf16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128].
+    """Split-precision (fp16 hi/lo, three MFMAs per operand pair) attention on the packed streams -> msg [bs*N,128].
     merge=False (needs a key split > 1): returns (scratch, nsplit) with the un-merged partials for layer_fused_x3;
     layout="pf": those partials in point-fragment order (csrc/split_layout.h) for layer_fused_io."""
     lib = _lib.load()
@@ -220,7 +220,7 @@ def frag_weights_tail(tail_w, gemm: str = "f32") -> torch.Tensor:
 
 @_on_device
 def frag_weights_head(head_w, gemm: str = "f32") -> torch.Tensor:
-    """(pcn w, b, qkv w, b): pcn kept fp32 (gemm "f32") or fp16 hi / scaled lo ("h3"), q|k|v -> bf16 hi / lo, biases as
+    """(pcn w, b, qkv w, b): pcn kept fp32 (gemm "f32") or fp16 hi / scaled lo ("h3"), q|k|v -> fp16 hi / lo, biases as
     one more k-step -> the head stream."""
     lib = _lib.load()
     out = torch.empty(int(lib.pdsc_wfrag_head_bytes()), dtype=torch.uint8, device=head_w[0].device)
@@ -234,7 +234,7 @@ def layer_fused_split(msg, res, feat_in, tail_w, head_w, bs: int, n: int, want_q
                       qkv_split: bool = False, frag: bool = False, gemm: str = "f32", want_feat: bool = True):
     """pdsc_layer_fused_split: like layer_fused, rows = bs pairs of n points, head emits the split streams.
     partials = (scratch, nsplit) from sc_attention_split(..., merge=False) replaces msg.
-    qkv_split: run the q|k|v projection in split precision (bf16 hi/lo weights).
+    qkv_split: run the q|k|v projection in split precision (fp16 hi/lo weights).
     frag: go through pdsc_layer_fused_frag (weights as fragment-ordered streams; implies qkv_split) -- the entry the
     forward uses; gemm = "h3" (frag only): fc1..fc3 / PointCN in the fp16 hi / scaled-lo arithmetic.
     want_feat = False: no feat output (what the forward asks of every layer but the last); head_w = None (frag only):

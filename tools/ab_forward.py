@@ -49,7 +49,7 @@ def apply(variant):
     env = {}
     for p in parts[1:]:
         k, v = p.split("=")
-        if k.startswith("@"):            # model attribute, e.g. @attention_precision=bf16x3_all, @layer_gemm=f32
+        if k.startswith("@"):            # model attribute, e.g. @attention_precision=fp16x3_all, @layer_gemm=f32
             setattr(model, k[1:], v)
             continue
         env[k] = v

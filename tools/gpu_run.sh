@@ -76,6 +76,46 @@ latency)
     line lat_trained_n1000_x1_$L --config trained_n1000_b1 --latency --att-leaves $L --no-cpu-baseline --steps 400 --warmup 20 --sustain-seconds 1
   done
   summ | tee "$OUT/latency_summary.txt" ;;
+ab_split16)
+  # same-box A/B of the split-operand format: this build (fp16 hi/lo) against a library built from the previous commit
+  # (bf16 hi/lo) placed at pointdsc_amd/libpointdsc_hip_bf16.so; interleaved so that board drift hits both alike
+  for R in 1 2 3; do
+    line s16_fp16_r$R --config n5000_b32 --no-cpu-baseline --sustain-seconds 1.5
+    POINTDSC_HIP_LIB=$ROOT/pointdsc_amd/libpointdsc_hip_bf16.so line s16_bf16_r$R --config n5000_b32 --no-cpu-baseline --sustain-seconds 1.5
+  done
+  line s16_fp16_kitti --config kitti_n5000_b16 --no-cpu-baseline --sustain-seconds 1
+  POINTDSC_HIP_LIB=$ROOT/pointdsc_amd/libpointdsc_hip_bf16.so line s16_bf16_kitti --config kitti_n5000_b16 --no-cpu-baseline --sustain-seconds 1
+  summ | tee "$OUT/ab_split16_summary.txt" ;;
+census_multiway)
+  timeout 900 python tools/parity_census.py --families multiway_n20000_b1,lomatch_n10000_b8,n12000_b4 2>&1 | tail -40 > "$OUT/census_multiway.txt"; cat "$OUT/census_multiway.txt" ;;
+att_err)
+  # measured error of the split-precision attention against the fp64 softmax (the construction of
+  # tests/test_gpu_parity.py::test_sc_attention_split_matches_fp64_softmax), to set that test's bounds from
+  timeout 600 python - > "$OUT/att_err.txt" 2>&1 <<'PY'
+import importlib.util, sys, torch
+sys.path.insert(0, "tests")
+spec = importlib.util.spec_from_file_location("tgp", "tests/test_gpu_parity.py"); t = importlib.util.module_from_spec(spec); spec.loader.exec_module(t)
+ops, g = t.ops, t.g
+for n, bs in ((257, 1), (1000, 2), (5000, 1), (1500, 9)):
+    gen = torch.Generator().manual_seed(n + bs)
+    batch = t.synthetic.make_batch(bs, n, seed=70 + n)
+    compat = ops.spatial_compat(g(batch["src_keypts"]), g(batch["tgt_keypts"]), g(torch.tensor([0.1])))
+    for qk_scale in (0.35, 2.0):
+        q, k, v = (torch.randn(bs, n, 128, generator=gen) * s for s in (qk_scale, qk_scale, 1.0))
+        qkv = torch.cat([q * t.QSCALE, k, v], dim=-1).reshape(bs * n, 384)
+        qs, kv = ops.pack_qkv_split(g(qkv), bs, n)
+        for nsplit in (1, 0, 3):
+            msg = ops.sc_attention_split(qs, kv, compat, bs, n, nsplit=nsplit).cpu().reshape(bs, n, 128)
+            et = em = 0.0
+            for b in range(bs):
+                cm = compat[b, :, :n].cpu()
+                want = t._attention_ref(q[b], k[b], v[b], cm)
+                scale = max(1.0, float(want.abs().max()))
+                et = max(et, float((msg[b].double() - want).abs().max()) / scale)
+                em = max(em, float((msg[b].double() - t._attention_split_model(q[b] * t.QSCALE, k[b], v[b], cm)).abs().max()) / scale)
+            print(f"n {n} bs {bs} qk_scale {qk_scale} nsplit {nsplit}: vs fp64 softmax {et:.2e}   vs fp64 evaluation of the split operands {em:.2e}", flush=True)
+PY
+  cat "$OUT/att_err.txt" ;;
 census_trained)
   timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16 --batches 0,1,2,4,8,16,32 > "$OUT/parity_census_trained.txt" 2>&1
   timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16 --batches 0,1 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/parity_census_trained_exact_fp32.txt" 2>&1
@@ -137,7 +177,7 @@ for i in (50, 0, 7):
     one = workloads.batch(name, i, 1)
     data = {k: one[k].cuda() for k in ("corr_pos", "src_keypts", "tgt_keypts")}; data["testing"] = True
     ref = ix["conf32"][i]
-    for att, cf, lg in (("bf16x3", "u16", "h3"), ("bf16x3", "f32", "h3"), ("bf16x3", "u16", "f32"), ("bf16x3", "f32", "f32"), ("fp32", "f32", "f32")):
+    for att, cf, lg in (("fp16x3", "u16", "h3"), ("fp16x3", "f32", "h3"), ("fp16x3", "u16", "f32"), ("fp16x3", "f32", "f32"), ("fp32", "f32", "f32")):
         model.attention_precision, model.compat_format, model.layer_gemm = att, cf, lg
         with torch.no_grad(): model(data)
         conf = model.workspace_view("conf", 1, w["num_corr"]).cpu().numpy()[: w["num_corr"]]

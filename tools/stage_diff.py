@@ -2,7 +2,7 @@
 """Where does a GPU forward leave the oracle?  Runs one pair of a bench workload through pdsc_forward_testing (inside a
 batch of --bs pairs, position 0) and through the CPU oracle with stages, and prints the first stage that differs.
 
-    python tools/stage_diff.py --config n1000_b1 --pair 0 [--bs 1] [--precision bf16x3|fp32]
+    python tools/stage_diff.py --config n1000_b1 --pair 0 [--bs 1] [--precision fp16x3|fp32]
 """
 import argparse
 import sys
@@ -19,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="n1000_b1")
 ap.add_argument("--pair", type=int, default=0)
 ap.add_argument("--bs", type=int, default=1)
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="fp16x3")
 ap.add_argument("--compat-format", default="u16")
 ap.add_argument("--index", type=int, default=0, help="position inside the batch (the batch starts at --pair)")
 a = ap.parse_args()
