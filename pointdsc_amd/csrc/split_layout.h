@@ -56,9 +56,13 @@ typedef float spf32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_sp16_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     const sp16x2 hv = __builtin_convertvector(spf32x2{x0, x1}, sp16x2);
     hi = __builtin_bit_cast(unsigned, hv);
-    const spf32x2 hf = __builtin_convertvector(hv, spf32x2);
-    const sp16x2 lv = __builtin_convertvector(spf32x2{x0 - hf[0], x1 - hf[1]}, sp16x2);
-    lo = __builtin_bit_cast(unsigned, lv);
+    // lo = f16(x - hi) straight from the packed halves: v_fma_mixlo_f16 / v_fma_mixhi_f16 evaluate fma(hi, -1, x) with the fp16
+    // source picked by op_sel and round the (exact: x - hi fits 13 bits) result into the low / high half of the destination --
+    // two instructions per pair where convert-back, subtract, convert-again took five
+    unsigned lv;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lv) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv) : "v"(hi), "v"(x1));
+    lo = lv;
 }
 
 static inline int spl_num_tiles(int N) { return ceil_div(N, SPL_BK); }

@@ -76,16 +76,17 @@ latency)
     line lat_trained_n1000_x1_$L --config trained_n1000_b1 --latency --att-leaves $L --no-cpu-baseline --steps 400 --warmup 20 --sustain-seconds 1
   done
   summ | tee "$OUT/latency_summary.txt" ;;
-ab_split16)
-  # same-box A/B of the split-operand format: this build (fp16 hi/lo) against a library built from the previous commit
-  # (bf16 hi/lo) placed at pointdsc_amd/libpointdsc_hip_bf16.so; interleaved so that board drift hits both alike
+ab_lib)
+  # same-box A/B of two library builds: this build against another one placed at pointdsc_amd/libpointdsc_hip_prev.so (same
+  # ABI version); interleaved so that board drift hits both alike.  (r05j: fp16 hi/lo operand pairs against the bf16 pairs of the
+  # commit before; r05l: lo halves by v_fma_mixlo/mixhi_f16 against convert-subtract-convert)
   for R in 1 2 3; do
-    line s16_fp16_r$R --config n5000_b32 --no-cpu-baseline --sustain-seconds 1.5
-    POINTDSC_HIP_LIB=$ROOT/pointdsc_amd/libpointdsc_hip_bf16.so line s16_bf16_r$R --config n5000_b32 --no-cpu-baseline --sustain-seconds 1.5
+    line s16_this_r$R --config n5000_b32 --no-cpu-baseline --sustain-seconds 1.5
+    POINTDSC_HIP_LIB=$ROOT/pointdsc_amd/libpointdsc_hip_prev.so line s16_prev_r$R --config n5000_b32 --no-cpu-baseline --sustain-seconds 1.5
   done
-  line s16_fp16_kitti --config kitti_n5000_b16 --no-cpu-baseline --sustain-seconds 1
-  POINTDSC_HIP_LIB=$ROOT/pointdsc_amd/libpointdsc_hip_bf16.so line s16_bf16_kitti --config kitti_n5000_b16 --no-cpu-baseline --sustain-seconds 1
-  summ | tee "$OUT/ab_split16_summary.txt" ;;
+  line s16_this_kitti --config kitti_n5000_b16 --no-cpu-baseline --sustain-seconds 1
+  POINTDSC_HIP_LIB=$ROOT/pointdsc_amd/libpointdsc_hip_prev.so line s16_prev_kitti --config kitti_n5000_b16 --no-cpu-baseline --sustain-seconds 1
+  summ | tee "$OUT/ab_lib_summary.txt" ;;
 census_multiway)
   timeout 900 python tools/parity_census.py --families multiway_n20000_b1,lomatch_n10000_b8,n12000_b4 2>&1 | tail -40 > "$OUT/census_multiway.txt"; cat "$OUT/census_multiway.txt" ;;
 att_err)
