@@ -7,8 +7,8 @@ Runs the split-precision attention launch back to back for --seconds on (a) rand
 instruction stream, no data toggling: MI355X_MICROARCH.md "DVFS give-back"), optionally (c) the 64-queries-per-wave record kernel
 (the r01-r04 record kernel `sc_attention_wide_kernel` was removed in r05: profiles/HISTORY.md), while a sampler thread reads the socket power and the shader clock every ~20 ms from
 sysfs (hwmon power1_average / power1_input, freq1_input) or, failing that, `amd-smi metric` / `rocm-smi`.  For every arm it
-prints launches/s, executed TFLOP/s (3 bf16 MFMAs per algorithmic product), mean / max power, mean shader clock, and the
-ENERGY PER EXECUTED MFMA (joules per v_mfma_f32_32x32x16_bf16 wave-instruction) -- the figure that says whether two forms of the
+prints launches/s, executed TFLOP/s (3 f16 MFMAs per algorithmic product), mean / max power, mean shader clock, and the
+ENERGY PER EXECUTED MFMA (joules per v_mfma_f32_32x32x16_f16 wave-instruction) -- the figure that says whether two forms of the
 kernel differ in what they ask of the power budget.  A chip that runs the random arm at its power cap with a lower clock than the
 zero arm is power-bound on this kernel.
 """
@@ -179,8 +179,8 @@ def main():
     c16 = ops.spatial_compat_u16(src, tgt, torch.tensor([0.1], device=dev))
     c32 = ops.spatial_compat(src, tgt, torch.tensor([0.1], device=dev)) if a.wide else None
     gen = torch.Generator().manual_seed(0)
-    flops_exec = 3 * 4.0 * 128 * n * n * bs                       # executed: three bf16 MFMAs per algorithmic product
-    mfma = flops_exec / (2.0 * 32 * 32 * 16)                      # v_mfma_f32_32x32x16_bf16 wave-instructions per launch
+    flops_exec = 3 * 4.0 * 128 * n * n * bs                       # executed: three f16 MFMAs per algorithmic product
+    mfma = flops_exec / (2.0 * 32 * 32 * 16)                      # v_mfma_f32_32x32x16_f16 wave-instructions per launch
     out = []
     for label, scale in (("random", 0.3), ("zeros", 0.0)):
         qkv = (torch.randn(bs * n, 384, generator=gen) * scale).to(dev)

@@ -16,7 +16,7 @@ def L(name):
 
 
 def bench_table():
-    out = ["| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of bf16 peak | fused layer launch, frac of 8 TB/s | compat build, frac of 8 TB/s | socket power in the sustained leg (share of the cap), J per pair | reference CPU path | check: max dT vs reference / oracle |",
+    out = ["| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of the 16-bit MFMA peak | fused layer launch, frac of 8 TB/s | compat build, frac of 8 TB/s | socket power in the sustained leg (share of the cap), J per pair | reference CPU path | check: max dT vs reference / oracle |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
     names = [("n5000_b32", "configs[2], headline"), ("n1000_b1", "configs[1]"), ("kitti_n5000_b16", "configs[3]"), ("lomatch_n10000_b8", "configs[4]"),
              ("kitti_n12000_b4", "the reference's KITTI evaluation size"), ("multiway_n20000_b1", "the reference's multiway size"),

@@ -22,7 +22,7 @@ def frac(x):
     return "—" if x is None else f"{x:.3f}"
 
 
-print("| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of bf16 peak | "
+print("| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of the 16-bit MFMA peak | "
       "fused layer launch, frac of 8 TB/s | compat build, frac of 8 TB/s | reference CPU path | check: max dT vs reference / oracle |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for name, label in (("n5000_b32", "`n5000_b32` (configs[2], headline)"), ("n1000_b1", "`n1000_b1` (configs[1])"),
