@@ -2553,8 +2553,11 @@ def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():
     nl = "encoder.blocks.NonLocal_layer_0."
     hidden_only = {nl + "projection_v.weight": 1.0e4, nl + "projection_v.bias": 1.0e4, nl + "fc_message.0.weight": 1.0e2,
                    nl + "fc_message.3.weight": 1.0e-6}
+    # (r05) only the attention's operands out of range: k of one layer ~1e5 while every weight stays below 3e4 and the residual
+    # stream O(1) -- the layer GEMMs may stay on H3, the attention must leave its fp16 operand pairs
+    k_only = {nl + "projection_k.weight": 1.0e5, nl + "projection_k.bias": 1.0e5}
     for scales, kind in (({"encoder.layer0.weight": 3.0e5}, None), ({"encoder.blocks.PointCN_layer_1.0.weight": 1.0e6}, None),
-                         (hidden_only, "fc_message hidden 1")):
+                         (hidden_only, "fc_message hidden 1"), (k_only, "q|k|v")):
         model = PointDSC(**kw)
         sd = synthetic.make_state_dict(model.state_dict(), seed=2)
         for key, scale in scales.items():
@@ -2564,8 +2567,17 @@ def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():
         assert model.layer_gemm == "h3"
         with pytest.warns(RuntimeWarning, match="fp16 range"):
             res = _forward(model, pair)
-        assert model.layer_gemm == "f32" and bool(torch.isfinite(res["final_trans"]).all())
-        if kind is not None:
+        assert bool(torch.isfinite(res["final_trans"]).all())
+        if kind == "q|k|v":
+            assert model.attention_precision == "fp32" and model.layer_gemm == "h3", (model.attention_precision, model.layer_gemm)
+            assert model.last_range_probe[kind] > 3.0e4 and model.last_range_probe["feature"] < 3.0e4, model.last_range_probe
+        else:
+            assert model.layer_gemm == "f32"
+            # weights out of range take the attention with them; a hidden fc_message activation alone does not (the attention
+            # follows ITS operands: PointCN output and q|k|v)
+            att_out = kind is None or not max(model.last_range_probe["PointCN"], model.last_range_probe["q|k|v"]) < 3.0e4
+            assert model.attention_precision == ("fp32" if att_out else "fp16x3"), (kind, model.attention_precision, getattr(model, "last_range_probe", None))
+        if kind is not None and kind != "q|k|v":
             # only a hidden activation leaves the range: the final features (all the r03 guard looked at) stay small
             probe = model.last_range_probe
             assert probe[kind] > 65504.0 and probe["feature"] < 3.0e4, probe
@@ -2575,7 +2587,7 @@ def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():
     model, _ = _bench_model("n5000_b32")
     model.invalidate_packed_weights()
     _forward(model, workloads.batch("n5000_b32", 0, 1))
-    assert model.layer_gemm == "h3" and max(model.last_range_probe.values()) < 3.0e4, model.last_range_probe
+    assert model.layer_gemm == "h3" and model.attention_precision == "fp16x3" and max(model.last_range_probe.values()) < 3.0e4, model.last_range_probe
 
 
 @pytest.mark.parametrize("gemm,fmt", [("h3", "u16"), ("f32", "f32")])
