@@ -77,6 +77,11 @@ WORKLOADS.update({
                                     pair=dict(noise=0.1, scale=60.0), inlier_cycle=TRAINED_CYCLE, seed0=13000,
                                     label="KITTI-like synthetic correspondences (60 m, sigma_d=1.2 m, threshold 0.6 m), TRAINED-LIKE weights, "
                                           "inlier ratio cycling 5/10/20/40 %"),
+    # BASELINE.json configs[4] on trained-like weights: low overlap = the lower half of the inlier-ratio range
+    "trained_lomatch_n10000_b8": dict(baseline_config=4, num_corr=10000, global_batch=8, model=BASE_MODEL, weights="trained_3dmatch", logit_shift=0.0,
+                                      pair=dict(noise=0.01, scale=3.0), inlier_cycle=(0.05, 0.1, 0.15, 0.25), seed0=14000,
+                                      label="3DLoMatch-like synthetic correspondences at N=10000, TRAINED-LIKE weights, inlier ratio cycling "
+                                            "5/10/15/25 %"),
 })
 DEFAULT = "n5000_b32"
 

@@ -1904,6 +1904,57 @@ def test_match_descriptors_ties_and_ragged_sizes():
         assert np.array_equal(got, np.argmin(dm, axis=1)) or np.abs(dm[np.arange(ns), got] - dm.min(axis=1)).max() < 1e-6
 
 
+def test_match_descriptors_near_ties_and_nan_distances_resolve_like_numpy():
+    """np.argmin keeps the FIRST index among equal distances, and two different radicands can round to one distance; a NaN distance
+    (negative radicand: |dot| > 1, or a NaN input) orders first -- the FIRST NaN.  Candidates one ulp apart, a pair of different
+    radicands with the same rounded square root, chains of one-ulp improvements, inner products above 1 and a NaN descriptor, on
+    inputs whose inner products are exact in any summation order (one non-zero column per source), so that numpy's distances
+    are the kernel's.  (Written for an arg-min on radicands with an exact fallback, profiles/r05_p_match_ablation.txt -- measured, not
+    shipped; the shipped per-element scan passes it as well.)"""
+    from oracle import correspondence_oracle as CO
+    from pointdsc_amd import correspondences
+    rs = np.random.RandomState(5)
+    ns, nt, d = 200, 900, 16
+    src = np.zeros((ns, d), np.float32)
+    src[np.arange(ns), np.arange(ns) % 5] = 1.0                      # source i = unit vector of column i % 5
+    tgt = np.zeros((nt, d), np.float32)
+    tgt[:, :4] = rs.uniform(-0.6, 0.6, size=(nt, 4)).astype(np.float32)
+    tgt[:, 4] = rs.uniform(-0.6, 0.2, size=nt).astype(np.float32)
+    one = np.float32(0.75)
+
+    def ulps(x, k, towards=2.0):
+        x = np.float32(x)
+        for _ in range(k):
+            x = np.nextafter(x, np.float32(towards))
+        return x
+    # column 0: a later target one ulp closer than an earlier one (neighbouring distances after rounding)
+    tgt[100, 0], tgt[500, 0] = one, ulps(one, 1)
+    # column 1: the closer one FIRST, then near misses behind it; column 2: a chain of improvements one ulp apart
+    tgt[50, 1], tgt[60, 1], tgt[700, 1] = ulps(one, 2), one, ulps(one, 1)
+    for k in range(6):
+        tgt[120 * k + 7, 2] = ulps(one, k)
+    # column 3: inner products above 1 (negative radicand -> NaN distance): np.argmin returns the first of them
+    tgt[300, 3], tgt[200, 3], tgt[850, 3] = 1.5, 1.25, 3.0
+    # column 4: two DIFFERENT radicands (1.5000011 first, 1.500001 later) that round to the SAME distance 1.2247453: the first index
+    # wins in np.argmin, the smaller radicand would win a scan on radicands alone
+    tgt[80, 4], tgt[640, 4] = ulps(0.25, 4, towards=-2.0), np.float32(0.25)
+    with np.errstate(invalid="ignore"):
+        dm = CO.nn_distance_matrix(src, tgt)
+    assert dm[4, 80] == dm[4, 640] and tgt[80, 4] != tgt[640, 4]
+    for case_nan in (False, True):
+        t = tgt.copy()
+        if case_nan:
+            t[150, 0] = np.nan                                       # row 150: NaN distance for EVERY source (0 * NaN), before most best matches
+        got = correspondences.match_descriptors(g(torch.from_numpy(src)), g(torch.from_numpy(t))).cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            want = np.argmin(CO.nn_distance_matrix(src, t), axis=1)
+        assert np.array_equal(got, want), (case_nan, np.flatnonzero(got != want)[:8], got[:10], want[:10])
+        if case_nan:
+            assert (want == 150).all()
+        else:
+            assert want[3] == 200 and want[4] == 80 and want[0] == 500 and want[1] == 50 and want[2] == 607, want[:5]
+
+
 def test_correspondences_feed_the_forward():
     """descriptors -> build_correspondences -> PointDSC.forward: the registration of a synthetic pair is recovered."""
     from pointdsc_amd import correspondences
