@@ -21,7 +21,8 @@ def bench_table():
     names = [("n5000_b32", "configs[2], headline"), ("n1000_b1", "configs[1]"), ("kitti_n5000_b16", "configs[3]"), ("lomatch_n10000_b8", "configs[4]"),
              ("kitti_n12000_b4", "the reference's KITTI evaluation size"), ("multiway_n20000_b1", "the reference's multiway size"),
              ("trained_n5000_b32", "trained-like weights, N = 5000"), ("trained_n1000_b1", "trained-like weights, N = 1000"),
-             ("trained_kitti_n5000_b16", "trained-like weights, KITTI scale"), ("n5000_b32_per_launch_leaves", "headline with `att_leaves = per_launch`")]
+             ("trained_kitti_n5000_b16", "trained-like weights, KITTI scale"), ("trained_lomatch_n10000_b8", "trained-like weights, N = 10 000"),
+             ("n5000_b32_per_launch_leaves", "headline with `att_leaves = per_launch`")]
     for n, lab in names:
         if not (ROOT / "profiles" / f"{TAG}_bench_line_{n}.json").exists():
             continue
