@@ -48,8 +48,16 @@ def share_table():
     return "\n".join(out)
 
 
-def census(path):
-    return subprocess.run([sys.executable, str(ROOT / "tools" / "census_table.py"), str(ROOT / "profiles" / path)], capture_output=True, text=True, check=True).stdout.strip()
+def census(*paths):
+    """census_table.py over the bundle's file and, behind it, the rows of records taken after the bundle (families added later)."""
+    out = []
+    for i, path in enumerate(paths):
+        f = ROOT / "profiles" / path
+        if not f.exists():
+            continue
+        t = subprocess.run([sys.executable, str(ROOT / "tools" / "census_table.py"), str(f)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+        out += t if not out else t[2:]
+    return "\n".join(out)
 
 
 def latency_table():
@@ -66,8 +74,8 @@ def latency_table():
     return "\n".join(out)
 
 
-BLOCKS = {"bench": bench_table, "shares": share_table, "latency": latency_table, "census": lambda: census(f"{TAG}_parity_census.txt"),
-          "census_fp32": lambda: census(f"{TAG}_parity_census_exact_fp32.txt")}
+BLOCKS = {"bench": bench_table, "shares": share_table, "latency": latency_table, "census": lambda: census(f"{TAG}_parity_census.txt", f"{TAG}_q_parity_census_trained_lomatch.txt"),
+          "census_fp32": lambda: census(f"{TAG}_parity_census_exact_fp32.txt", f"{TAG}_q_parity_census_trained_lomatch_exact_fp32.txt")}
 
 if __name__ == "__main__":
     p = ROOT / "DESIGN.md"
