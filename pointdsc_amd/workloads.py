@@ -82,6 +82,15 @@ WORKLOADS.update({
                                       pair=dict(noise=0.01, scale=3.0), inlier_cycle=(0.05, 0.1, 0.15, 0.25), seed0=14000,
                                       label="3DLoMatch-like synthetic correspondences at N=10000, TRAINED-LIKE weights, inlier ratio cycling "
                                             "5/10/15/25 %"),
+    # the reference's real evaluation sizes (evaluation/test_KITTI.py:120, multiway/test_multi_ate.py:245) on trained-like weights
+    "trained_kitti_n12000_b4": dict(baseline_config=None, num_corr=12000, global_batch=4, model=KITTI_MODEL, weights="trained_kitti", logit_shift=0.0,
+                                    pair=dict(noise=0.1, scale=60.0), inlier_cycle=TRAINED_CYCLE, seed0=15000,
+                                    label="KITTI-like synthetic correspondences at the reference's evaluation size (N=12000), TRAINED-LIKE weights, "
+                                          "inlier ratio cycling 5/10/20/40 %"),
+    "trained_multiway_n20000_b1": dict(baseline_config=None, num_corr=20000, global_batch=1, model=BASE_MODEL, weights="trained_3dmatch", logit_shift=0.0,
+                                       pair=dict(noise=0.01, scale=3.0), inlier_cycle=(0.05, 0.1, 0.15, 0.25), seed0=16000,
+                                       label="3DMatch-like synthetic correspondences at the multiway evaluation size (N=20000), TRAINED-LIKE weights, "
+                                             "inlier ratio cycling 5/10/15/25 %"),
 })
 DEFAULT = "n5000_b32"
 
