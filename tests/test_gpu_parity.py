@@ -1406,7 +1406,8 @@ def test_parity_census(name, step, gemm):
 
 
 TRAINED_CENSUS = [("trained_n1000_b1", 1), ("trained_n1000_b1", 16), ("trained_n5000_b32", 32), ("trained_n5000_b32", 4),
-                  ("trained_kitti_n5000_b16", 16), ("trained_kitti_n5000_b16", 2), ("trained_lomatch_n10000_b8", 8), ("trained_lomatch_n10000_b8", 1)]
+                  ("trained_kitti_n5000_b16", 16), ("trained_kitti_n5000_b16", 2), ("trained_lomatch_n10000_b8", 8), ("trained_lomatch_n10000_b8", 1),
+                  ("trained_kitti_n12000_b4", 4), ("trained_kitti_n12000_b4", 1), ("trained_multiway_n20000_b1", 1)]
 
 
 @pytest.mark.parametrize("arith", ["default", "exact_fp32"])

@@ -45,7 +45,7 @@ if [ -z "$QUICK" ]; then
   done
   timeout 1200 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/${TAG}_parity_census.txt" 2>&1
   timeout 600 python tools/parity_census.py --batches 0 --att-leaves per_launch > "$OUT/${TAG}_parity_census_per_launch_leaves.txt" 2>&1
-  timeout 900 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,trained_lomatch_n10000_b8,kitti_n5000_b16,kitti_n12000_b4 --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
+  timeout 900 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,trained_lomatch_n10000_b8,trained_kitti_n12000_b4,trained_multiway_n20000_b1,kitti_n5000_b16,kitti_n12000_b4 --batches 0,1,2 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/${TAG}_parity_census_exact_fp32.txt" 2>&1
   timeout 300 python tools/attention_power.py --seconds 5 > "$OUT/${TAG}_attention_power.txt" 2>&1
   timeout 300 python tools/forward_power.py --seconds 4 > "$OUT/${TAG}_forward_power.txt" 2>&1
   timeout 200 python tools/forward_power.py --seconds 3 --pairs 4 > "$OUT/${TAG}_forward_power_4pairs.txt" 2>&1

@@ -118,8 +118,8 @@ for n, bs in ((257, 1), (1000, 2), (5000, 1), (1500, 9)):
 PY
   cat "$OUT/att_err.txt" ;;
 census_trained)
-  timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,trained_lomatch_n10000_b8 --batches 0,1,2,4,8,16,32 > "$OUT/parity_census_trained.txt" 2>&1
-  timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,trained_lomatch_n10000_b8 --batches 0,1 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/parity_census_trained_exact_fp32.txt" 2>&1
+  timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,trained_lomatch_n10000_b8,trained_kitti_n12000_b4,trained_multiway_n20000_b1 --batches 0,1,2,4,8,16,32 > "$OUT/parity_census_trained.txt" 2>&1
+  timeout 1200 python tools/parity_census.py --families trained_n1000_b1,trained_n5000_b32,trained_kitti_n5000_b16,trained_lomatch_n10000_b8,trained_kitti_n12000_b4,trained_multiway_n20000_b1 --batches 0,1 --attention-precision fp32 --compat-format f32 --layer-gemm f32 > "$OUT/parity_census_trained_exact_fp32.txt" 2>&1
   grep -E "^trained|strict pass|registration" "$OUT/parity_census_trained.txt" | cut -c1-400 | head -80 ;;
 census)
   timeout 1500 python tools/parity_census.py --batches 0,1,2,4,8,16,32 > "$OUT/parity_census.txt" 2>&1
