@@ -2607,7 +2607,7 @@ def test_h3_falls_back_to_fp32_gemms_outside_the_fp16_range():
                    nl + "fc_message.3.weight": 1.0e-6}
     # (r05) only the attention's operands out of range: k of one layer ~1e5 while every weight stays below 3e4 and the residual
     # stream O(1) -- the attention must leave its fp16 operand pairs
-    k_only = {nl + "projection_k.weight": 1.0e5, nl + "projection_k.bias": 1.0e5}
+    k_only = {nl + "projection_k.weight": 6.0e4, nl + "projection_k.bias": 6.0e4}     # (|w| stays below the weight check's 3e4: 0.35 x 6e4)
     for scales, kind in (({"encoder.layer0.weight": 3.0e5}, None), ({"encoder.blocks.PointCN_layer_1.0.weight": 1.0e6}, None),
                          (hidden_only, "fc_message hidden 1"), (k_only, "q|k|v")):
         model = PointDSC(**kw)

@@ -74,8 +74,8 @@ def latency_table():
     return "\n".join(out)
 
 
-BLOCKS = {"bench": bench_table, "shares": share_table, "latency": latency_table, "census": lambda: census(f"{TAG}_parity_census.txt", f"{TAG}_q_parity_census_trained_lomatch.txt"),
-          "census_fp32": lambda: census(f"{TAG}_parity_census_exact_fp32.txt", f"{TAG}_q_parity_census_trained_lomatch_exact_fp32.txt")}
+BLOCKS = {"bench": bench_table, "shares": share_table, "latency": latency_table, "census": lambda: census(f"{TAG}_parity_census.txt"),
+          "census_fp32": lambda: census(f"{TAG}_parity_census_exact_fp32.txt")}
 
 if __name__ == "__main__":
     p = ROOT / "DESIGN.md"
