@@ -14,6 +14,10 @@
 #   knn_bench       kNN of the seeds: two-launch (S x N matrix) form against the fused form
 #   match_bench     tools/match_bench.py (f-2 correspondence construction)
 #   kitti_stage     which arithmetic moves the KITTI pairs 60 / 21 / 26: one knob at a time
+#   kitti_stage_trained  the same on the trained-like KITTI family, with this library's logits against the reference's recorded ones
+#   ab_lib          same-box A/B of this build against pointdsc_amd/libpointdsc_hip_prev.so (interleaved bench lines)
+#   att_err         one split-precision attention launch against the fp64 softmax (sets the bounds of the stage test)
+#   census_multiway tools/parity_census.py on the large-N seeded families
 set -u
 TAG=${1:?tag}
 shift
