@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput bench of the PointDSC outlier-rejection hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config NAME]      (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config NAME]      (N>1: under torch.distributed.run, or plain: it re-executes itself
+                                                                        under torch.distributed.run --nproc-per-node N)
 
 Metric (BASELINE.json): point-cloud pairs/sec at N=5000 correspondences.  One "step" = one pass of the whole
 hot path (pdsc_forward_testing: compat build, 12 SCNonlocal layers, seeds, per-seed solver, scoring,
@@ -184,6 +185,152 @@ def cpu_baseline_worker(config: str, pairs: int, threads: int, check_pairs: int,
                       "oracle_labels": [torch.nonzero(c["final_labels"][0] > 0).flatten().tolist() for c in chk]}), flush=True)
 
 
+def reference_check(config, first_pair, B, N, res, dec, census_mod, w, kw, batch):
+    """Parity of one forward's outputs against the unmodified reference's outputs on the same pairs (tests/golden/census_<config>.npz:
+    its fp32 and its fp64 run; bench_<config>.npz for the large-N workloads): the contract of BASELINE.json, no looser tolerance for any
+    pair -- labels bit-exact and R/t within 1e-4 of the fp32 output; a pair outside it passes only with the reference's fp64 output
+    under the same contract or a NAMED rule of tools/parity_census.py:explain with its bounded check (same rule as test_parity_census).
+    Returns the fields of the line's `check` object."""
+    check = {}
+    gold = ROOT / "tests" / "golden" / f"census_{config}.npz"
+    gold_first = ROOT / "tests" / "golden" / f"bench_{config}.npz"
+    if not gold.exists() and gold_first.exists() and first_pair == 0:
+        # workloads without a census (the large-N ones): the reference's outputs on the FIRST pairs (oracle/make_bench_goldens.py)
+        import numpy as np
+        fxb = np.load(gold_first, allow_pickle=False)
+        g = min(B, fxb["ref_final_trans"].shape[0])
+        lab = torch.from_numpy(np.unpackbits(fxb["ref_final_labels_bits"][:g], axis=1)[:, :N].astype(np.float32))
+        dTb = (res["final_trans"][:g].cpu().double() - torch.from_numpy(fxb["ref_final_trans"][:g]).double()).abs().amax(dim=(1, 2))
+        flb = (res["final_labels"][:g].cpu() != lab).sum(dim=1)
+        check.update(pairs_vs_reference=g, max_abs_dT_vs_reference=float(dTb.max()), max_abs_dT_vs_reference_fp32=float(dTb.max()),
+                     pairs_failing_vs_reference=[int(i) for i in torch.nonzero(~((dTb < 1e-4) & (flb == 0))).flatten()],
+                     label_flips_vs_reference=int(flb.sum()),
+                     reference_outputs="tests/golden/bench_%s.npz (unmodified reference, first %d pair(s), oracle/make_bench_goldens.py)" % (config, g))
+    if gold.exists():
+        import numpy as np
+        fx = np.load(gold, allow_pickle=False)
+        f0 = first_pair
+        g = max(0, min(B, fx["ref32_final_trans"].shape[0] - f0))
+        fx = {k: (fx[k][f0:f0 + g] if getattr(fx[k], "ndim", 0) >= 1 and fx[k].shape[0] == fx["ref32_final_trans"].shape[0] else fx[k]) for k in fx.files}
+        got_T, got_lab = res["final_trans"][:g].cpu().double(), res["final_labels"][:g].cpu()
+        per = {}
+        for tag in ("ref32", "ref64"):
+            lab = torch.from_numpy(np.unpackbits(fx[tag + "_final_labels_bits"][:g], axis=1)[:, :N].astype(np.float32))
+            per[tag] = ((got_T - torch.from_numpy(fx[tag + "_final_trans"][:g]).double()).abs().amax(dim=(1, 2)), (got_lab != lab).sum(dim=1))
+        ok32 = (per["ref32"][0] < 1e-4) & (per["ref32"][1] == 0)
+        # the rule of tests/test_gpu_parity.py::test_parity_census: a pair outside the contract against the reference's fp32 output needs
+        # the reference's fp64 output under the same contract (where its two runs differ) or a NAMED rule checked against the
+        # decisions recorded in tests/golden/census_internals_<config>.npz / census_refine_<config>.npz (tools/parity_census.py)
+        ref_self = np.abs(fx["ref32_final_trans"][:g].astype(np.float64) - fx["ref64_final_trans"][:g]).max(axis=(1, 2))
+        ill = (ref_self >= 1e-4) | (fx["ref32_final_labels_bits"][:g] != fx["ref64_final_labels_bits"][:g]).any(axis=1)
+        ixp = ROOT / "tests" / "golden" / f"census_internals_{config}.npz"
+        outside, failing = [], []
+        ok64 = (per["ref64"][0] < 1e-4) & (per["ref64"][1] == 0)
+        finite = torch.isfinite(res["final_trans"][:g].cpu()).flatten(1).all(dim=1) & torch.isfinite(got_lab).all(dim=1)
+        for i in [int(i) for i in torch.nonzero(~ok32).flatten()]:
+            # (ADVICE r04) a pair on which the reference does not reproduce itself is NOT excused by that alone: the result must
+            # still be finite and either equal the reference's fp64 output under the same contract or match a decision the
+            # reference recorded (explain below) -- garbage on such a pair fails the run
+            why = "equals the reference's fp64 output (its fp32 run differs from it)" if bool(ill[i] and ok64[i]) else "no decision record"
+            excused = bool(ill[i] and ok64[i] and finite[i])
+            if dec is not None and ixp.exists():
+                try:
+                    ix = np.load(ixp, allow_pickle=False)
+                    rxp = ROOT / "tests" / "golden" / f"census_refine_{config}.npz"
+                    rx = np.load(rxp, allow_pickle=False) if rxp.exists() else None
+                    l32 = np.unpackbits(fx["ref32_final_labels_bits"][i])[:N]
+                    flipped = np.flatnonzero((got_lab[i].numpy() > 0) != (l32 > 0))
+                    okx, why = census_mod.explain(f0 + i, {k: v[i] for k, v in dec.items()}, ix,
+                                                  {k: batch[k][i] for k in ("src_keypts", "tgt_keypts")}, float(kw["inlier_threshold"]),
+                                                  float(w["pair"]["scale"]), flipped if float(per["ref32"][0][i]) < 1e-4 else None,
+                                                  nms_radius=float(kw["nms_radius"]), rx=rx, T_here=res["final_trans"][i].cpu().numpy(),
+                                                  T_ref=fx["ref32_final_trans"][i], label_flips=int(per["ref32"][1][i]))
+                    excused = (excused or bool(okx)) and bool(finite[i])
+                except Exception as e:  # noqa: BLE001
+                    why = f"explain failed: {e!r}"
+            outside.append({"pair": f0 + i, "dT_vs_ref_fp32": float(per["ref32"][0][i]), "label_flips": int(per["ref32"][1][i]),
+                            "reference_not_self_consistent": bool(ill[i]), "excused": excused, "why": why})
+            if not excused:
+                failing.append(f0 + i)
+        # (a one-pair shard whose pair sits outside with a recorded cause has NO pair inside: the maximum over the inside set is
+        #  then 0 by convention and the explicit list decides -- r05: multiway_n20000_b1 pair 0, knn-tie)
+        n_in = int(ok32.sum())
+        check.update(pairs_vs_reference=g, pairs_inside_fp32_contract=n_in,
+                     max_abs_dT_vs_reference=float(per["ref32"][0][ok32].max()) if n_in else 0.0,
+                     max_abs_dT_vs_reference_fp32=float(per["ref32"][0].max()),
+                     pairs_outside_fp32_contract=outside, pairs_failing_vs_reference=failing,
+                     outputs_finite=bool(finite.all()),
+                     label_flips_vs_reference=int(per["ref32"][1][ok32].sum()) if n_in else 0,
+                     reference_outputs="tests/golden/census_%s.npz (unmodified reference, fp32 and fp64 runs, "
+                                       "oracle/make_census_goldens.py) + census_internals_%s.npz (its recorded decisions)"
+                                       % (config, config))
+
+    return check
+
+
+def extra_leg(config, over, what, args, dev, lib, census_mod, use_tail):
+    """One short leg of another line: its own module, pairs, timed region (two forwards in flight, like the headline) and parity check
+    (reference_check on the last forward of ITS timed region).  Returns the object printed under `extra`."""
+    from pointdsc_amd import PointDSC, workloads
+    from pointdsc_amd.pipeline import InFlight
+    w = workloads.WORKLOADS[config]
+    kw = dict(w["model"])
+    B, N = w["global_batch"], w["num_corr"]
+    model = PointDSC(**kw)
+    model.load_state_dict(workloads.state_dict(config, model.state_dict()))
+    model = model.eval().to(dev)
+    for k, v in over.items():
+        setattr(model, k, v)
+    batch = workloads.batch(config, 0, B)
+    data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    data["testing"] = True
+    run2, run1 = InFlight(model, depth=2, tail_streams=use_tail), InFlight(model, depth=1)
+    for _ in range(3):
+        res = run2(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        run2(data)
+    torch.cuda.synchronize()
+    steps = max(8, min(2000, int(math.ceil(args.extra_seconds / max((time.perf_counter() - t0) / 4, 1e-5)))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = run2(data)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"what": what, "value": round(B * steps / dt, 3), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "pairs_per_step": B, "in_flight": 2, "compat_format": model.compat_format, "layer_gemm": model.layer_gemm,
+           "attention_precision": model.attention_precision,
+           "weights": "trained-like (tests/golden/%s.npz)" % w["weights"] if "weights" in w else "seeded random"}
+    last = {k: res[k].clone() for k in ("final_trans", "final_labels")}
+    dec = census_mod.decisions(model, B, N) if census_mod is not None else None
+    chk = reference_check(config, 0, B, N, last, dec, census_mod, w, kw, batch)
+    chk["ok"] = bool(chk.get("max_abs_dT_vs_reference") is not None and chk["max_abs_dT_vs_reference"] < 1e-4 and
+                     chk.get("label_flips_vs_reference") == 0 and not chk.get("pairs_failing_vs_reference") and chk.get("outputs_finite", True))
+    out["check"] = chk
+    # the compat build of this leg on one stream, hipEvents around the launch (same recorder as the headline's roofline objects)
+    n_ev = 6
+    _lib_check = __import__("pointdsc_amd._lib", fromlist=["check"]).check
+    _lib_check(lib.pdsc_profile_enable(n_ev + 4), "pdsc_profile_enable")
+    _lib_check(lib.pdsc_profile_reset(), "pdsc_profile_reset")
+    for _ in range(n_ev):
+        run1(data)
+    torch.cuda.synchronize()
+    ms, n = C.c_double(0), C.c_int(0)
+    _lib_check(lib.pdsc_profile_read(1, C.byref(ms), C.byref(n)), "pdsc_profile_read")
+    _lib_check(lib.pdsc_profile_enable(0), "pdsc_profile_enable(0)")
+    if n.value:
+        c16 = model.compat_format == "u16"
+        nbytes = ((2.0 if c16 else 4.0) * N * N + 24.0 * N) * B
+        avg = ms.value / n.value * 1e-3
+        out["roofline_compat"] = {"kernel": "compat_sym_u16_kernel" if c16 else "compat_sym_kernel", "bound": "hbm", "achieved": round(nbytes / avg / 1e9, 1),
+                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(nbytes / avg / 1e9 / PEAK_HBM_GBS, 4), "launches": n.value,
+                                  "avg_launch_ms": round(avg * 1e3, 4), "bytes_per_launch": nbytes}
+    del run2, run1, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def parse():
     from pointdsc_amd import workloads
     ap = argparse.ArgumentParser()
@@ -231,6 +378,11 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-port", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--check-pairs", type=int, default=2, help=argparse.SUPPRESS)
+    ap.add_argument("--extra", choices=["auto", "on", "off"], default="auto",
+                    help="after the headline, short legs (<= 3 s each) of the lines the headline does not show, each with its own parity "
+                         "check, printed under `extra`: the trained-like checkpoint of the same configuration and the headline workload with the "
+                         "bit-exact fp32 spatial-consistency matrix (auto: on for the default invocation -- one GPU, default config, no --latency)")
+    ap.add_argument("--extra-seconds", type=float, default=1.5, help="timed length of each extra leg")
     ap.add_argument("--first-pair", type=int, default=0,
                     help="start the workload's pair list at this pair (default 0 = the configuration as BASELINE.json quotes it); e.g. "
                          "--config kitti_n5000_b16 --global-batch 2 --first-pair 60 times and checks the census pair the parity "
@@ -262,6 +414,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: launch ourselves, one process per GPU, exactly as the driver's
+            # torch.distributed.run line would (rendezvous on 127.0.0.1, a free port); the ranks' output is ours
+            import socket
+            import subprocess
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+            log("--gpus %d without a launcher: re-executing under torch.distributed.run (%s)" % (args.gpus, " ".join(cmd[1:8])))
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            sys.exit(subprocess.run(cmd, env=env).returncode)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if args.backend == "gloo":
         local_rank %= max(torch.cuda.device_count(), 1)          # rehearsal: ranks share the visible GPU(s)
@@ -398,7 +563,7 @@ def main():
     poses_sha = hashlib.sha256(out["final_trans"].detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16] if isinstance(out, dict) else None
     # ... and the discrete decisions of that forward (seeds, votes, chosen hypothesis, refinement trace, neighbour sets), read from
     # its workspace before the next leg overwrites it: what tools/parity_census.py:explain needs should a pair leave the contract
-    timed_dec = None
+    timed_dec, census_mod = None, None
     try:
         import importlib.util
         _spec = importlib.util.spec_from_file_location("parity_census", ROOT / "tools" / "parity_census.py")
@@ -506,7 +671,12 @@ def main():
     lay_ns = int(lib.pdsc_attention_split_default_split(B, N))
     if lay_h3 and model.att_leaves != "per_launch":
         lay_ns = attention_plan(lib, B, N, model.att_leaves)["leaves"]
-    lay_bytes = (520.0 * lay_ns + 512 + 512 + 512 + 32768 / 32.0) * N * B
+    # r06: `bytes_per_launch` is the MINIMAL traffic of the fused launch, fixed by the algorithm and independent
+    # of how the attention split its keys: per point ONE message row in (512 B) + the residual row in (512 B), featB (512 B), the Q
+    # rows (fp16 hi|lo, 512 B) and the point's share of the K/V tile image (32 KiB / 32 = 1024 B) out = 3072 B.  What this
+    # implementation moves on top (one 520-byte partial per LEAF instead of one merged message) is reported as `moved_bytes`.
+    lay_bytes = 3072.0 * N * B
+    lay_moved = (520.0 * lay_ns + 512 + 512 + 512 + 32768 / 32.0) * N * B
     lay_gbs = lay_bytes / lay_avg / 1e9 if lay_n else None
     att_flops = 4.0 * 128 * float(N) * float(N) * B           # 2 GEMMs x 2 flop/MAC x C x N^2 per pair, per launch
     att_avg = att_ms / max(att_n, 1) * 1e-3
@@ -554,9 +724,12 @@ def main():
                    "att_leaves": None if fp32 else model.att_leaves,
                    "attention_plan": None if fp32 else attention_plan(lib, B, N, model.att_leaves),
                    "latency_mode": bool(args.latency), "gathered_poses_sha256_16": poses_sha,
-                   "parallelism": "pairs sharded over %d GPU(s), one all_gather of poses (%s); %d forward(s) in flight per GPU "
+                   "collective": ("none (single process, no process group)" if not (world > 1 or solo_pg) else
+                                  "all_gather_into_tensor of the 64-byte poses, %s, world %d" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", world)),
+                   "parallelism": "pairs sharded over %d GPU(s), %s; %d forward(s) in flight per GPU "
                                   "(consecutive steps alternate between HIP streams%s)"
-                                  % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU", depth["d"],
+                                  % (world, ("no collective (single process)" if not (world > 1 or solo_pg) else
+                                             "one all_gather of poses (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal, ranks share the GPU")), depth["d"],
                                      ", each replayed as a captured hipGraph" if (runners[in_flight].graphs and runners[in_flight]._captured) else "")},
         "roofline": roof,
         # H3 kernel: algorithmic HBM bytes per launch / its duration against 8 TB/s; otherwise matrix-pipe issue cycles the
@@ -565,7 +738,10 @@ def main():
                             "achieved": None if lay_gbs is None else round(lay_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": None if lay_gbs is None else round(lay_gbs / PEAK_HBM_GBS, 4),
                             "traffic": None, "launches": lay_n, "avg_launch_ms": round(lay_avg * 1e3, 4),
-                            "bytes_per_launch": lay_bytes, "flops_per_launch": lay_flops} if lay_h3 else
+                            "bytes_per_launch": lay_bytes, "bytes_per_point": 3072, "moved_bytes": lay_moved,
+                            "moved_bytes_per_point": 520 * lay_ns + 2560, "partials_read_per_point": lay_ns,
+                            "moved_frac": None if not lay_n else round(lay_moved / lay_avg / 1e9 / PEAK_HBM_GBS, 4),
+                            "flops_per_launch": lay_flops} if lay_h3 else
                            {"kernel": "layer_wave_kernel" if not lib.pdsc_layer_prefers_block(B, N) else "layer_fused_kernel",
                             "bound": "mfma", "achieved": None if lay_ghz is None else round(lay_ghz, 4), "peak": MAX_CLOCK_GHZ,
                             "unit": "G matrix-pipe cycles/s per SIMD",
@@ -589,17 +765,27 @@ def main():
     line["zero_copy_graphs"] = bool(runners[in_flight].zero_copy and line["hip_graphs"])
     if single is not None:
         line["single_stream"] = single
-    traffic_file = ROOT / "profiles" / "traffic.json"      # PMC-derived HBM bytes per launch, if collected
+    # PMC-derived HBM bytes per launch (tools/traffic_from_pmc.py writes profiles/traffic.json with the digest of the library sources it
+    # was collected on): used only when that digest is THIS library's -- a figure from another build is not this run's traffic (r05's
+    # line carried r04's number this way)
+    traffic_file = ROOT / "profiles" / "traffic.json"
+    line["traffic_source"] = None
     if traffic_file.exists():
         try:
+            from pointdsc_amd import build as _build
             tj = json.loads(traffic_file.read_text())
             key = f"{args.config}_B{B}" + ("_u16" if c16 else "")
-            if key in tj:
+            digest = _build.source_digest()
+            if tj.get("_library_source_sha256") != digest:
+                line["traffic_source"] = "profiles/traffic.json ignored: collected on library sources %s, this run's are %s" % (
+                    str(tj.get("_library_source_sha256"))[:12], digest[:12])
+            elif key in tj:
                 line["roofline"]["traffic"] = tj[key].get(line["roofline"]["kernel"])
                 line["roofline_compat"]["traffic"] = tj[key].get(line["roofline_compat"]["kernel"])
                 line["roofline_layer"]["traffic"] = tj[key].get(line["roofline_layer"]["kernel"])
-        except Exception:
-            pass
+                line["traffic_source"] = "profiles/traffic.json (%s; library sources %s = this build)" % (tj.get("_collected", "rocprofv3 --pmc"), digest[:12])
+        except Exception as e:  # noqa: BLE001
+            line["traffic_source"] = "profiles/traffic.json unreadable: %r" % (e,)
 
     # ---- parity of this run's outputs, part 1: EVERY pair of rank 0's shard against the unmodified reference's outputs on
     #      the same pairs (tests/golden/census_<config>.npz: its fp32 and its fp64 run, oracle/make_census_goldens.py).  The
@@ -613,75 +799,28 @@ def main():
             # the single-stream leg ran the same pairs on one stream afterwards: the schedule must not change a bit of the result
             check["timed_result_equals_single_stream_result_bitwise"] = bool(
                 torch.equal(timed_res["final_trans"], last["res"]["final_trans"]) and torch.equal(timed_res["final_labels"], last["res"]["final_labels"]))
-        gold = ROOT / "tests" / "golden" / f"census_{args.config}.npz"
-        gold_first = ROOT / "tests" / "golden" / f"bench_{args.config}.npz"
-        if not gold.exists() and gold_first.exists() and args.first_pair == 0:
-            # workloads without a census (the large-N ones): the reference's outputs on the FIRST pairs (oracle/make_bench_goldens.py)
-            import numpy as np
-            fxb = np.load(gold_first, allow_pickle=False)
-            g = min(B, fxb["ref_final_trans"].shape[0])
-            lab = torch.from_numpy(np.unpackbits(fxb["ref_final_labels_bits"][:g], axis=1)[:, :N].astype(np.float32))
-            dTb = (res["final_trans"][:g].cpu().double() - torch.from_numpy(fxb["ref_final_trans"][:g]).double()).abs().amax(dim=(1, 2))
-            flb = (res["final_labels"][:g].cpu() != lab).sum(dim=1)
-            check.update(pairs_vs_reference=g, max_abs_dT_vs_reference=float(dTb.max()), max_abs_dT_vs_reference_fp32=float(dTb.max()),
-                         pairs_failing_vs_reference=[int(i) for i in torch.nonzero(~((dTb < 1e-4) & (flb == 0))).flatten()],
-                         label_flips_vs_reference=int(flb.sum()),
-                         reference_outputs="tests/golden/bench_%s.npz (unmodified reference, first %d pair(s), oracle/make_bench_goldens.py)" % (args.config, g))
-        if gold.exists():
-            import numpy as np
-            fx = np.load(gold, allow_pickle=False)
-            f0 = args.first_pair
-            g = max(0, min(B, fx["ref32_final_trans"].shape[0] - f0))
-            fx = {k: (fx[k][f0:f0 + g] if getattr(fx[k], "ndim", 0) >= 1 and fx[k].shape[0] == fx["ref32_final_trans"].shape[0] else fx[k]) for k in fx.files}
-            got_T, got_lab = res["final_trans"][:g].cpu().double(), res["final_labels"][:g].cpu()
-            per = {}
-            for tag in ("ref32", "ref64"):
-                lab = torch.from_numpy(np.unpackbits(fx[tag + "_final_labels_bits"][:g], axis=1)[:, :N].astype(np.float32))
-                per[tag] = ((got_T - torch.from_numpy(fx[tag + "_final_trans"][:g]).double()).abs().amax(dim=(1, 2)), (got_lab != lab).sum(dim=1))
-            ok32 = (per["ref32"][0] < 1e-4) & (per["ref32"][1] == 0)
-            # the rule of tests/test_gpu_parity.py::test_parity_census: a pair outside the contract against the reference's fp32
-            # output needs a recorded discrete cause -- the reference not reproducing itself on it (its fp32 and fp64 runs differ in
-            # pose >= 1e-4 or in the mask), or a tie recorded in tests/golden/census_internals_<config>.npz (tools/parity_census.py)
-            ref_self = np.abs(fx["ref32_final_trans"][:g].astype(np.float64) - fx["ref64_final_trans"][:g]).max(axis=(1, 2))
-            ill = (ref_self >= 1e-4) | (fx["ref32_final_labels_bits"][:g] != fx["ref64_final_labels_bits"][:g]).any(axis=1)
-            ixp = ROOT / "tests" / "golden" / f"census_internals_{args.config}.npz"
-            outside, failing = [], []
-            ok64 = (per["ref64"][0] < 1e-4) & (per["ref64"][1] == 0)
-            finite = torch.isfinite(res["final_trans"][:g].cpu()).flatten(1).all(dim=1) & torch.isfinite(got_lab).all(dim=1)
-            for i in [int(i) for i in torch.nonzero(~ok32).flatten()]:
-                #  a pair on which the reference does not reproduce itself is NOT excused by that alone: the result must
-                # still be finite and either equal the reference's fp64 output under the same contract or match a decision the
-                # reference recorded (explain below) -- garbage on such a pair fails the run
-                why = "equals the reference's fp64 output (its fp32 run differs from it)" if bool(ill[i] and ok64[i]) else "no decision record"
-                excused = bool(ill[i] and ok64[i] and finite[i])
-                if timed_dec is not None and ixp.exists() and rank == 0:
-                    try:
-                        ix = np.load(ixp, allow_pickle=False)
-                        l32 = np.unpackbits(fx["ref32_final_labels_bits"][i])[:N]
-                        flipped = np.flatnonzero((got_lab[i].numpy() > 0) != (l32 > 0))
-                        okx, why = census_mod.explain(f0 + i, {k: v[i] for k, v in timed_dec.items()}, ix,
-                                                      {k: batch[k][i] for k in ("src_keypts", "tgt_keypts")}, float(kw["inlier_threshold"]),
-                                                      float(w["pair"]["scale"]), flipped if float(per["ref32"][0][i]) < 1e-4 else None,
-                                                      nms_radius=float(kw["nms_radius"]))
-                        excused = (excused or bool(okx)) and bool(finite[i])
-                    except Exception as e:  # noqa: BLE001
-                        why = f"explain failed: {e!r}"
-                outside.append({"pair": f0 + i, "dT_vs_ref_fp32": float(per["ref32"][0][i]), "label_flips": int(per["ref32"][1][i]),
-                                "reference_not_self_consistent": bool(ill[i]), "excused": excused, "why": why})
-                if not excused:
-                    failing.append(f0 + i)
-            # (a one-pair shard whose pair sits outside with a recorded cause has NO pair inside: the maximum over the inside set is
-            #  then 0 by convention and the explicit list decides -- r05: multiway_n20000_b1 pair 0, knn-tie)
-            n_in = int(ok32.sum())
-            check.update(pairs_vs_reference=g, pairs_inside_fp32_contract=n_in,
-                         max_abs_dT_vs_reference=float(per["ref32"][0][ok32].max()) if n_in else 0.0,
-                         max_abs_dT_vs_reference_fp32=float(per["ref32"][0].max()),
-                         pairs_outside_fp32_contract=outside, pairs_failing_vs_reference=failing,
-                         outputs_finite=bool(finite.all()),
-                         label_flips_vs_reference=int(per["ref32"][1][ok32].sum()) if n_in else 0,
-                         reference_outputs="tests/golden/census_%s.npz (unmodified reference, fp32 and fp64 runs, "
-                                           "oracle/make_census_goldens.py) + census_internals_%s.npz (its recorded decisions)"
-                                           % (args.config, args.config))
+        check.update(reference_check(args.config, args.first_pair, B, N, res, timed_dec if rank == 0 else None, census_mod, w, kw, batch))
+
+    # ---- extra legs: the lines a default invocation would otherwise never show ----
+    want_extra = args.extra == "on" or (args.extra == "auto" and world == 1 and args.config == workloads.DEFAULT and not args.latency
+                                        and not fp32 and not args.global_batch and not args.pairs_per_gpu and not args.first_pair)
+    if want_extra and world == 1:
+        line["extra"] = {}
+        legs = []
+        if ("trained_" + args.config) in workloads.WORKLOADS:
+            legs.append(("trained_" + args.config, {}, "the same configuration on the trained-like checkpoint"))
+        if model.compat_format != "f32":
+            legs.append((args.config, {"compat_format": "f32"}, "the headline workload with the spatial-consistency matrix stored as the "
+                                                                 "reference's fp32 values, bit for bit (compat_format = 'f32')"))
+        for cfg, over, what in legs:
+            try:
+                line["extra"][cfg + "".join("_%s_%s" % kv for kv in sorted(over.items()))] = extra_leg(
+                    cfg, over, what, args, dev, lib, census_mod, use_tail)
+            except Exception as e:  # noqa: BLE001
+                line["extra"][cfg] = {"error": repr(e), "ok": False}
+        c32 = next((v.get("roofline_compat") for v in line["extra"].values() if isinstance(v, dict) and v.get("roofline_compat")), None)
+        if c32 is not None:
+            line["roofline_compat"]["f32_format"] = c32
 
     # ---- CPU baseline: the reference's CPU path on this host's cores, bounded sample (rank 0, N=1 only), in a child
     #      process with a wall-clock cap so the bench always finishes; the same child runs the exact oracle on the
@@ -742,6 +881,10 @@ def main():
         check["ok"] = (max(dts) < 1e-4 and sum(fl) == 0 and not check.get("pairs_failing_vs_reference") and
                        check.get("outputs_finite", True) and
                        check.get("timed_result_equals_single_stream_result_bitwise", True)) if dts else None
+        if check["ok"] and line.get("extra"):
+            # an extra leg that misses the contract fails the run like the headline would
+            check["extra_legs_ok"] = all(bool(v.get("check", {}).get("ok")) for v in line["extra"].values())
+            check["ok"] = bool(check["extra_legs_ok"])
         line["check"] = check
     print(json.dumps(line), flush=True)
     if world > 1 or solo_pg:

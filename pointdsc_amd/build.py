@@ -70,6 +70,16 @@ def _digest(flags=None) -> str:
     return h.hexdigest()
 
 
+def source_digest() -> str:
+    """sha256 over the product library's sources (csrc/*.hip, csrc/*.h, include/pointdsc_hip.h) -- what identifies "this build" for
+    evidence files collected on the GPU box (profiles/traffic.json)."""
+    h = hashlib.sha256()
+    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "pointdsc_hip.h"]):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True, experiments: bool = False, slp: bool = False) -> Path:
     flags = FLAGS + ([] if slp else NO_SLP) + (["-DPDSC_EXPERIMENTS"] if experiments else [])
     lib, obj_dir = (SLP_LIB, SLP_OBJ_DIR) if slp else ((EXP_LIB, EXP_OBJ_DIR) if experiments else (LIB, OBJ_DIR))

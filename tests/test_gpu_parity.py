@@ -1261,6 +1261,14 @@ def test_reference_golden_pair_inside_a_batch(name, bs, pos):
 
 _BENCH_MODELS = {}
 
+# (family, batch) -> {pair: rule} of test_bench_workload_matches_reference_golden: which of the timed pairs sit outside the strict
+# fp32 contract and by which NAMED rule of tools/parity_census.py:explain (each with its own bounded check).  Everything not listed
+# is held to labels bit-exact and R/t < 1e-4 against the reference's fp32 output.
+_GOLDEN_PAIR_RULES = {
+    # the reference's k-th / (k+1)-th neighbour distances of the winning seed are 1.2e-7 apart (recorded gap)
+    ("multiway_n20000_b1", 1): {0: "knn-tie"},
+}
+
 
 LAYER_GEMM_DEFAULT = PointDSC().layer_gemm
 COMPAT_FORMAT_DEFAULT = PointDSC().compat_format
@@ -1319,18 +1327,26 @@ def test_bench_workload_matches_reference_golden(name, bs):
     mod = _census_module()
     ixp = GOLDEN / f"census_internals_{name}.npz"
     strict = (d32 < 1e-4) & (f32 == 0)
+    used = {}
     if not bool(strict.all()):
         ix = np.load(ixp, allow_pickle=False)
+        rxp = GOLDEN / f"census_refine_{name}.npz"
+        rx = np.load(rxp, allow_pickle=False) if rxp.exists() else None
         dec = mod.decisions(model, bs, n)
-        ref_self = np.abs(cfx["ref32_final_trans"][:bs].astype(np.float64) - cfx["ref64_final_trans"][:bs]).max(axis=(1, 2))
-        ill = (ref_self >= 1e-4) | (cfx["ref32_final_labels_bits"][:bs] != cfx["ref64_final_labels_bits"][:bs]).any(axis=1)
         l32 = np.unpackbits(cfx["ref32_final_labels_bits"][:bs], axis=1)[:, :n]
         for i in np.flatnonzero(~strict.numpy()).tolist():
             flipped = np.flatnonzero((res["final_labels"][i].cpu().numpy() > 0) != (l32[i] > 0))
             okx, why = mod.explain(i, {k: v[i] for k, v in dec.items()}, ix, {k: batch[k][i] for k in ("src_keypts", "tgt_keypts")},
                                    float(w["model"]["inlier_threshold"]), float(w["pair"]["scale"]), flipped if float(d32[i]) < 1e-4 else None,
-                                   nms_radius=float(w["model"]["nms_radius"]))
-            assert okx or ill[i], (i, float(d32[i]), int(f32[i]), why)
+                                   nms_radius=float(w["model"]["nms_radius"]), rx=rx, T_here=res["final_trans"][i].cpu().numpy(),
+                                   T_ref=cfx["ref32_final_trans"][i], label_flips=int(f32[i]))
+            # r06: the reference not reproducing itself on a pair passes NOTHING by itself -- outside the fp32
+            # contract a pair needs the reference's fp64 output under the same contract (ok[i]) or a NAMED rule with its bounded check
+            assert okx or bool(ok[i]), (i, float(d32[i]), int(f32[i]), why)
+            used[i] = "fp64 reference" if bool(ok[i]) and not okx else mod.rule_of(why)
+    # the golden pairs this test is parametrised on use EXACTLY these rules (no silent widening -- a new pair or a new
+    # rule on these pairs fails here and has to be added by name)
+    assert used == _GOLDEN_PAIR_RULES.get((name, bs), {}), (name, bs, used)
     # every pair of the batch, golden or not, must register (well-conditioned workload) and be a rigid motion
     T = res["final_trans"].cpu().double()
     assert (T[:, :3, :3] @ T[:, :3, :3].transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-5
@@ -1380,7 +1396,10 @@ def test_parity_census(name, step, gemm):
     contract against the unmodified reference's fp32 output (labels bit-exact, R/t within 1e-4).  A pair outside it passes ONLY
     with a recorded discrete cause, checked against what the reference itself decided on that pair
     (tests/golden/census_internals_<name>.npz, oracle/make_census_internals.py; rules in tools/parity_census.py:explain):
-      * the reference does not reproduce itself there (its own fp32 and fp64 runs differ in pose >= 1e-4 or in the label mask), or
+      * the result equals the reference's fp64 output under the same contract (r06: that the reference does not reproduce itself
+        on a pair passes nothing by itself any more), or
+      * degenerate solve: the reference's own recorded singular values say its last refinement solve ran on two correspondences;
+        the pose must then be a proper rigid motion that sends those correspondences where the reference's pose sends them, or
       * hypothesis tie: another hypothesis chosen, within one vote of the winner in the reference's votes AND in this run's, or
       * refinement: same hypothesis, the inlier-count sequence leaves the reference's by exactly one vote, or
       * kNN tie: the seed's 40-neighbour set differs and the reference recorded that seed's top-k boundary gap at round-off level, or
@@ -1447,6 +1466,61 @@ def test_parity_census_trained_like_weights(name, step, arith):
         #  into several 1e-2 deg in the reference's number and in this one alike -- the column is compared at the 0.1 deg the
         #  reference's evaluation tables print)
         assert reg["max_abs_RE_diff_deg"] < 0.1 and reg["max_abs_TE_diff_cm"] < 0.01 * scale * 3.0, reg
+
+
+@pytest.mark.parametrize("name,step,pairs", [("trained_n1000_b1", 1, 64), ("trained_n1000_b1", 16, 256), ("trained_n5000_b32", 32, 128),
+                                             ("trained_kitti_n5000_b16", 16, 128), ("trained_lomatch_n10000_b8", 8, 32)])
+def test_trained_checkpoint_stage_decisions_equal_the_reference(name, step, pairs):
+    """the stage tests on discrete work (a-5 seeds, a-6 neighbour sets, a-10 votes) tolerate a few per cent
+    of near-tie differences because SEEDED weights collapse the feature space (top-k boundary gaps of 5e-7).  On the trained-like
+    checkpoints (gaps of 8e-4) there is no such excuse, so here equality is demanded at 100 %, against what the unmodified reference
+    itself decided on every pair (tests/golden/census_internals_<name>.npz: its seeds, neighbour-set hashes, integer votes, chosen
+    hypothesis, refinement inlier counts):
+      * the seed list (order included) equals the reference's on every pair,
+      * the 40-neighbour set of EVERY seed of every pair equals the reference's (FNV hash of the sorted set),
+      * the vote count of EVERY hypothesis equals the reference's, and so does the chosen one,
+      * the refinement's inlier-count sequence equals the reference's.
+    Only exception, named and checked: pairs on which the reference's own logits leave fewer than S positive keys (its seed list is
+    then partly torch.argsort's order of keys tied at zero -- models/PointDSC.py:211-217; recognised from its recorded logits)."""
+    if not (GOLDEN / f"census_internals_{name}.npz").exists():
+        pytest.skip(f"tests/golden/census_internals_{name}.npz not generated")
+    model, _ = _bench_model(name)
+    mod = _census_module()
+    ix = np.load(GOLDEN / f"census_internals_{name}.npz", allow_pickle=False)
+    w = workloads.WORKLOADS[name]
+    n, S = w["num_corr"], int(w["num_corr"] * w["model"]["ratio"])
+    total = min(pairs, ix["seeds32"].shape[0])
+    # the zero-key regime, from the reference's recorded logits alone
+    zero_key = set()
+    checked = {"pairs": 0, "seeds": 0, "votes": 0}
+    for first in range(0, total, step):
+        g_ = min(step, total - first)
+        batch = workloads.batch(name, first, g_)
+        _forward(model, batch)
+        dec = mod.decisions(model, g_, n)
+        for b in range(g_):
+            i = first + b
+            conf = ix["conf32"][i]
+            src = batch["src_keypts"][b].float()
+            d = torch.cdist(src[None], src[None])[0].numpy()
+            is_max = ((conf[:, None] >= conf[None, :]) | (d >= np.float32(w["model"]["nms_radius"]))).all(axis=1)
+            if int(((conf * is_max) > 0).sum()) < S:
+                zero_key.add(i)
+                continue
+            assert np.array_equal(dec["seeds"][b], ix["seeds32"][i]), (i, "seed list differs", int((dec["seeds"][b] != ix["seeds32"][i]).sum()))
+            hashes = np.array([mod.set_hash(r) for r in dec["knn"][b]], dtype=np.uint64)
+            bad = np.flatnonzero(hashes != ix["knn_hash32"][i])
+            assert len(bad) == 0, (i, "neighbour sets differ on seeds", bad[:8].tolist(), "reference gaps", ix["knn_gap32"][i][bad[:8]].tolist())
+            assert np.array_equal(dec["counts"][b], ix["counts32"][i]), (i, "votes differ", int((dec["counts"][b] != ix["counts32"][i]).sum()),
+                                                                        int(np.abs(dec["counts"][b] - ix["counts32"][i]).max()))
+            assert int(dec["best"][b]) == int(ix["best32"][i]), (i, "chosen hypothesis differs")
+            assert np.array_equal(dec["trace"][b][:21], ix["refine_counts32"][i]), (i, dec["trace"][b][:21].tolist(), ix["refine_counts32"][i].tolist())
+            checked["pairs"] += 1
+            checked["seeds"] += S
+            checked["votes"] += S
+    print(f"{name} x{step}: {checked}; zero-key pairs skipped {sorted(zero_key)}")
+    assert len(zero_key) <= max(3, total // 40), sorted(zero_key)
+    assert checked["pairs"] >= total - len(zero_key)
 
 
 @pytest.mark.parametrize("fmt", ["f32", "u16"])

@@ -233,3 +233,60 @@ def test_bench_check_judges_a_census_pair_outside_the_contract_by_its_recorded_c
     assert chk["ok"] is True and chk["timed_result_equals_single_stream_result_bitwise"] is True and chk["pairs_failing_vs_reference"] == []
     for p in chk["pairs_outside_fp32_contract"]:
         assert p["excused"] and p["pair"] in (60, 61) and ("knn-tie" in p["why"] or p["why"].startswith(("tie", "refinement", "label-edge"))), p
+
+
+@pytest.mark.gpu
+def test_plain_bench_invocation_with_eight_gpus_launches_itself():
+    """`python bench.py --gpus 8` WITHOUT a launcher (no WORLD_SIZE in the environment) must not exit -- it re-executes
+    itself under torch.distributed.run, one process per rank (here --backend gloo: 8 ranks on the one visible GPU), and prints the one
+    JSON line of the 8-rank job; the one-process line says that no collective ran."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    common = ["--steps", "2", "--warmup", "1", "--config", "n5000_b32", "--no-cpu-baseline", "--sustain-seconds", "0", "--settle-seconds", "0"]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--backend", "gloo"] + common,
+                       capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["pairs_per_gpu"] == 4 and line["value"] > 0 and line["check"]["ok"] is not False
+    assert "all_gather" in line["config"]["collective"] and "world 8" in line["config"]["collective"]
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--extra", "off"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=str(root), env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line1["config"]["collective"].startswith("none") and "RCCL" not in line1["config"]["parallelism"]
+
+
+def test_plain_multi_gpu_invocation_reexecutes_under_the_launcher(monkeypatch):
+    """The same on a box without a GPU: the re-execution itself (command line, rendezvous address, environment), with subprocess.run
+    replaced by a recorder -- no forward runs."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("bench_under_test", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = list(cmd), dict(env or {})
+        return subprocess.CompletedProcess(cmd, 0)
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in seen["env"]

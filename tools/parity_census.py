@@ -85,6 +85,67 @@ def set_hash(idx) -> int:
 KNN_TIE_GAP = 2e-6
 
 
+# A weighted Procrustes solve (models/common.py:7-45) determines its rotation only when the 3x3 covariance H has rank >= 2.  Below this
+# ratio of the reference's OWN second to first singular value (as torch.svd returned them inside the reference's post-refinement,
+# tests/golden/census_refine_<name>.npz, oracle/make_census_refine_sv.py) the solve had two correspondences or collinear ones: every
+# rotation about their common line fits equally, and the null-space columns of U and V are whatever LAPACK leaves there (the
+# reference's fp32 and fp64 runs land O(1) apart on such pairs).  Measured on the census: the two pairs this rule fires on record
+# s2/s1 = 0 ... 3e-8; the smallest ratio of any other LAST solve in the twelve families is > 1e-2.
+DEGENERATE_SV_RATIO = 1e-4
+
+
+def _kabsch64(A, B, w):
+    """models/common.py:19-42 in fp64 numpy (the chain below only needs it to walk from one recorded inlier set to the next)."""
+    w = np.where(w < 0, 0.0, w)
+    ca = (A * w[:, None]).sum(0) / (w.sum() + 1e-6)
+    cb = (B * w[:, None]).sum(0) / (w.sum() + 1e-6)
+    H = (A - ca).T @ ((B - cb) * w[:, None])
+    U, _, Vt = np.linalg.svd(H)
+    V = Vt.T
+    D = np.diag([1.0, 1.0, np.linalg.det(V @ U.T)])
+    R = V @ D @ U.T
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, cb - R @ ca
+    return T
+
+
+def degenerate_solve(i: int, ix, rx, batch_row, T_here, T_ref):
+    """(holds, text).  NOT an excuse by itself: when the reference's last refinement solve on pair i was rank-deficient (its own
+    recorded singular values), the contract's pose comparison is replaced by the comparison the data still determines -- the pose
+    returned here must be finite, a proper rigid motion, and send every correspondence that entered that solve to within 1e-4 of where
+    the reference's fp32 pose sends it (two points fix the translation of their centroid and the direction of their line, not the
+    rotation about it)."""
+    if rx is None or batch_row is None or T_here is None:
+        return False, "no singular-value record"
+    solves = int(rx["refine_solves32"][i])
+    if solves == 0:
+        return False, "the reference ran no refinement solve"
+    sv = rx["refine_sv32"][i][solves - 1]
+    ratio = float(sv[1] / sv[0]) if sv[0] > 0 else 0.0
+    if not ratio < DEGENERATE_SV_RATIO:
+        return False, f"the reference's last solve is well-posed (singular values {sv.tolist()})"
+    src, tgt = batch_row["src_keypts"].double().numpy(), batch_row["tgt_keypts"].double().numpy()
+    thr = float(ix["refine_threshold"])
+    T = ix["initial_trans32"][i].astype(np.float64)
+    inl = None
+    for s in range(solves):                                                    # models/PointDSC.py:421-437, walked in fp64
+        l2 = np.linalg.norm(src @ T[:3, :3].T + T[:3, 3] - tgt, axis=1)
+        inl = l2 < thr
+        if int(inl.sum()) != int(rx["refine_inliers32"][i][s]):
+            return False, f"fp64 walk of the refinement leaves the reference's recorded inlier counts at solve {s}"
+        if s < solves - 1:
+            T = _kabsch64(src[inl], tgt[inl], 1.0 / (1.0 + (l2[inl] / thr) ** 2))
+    Th, Tr = np.asarray(T_here, np.float64), np.asarray(T_ref, np.float64)
+    R = Th[:3, :3]
+    rigid = bool(np.isfinite(Th).all() and np.abs(R.T @ R - np.eye(3)).max() < 1e-5 and np.linalg.det(R) > 0 and np.array_equal(Th[3], [0, 0, 0, 1]))
+    d = np.abs((src[inl] @ R.T + Th[:3, 3]) - (src[inl] @ Tr[:3, :3].T + Tr[:3, 3])).max()
+    text = (f"degenerate-solve: the reference's last refinement solve ran on {int(inl.sum())} correspondences, singular values "
+            f"{[float(f'{x:.3g}') for x in sv]} (s2/s1 = {ratio:.1e} < {DEGENERATE_SV_RATIO:.0e}): the rotation about their line is not determined; "
+            f"the pose returned here is {'a proper rigid motion' if rigid else 'NOT a rigid motion'} and sends those correspondences to within "
+            f"{d:.1e} of where the reference's pose sends them (allowed 1e-4)")
+    return bool(rigid and d < 1e-4), text
+
+
 def knn_tie(dec, ix, i: int, corr: int):
     """(differs, gap): does the neighbour set of the seed sitting on correspondence `corr` differ between this run and the
     reference's fp32 run, and what boundary gap did the reference record for that seed."""
@@ -100,6 +161,8 @@ def rule_of(text: str) -> str:
         return "knn-tie"
     if text.startswith("zero-key tie"):
         return "zero-key tie"
+    if text.startswith("degenerate-solve"):
+        return "degenerate-solve"
     return text.split(":")[0]
 
 
@@ -129,7 +192,7 @@ def zero_key_tie(ix, i: int, dec, batch_row, nms_radius: float):
                        f"({r_corr}, key {'0' if zero[1] else 'positive'})")
 
 
-def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None, nms_radius=None):
+def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None, nms_radius=None, rx=None, T_here=None, T_ref=None, label_flips=None):
     """Why pair i may leave BASELINE.json's contract: checked against what the reference itself decided on that pair
     (tests/golden/census_internals_<name>.npz, oracle/make_census_internals.py).  Returns (excused, text).
       tie          the GPU chose another hypothesis than the reference (models/PointDSC.py:329 argmax over integer vote counts), the
@@ -145,7 +208,10 @@ def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None,
       zero-key tie the two seed lists differ, the reference's own recorded logits leave fewer than S positive keys (the rest of its seed
                    list is drawn from keys tied at 0 in torch.argsort's backend-defined order), one of the two chosen hypotheses sits on
                    such a key, and the hypothesis found here has at least the reference's maximal vote count minus one.
-    Anything else is not excused."""
+      degenerate-solve  same hypothesis, same refinement sequence, same neighbour set, labels equal, and the reference's own recorded
+                   singular values say its last refinement solve was rank-deficient (two correspondences): the pose comparison is
+                   replaced by the one the data determines (degenerate_solve above) -- a bounded check, not a pass.
+    Anything else is not excused, whether or not the reference's fp32 and fp64 runs agree with each other on the pair."""
     seeds_r, counts_r, best_r = ix["seeds32"][i], ix["counts32"][i], int(ix["best32"][i])
     g_corr, r_corr = int(dec["seeds"][dec["best"]]), int(seeds_r[best_r])
     if g_corr != r_corr:
@@ -208,6 +274,10 @@ def explain(i: int, dec, ix, batch_row=None, thr=None, scale=None, flipped=None,
         eps = 8 * 2.0 ** -24 * scale
         ok = bool((np.abs(res - thr) <= eps).all())
         return ok, f"label-edge: same hypothesis and refinement; flipped correspondences {list(map(int, flipped))} have residuals {np.abs(res - thr).tolist()} from the threshold (allowed {eps:.1e})"
+    if label_flips == 0:
+        holds, text = degenerate_solve(i, ix, rx, batch_row, T_here, T_ref)
+        if holds or text.startswith("degenerate-solve"):
+            return holds, text
     return False, f"same hypothesis, same refinement sequence, neighbour set {'equal' if differs is not None else 'not recorded'}: no recorded discrete cause"
 
 
@@ -215,6 +285,8 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
     fx = np.load(ROOT / "tests" / "golden" / f"census_{name}.npz", allow_pickle=False)
     ixp = ROOT / "tests" / "golden" / f"census_internals_{name}.npz"
     ix = np.load(ixp, allow_pickle=False) if ixp.exists() else None
+    rxp = ROOT / "tests" / "golden" / f"census_refine_{name}.npz"
+    rx = np.load(rxp, allow_pickle=False) if rxp.exists() else None
     w = workloads.WORKLOADS[name]
     n = w["num_corr"]
     total = fx["ref32_final_trans"].shape[0] if pairs <= 0 else min(pairs, fx["ref32_final_trans"].shape[0])
@@ -259,7 +331,8 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
                 flipped = np.flatnonzero((Lall[i] > 0) != (l32[i] > 0))
                 verdicts[int(i)] = explain(int(i), D[i], ix, {k: one[k][0] for k in ("src_keypts", "tgt_keypts")},
                                            float(w["model"]["inlier_threshold"]), float(w["pair"]["scale"]),
-                                           flipped if float(d32[i]) < 1e-4 else None, nms_radius=float(w["model"]["nms_radius"]))
+                                           flipped if float(d32[i]) < 1e-4 else None, nms_radius=float(w["model"]["nms_radius"]),
+                                           rx=rx, T_here=torch.cat(T)[int(i)].numpy(), T_ref=fx["ref32_final_trans"][int(i)], label_flips=int(f32[i]))
         d = dbest.numpy()
         hist = [int(((d >= lo) & (d < hi)).sum()) for lo, hi in zip((0.0,) + EDGES, EDGES + (np.inf,))]
         t64 = torch.from_numpy(fx["ref64_final_trans"][:total]).double()
@@ -295,7 +368,11 @@ def run_family(name: str, batches, compat_format=None, layer_gemm=None, pairs: i
                      "outside_fp32_contract_detail": [{"pair": i, "dT_vs_ref_fp32": float(d32[i]), "label_flips": int(f32[i]), "excused": bool(v[0]),
                                                        "reference_not_self_consistent": bool(ill[i]), "why": v[1]} for i, v in verdicts.items()],
                      "reference_not_self_consistent": [int(i) for i in np.flatnonzero(ill)],
-                     "unexcused": [i for i, v in verdicts.items() if not v[0] and not ill[i]] if ix is not None else None}
+                     # r06: a pair on which the reference does not reproduce itself is no longer passed for that alone -- outside the fp32 contract a
+                     # pair needs the reference's fp64 output under the same contract (ok) or a NAMED rule of explain(), whatever `ill` says
+                     "unexcused": [i for i, v in verdicts.items() if not v[0] and not bool(ok[i])] if ix is not None else None,
+                     "excused_by_rule": {r: sorted(i for i, v in verdicts.items() if v[0] and rule_of(v[1]) == r)
+                                         for r in sorted({rule_of(v[1]) for v in verdicts.values() if v[0]})}}
     return out, model
 
 
@@ -331,6 +408,7 @@ def main():
                     print("    ", json.dumps(fd), flush=True)
                 print(f"    outside the fp32 contract: {r['outside_fp32_contract']}; unexcused by the reference's recorded decisions: {r['unexcused']}; "
                       f"strict pass rate {r['strict_fp32_contract_pass_rate']:.4f}; excuses used {r['excuses_used']}", flush=True)
+                print(f"    pairs excused, by rule: {json.dumps(r['excused_by_rule'])}", flush=True)
                 print(f"    registration: {json.dumps(r['registration'])}", flush=True)
                 for fd in r["outside_fp32_contract_detail"]:
                     print("      ", json.dumps(fd), flush=True)
