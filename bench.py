@@ -308,7 +308,11 @@ def extra_leg(config, over, what, args, dev, lib, census_mod, use_tail):
     chk["ok"] = bool(chk.get("max_abs_dT_vs_reference") is not None and chk["max_abs_dT_vs_reference"] < 1e-4 and
                      chk.get("label_flips_vs_reference") == 0 and not chk.get("pairs_failing_vs_reference") and chk.get("outputs_finite", True))
     out["check"] = chk
-    # the compat build of this leg on one stream, hipEvents around the launch (same recorder as the headline's roofline objects)
+    if model.compat_format != "f32":
+        del run2, run1, model
+        torch.cuda.empty_cache()
+        return out
+    # the fp32-format compat build on one stream, hipEvents around the launch (same recorder as the headline's roofline objects)
     n_ev = 6
     _lib_check = __import__("pointdsc_amd._lib", fromlist=["check"]).check
     _lib_check(lib.pdsc_profile_enable(n_ev + 4), "pdsc_profile_enable")
@@ -818,7 +822,8 @@ def main():
                     cfg, over, what, args, dev, lib, census_mod, use_tail)
             except Exception as e:  # noqa: BLE001
                 line["extra"][cfg] = {"error": repr(e), "ok": False}
-        c32 = next((v.get("roofline_compat") for v in line["extra"].values() if isinstance(v, dict) and v.get("roofline_compat")), None)
+        c32 = next((v.get("roofline_compat") for v in line["extra"].values()
+                    if isinstance(v, dict) and (v.get("roofline_compat") or {}).get("kernel") == "compat_sym_kernel"), None)
         if c32 is not None:
             line["roofline_compat"]["f32_format"] = c32
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PDSC_VERSION 7
+#define PDSC_VERSION 8
 #define PDSC_CHANNELS 128        /* num_channels of every released PointDSC model */
 #define PDSC_MAX_K 64            /* neighbours per seed handled by one wavefront   */
 #define PDSC_MAX_POWER_ITERS 32
@@ -132,9 +132,12 @@ enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
  *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 16/3 x the matrix-pipe time.
  *   FP16X3_ALL: the point-wise GEMMs too (pdsc_layer_fused_x3): their error lands on the residual stream un-averaged.
  *           A/B record: accepted by experiments builds only.
- * (PDSC_ATT_BF16X3 / _ALL: the rounds 1-4 names of values 0 / 2, kept as aliases.) */
-enum pdsc_attention_precision { PDSC_ATT_FP16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_FP16X3_ALL = 2,
-                                PDSC_ATT_BF16X3 = PDSC_ATT_FP16X3, PDSC_ATT_BF16X3_ALL = PDSC_ATT_FP16X3_ALL };
+ * BREAKING in PDSC_VERSION 8: the names PDSC_ATT_BF16X3 / PDSC_ATT_BF16X3_ALL of rounds 1-4 are GONE (they were aliases of values 0 / 2
+ * in version 7).  Those modes split into bf16 pairs and had fp32's range; values 0 / 2 split into fp16 pairs and do not -- a C caller
+ * that still spells the old name must not compile into different arithmetic silently.  Range contract of FP16X3: every forward
+ * carries a device-side sentinel (workspace entry "range_flag", [bs] u32, pdsc_workspace_offset): a pair any of whose activations
+ * reached 65504 on its way into an fp16 pair has a non-zero word there after the call AND its final_trans is returned as NaN. */
+enum pdsc_attention_precision { PDSC_ATT_FP16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_FP16X3_ALL = 2 };
 
 /* ---- packed weights --------------------------------------------------------------------------
  * One flat fp32 buffer holding the model with BatchNorm (eval) folded into the preceding conv and

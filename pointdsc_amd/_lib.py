@@ -151,7 +151,7 @@ def load() -> C.CDLL:
             raise PointDSCLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.pdsc_version() != 7:
+    if lib.pdsc_version() != 8:
         raise PointDSCLibraryError(f"unexpected library version {lib.pdsc_version()}")
     _lib = lib
     return lib

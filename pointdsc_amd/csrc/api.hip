@@ -8,6 +8,7 @@
 #include <mutex>
 #include "pdsc_common.h"
 #include "ragged.h"
+#include "attention_common.h"
 
 namespace pdsc {
 
@@ -15,6 +16,11 @@ static thread_local char g_err[512] = "";
 
 const int*& layer_nvalid_slot() {
     static thread_local const int* slot = nullptr;
+    return slot;
+}
+
+unsigned int*& range_flag_slot() {
+    static thread_local unsigned int* slot = nullptr;
     return slot;
 }
 
@@ -252,6 +258,7 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
     L.add("best", (size_t)bs * sizeof(int));
     L.add("initial_trans", (size_t)bs * 16 * f);
     L.add("solves", (size_t)bs * sizeof(int));
+    L.add("range_flag", (size_t)bs * sizeof(unsigned int));      // fp16 range sentinel (pdsc_common.h): != 0 = pair b left the fp16 range
     L.add("refine_trace", (size_t)bs * PDSC_REFINE_TRACE * sizeof(int));      // inlier count per refinement iteration, -1 padded (parity census)
 #ifdef PDSC_EXPERIMENTS
     L.add("score_dbg", (size_t)bs * S * 16 * f);        // diagnostics of the scoring kernel (score.hip, DBG)
@@ -358,18 +365,20 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         explicit SlotGuard(const int* p) { layer_nvalid_slot() = p; }
         ~SlotGuard() { layer_nvalid_slot() = nullptr; }
     } slot_guard(nvalid);
+    struct RangeGuard {      // ... and the range sentinel's flag array (pdsc_common.h)
+        ~RangeGuard() { range_flag_slot() = nullptr; }
+    } range_guard;
     hipStream_t hst = (hipStream_t)stream;
     if (nvalid) {
         PDSC_REQUIRE(mode == 0 && svalid, "pdsc_forward_testing_ragged: testing forward only, both count arrays needed");
-        PDSC_REQUIRE(cfg->attention_precision != PDSC_ATT_FP32, "pdsc_forward_testing_ragged: needs a split-precision attention mode "
-                     "(the exact-fp32 attention kernel takes one N per launch)");
         PDSC_REQUIRE(n_min >= 2 && n_min <= N, "pdsc_forward_testing_ragged: n_min=%d (N=%d)", n_min, N);
         // one launch has one neighbour count k = min(cfg->k, N - 1); the reference clamps per pair, k_b = min(k, num_corr_b - 1)
         // (models/PointDSC.py:250): a pair with fewer than k + 1 correspondences must be its own call
         PDSC_REQUIRE(n_min > (cfg->k < N - 1 ? cfg->k : N - 1), "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has no "
                      "more than k=%d: the reference clamps k per pair (k = min(k, num_corr - 1)); run such a pair in its own call",
                      n_min, cfg->k < N - 1 ? cfg->k : N - 1);
-        PDSC_REQUIRE(cfg->att_leaves >= PDSC_LEAVES_CANONICAL || (n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
+        PDSC_REQUIRE(cfg->attention_precision == PDSC_ATT_FP32 || cfg->att_leaves >= PDSC_LEAVES_CANONICAL ||
+                     (n_min + 31) / 32 >= pdsc_attention_split_default_split(bs, N),
                      "pdsc_forward_testing_ragged: the shortest pair (%d correspondences) has fewer 32-key tiles than the key split "
                      "planned for bs=%d, N=%d (%d): batch pairs of more similar size", n_min, bs, N, pdsc_attention_split_default_split(bs, N));
     }
@@ -406,6 +415,9 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     const size_t att_bytes = L.bytes_of("att_scratch");
     void* q_split = split ? ws + L.find("q_split") : nullptr;
     void* kv_tiles = split ? ws + L.find("kv_tiles") : nullptr;
+    // fp16 range sentinel: zeroed by the layer0 launch, set by the layer kernels' conversion sites, read by the refinement launch
+    unsigned int* range_flag = split && !probe ? (unsigned int*)(ws + L.find("range_flag")) : nullptr;
+    range_flag_slot() = range_flag;
 
     // Step 1 (models/PointDSC.py:150-155): compat, then the SCNonlocal encoder
     const bool compat16 = split && cfg->compat_format == PDSC_COMPAT_U16;
@@ -417,7 +429,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         return launch_attention_split_ex(q_split, kv_tiles, compat, compat16 ? PDSC_COMPAT_U16 : PDSC_COMPAT_F32, ld, msg_out, att_scratch,
                                          att_bytes, bs, N, nsplit, PDSC_PARTIALS_ROWS, nvalid, hst);
     };
-    PDSC_TRY(pdsc_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, stream));
+    PDSC_TRY(launch_layer0(corr_pos, cfg->in_dim, W(PDSC_W_LAYER0_W, 0), W(PDSC_W_LAYER0_B, 0), featA, M, range_flag, bs, hst));
     // probe != NULL (pdsc_encoder_range_probe): one launch per conv, every intermediate in the workspace, |max| of each kind recorded
     const int fused = probe ? 0 : env_int("PDSC_FUSED_LAYERS", 1);          // tuning/A-B knob: 0 = one pdsc_linear launch per conv
     auto P = [&](int kind, const float* x, size_t count) { return probe ? launch_absmax(x, count, probe + kind, hst) : PDSC_OK; };
@@ -525,7 +537,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
                                   stream));
         float *cur = featB, *nxt = featC;
         for (int i = 0; i < cfg->num_layers; ++i) {
-            PDSC_TRY(pdsc_sc_attention(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, stream));
+            PDSC_TRY(launch_attention_fp32(qkv, compat, ld, msg, att_scratch, att_bytes, bs, N, 0, nvalid, hst));      // (r06: ragged batches too)
             const bool last = i + 1 == cfg->num_layers;
             PDSC_TRY(pdsc_layer_fused(msg, cur, nullptr, last ? featA : nullptr, last ? nullptr : nxt, last ? nullptr : qkv,
                                       W(PDSC_W_FC1_W, i), W(PDSC_W_FC1_B, i), W(PDSC_W_FC2_W, i), W(PDSC_W_FC2_B, i),
@@ -611,7 +623,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     if (mode == 0) {
         PDSC_TRY(launch_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S, nvalid, hst));
         // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
-        PDSC_TRY(launch_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N, nvalid, hst, I("refine_trace")));
+        PDSC_TRY(launch_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N, nvalid, hst, I("refine_trace"), range_flag));
     } else {
         // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,

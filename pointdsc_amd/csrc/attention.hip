@@ -61,21 +61,26 @@ __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int qb = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
-    const int N = a.N;
+    // ragged batches: this pair's own count decides its queries, its keys and its tile range; the strides stay those of the longest pair
+    const int NS = a.N;
+    const int N = a.nvalid ? a.nvalid[b] : NS;
+    if (qb * ATT_BQ >= N) return;                                   // (uniform over the workgroup: no query of this block exists)
+    const int ntiles = a.nvalid ? ceil_div_dev(N, ATT_BK) : a.num_tiles;
 
-    // key-tile range of this split: tiles [kt0, kt1)
-    const int per = a.num_tiles / a.nsplit, rem = a.num_tiles % a.nsplit;
+    // key-tile range of this split: tiles [kt0, kt1) -- possibly empty for a short pair of a ragged batch: its partial is then
+    // (m = -1e30, l = 0, O = 0), which the merge weighs with exp2(-1e30 - max) = 0
+    const int per = ntiles / a.nsplit, rem = ntiles % a.nsplit;
     const int kt0 = sp * per + min(sp, rem);
     const int kt1 = kt0 + per + (sp < rem ? 1 : 0);
 
-    const float* qkvb = a.qkv + (size_t)b * N * ATT_QKV_LD;
+    const float* qkvb = a.qkv + (size_t)b * NS * ATT_QKV_LD;
     const float* kbase = qkvb + ATT_C;
     const float* vbase = qkvb + 2 * ATT_C;
     const int qrow = min(qb * ATT_BQ + wave * 32 + l31, N - 1);
-    const float* crow = a.compat + ((size_t)b * N + qrow) * a.ld + 4 * h;
+    const float* crow = a.compat + ((size_t)b * NS + qrow) * a.ld + 4 * h;
 
     // prologue: first K/V tile in flight, then this lane's Q fragment
-    issue_tile_loads(kbase, vbase, kt0 * ATT_BK, N, lds, lds + 2 * ATT_TILE_FLOATS, wave, lane);
+    if (kt0 < kt1) issue_tile_loads(kbase, vbase, kt0 * ATT_BK, N, lds, lds + 2 * ATT_TILE_FLOATS, wave, lane);
     f32x4 qf[16];
     {
         const float* qsrc = qkvb + (size_t)qrow * ATT_QKV_LD + 4 * h;
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
     }
     f32x4 cc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const f32x4*>(crow + kt0 * ATT_BK + 8 * g);
+    for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const f32x4*>(crow + min(kt0, ntiles - 1) * ATT_BK + 8 * g);
 
     f32x16 o[4];
 #pragma unroll
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void sc_attention_kernel(AttArgs a) {
     const int query = qb * ATT_BQ + wave * 32 + l31;
     if (query < N) {
         if (a.nsplit == 1) {
-            float* dst = a.msg + ((size_t)b * N + query) * ATT_C;
+            float* dst = a.msg + ((size_t)b * NS + query) * ATT_C;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(AttArgs a) {
     const int b = blockIdx.y;
     const long long query = gid >> 5;
     const int c4 = (int)(gid & 31) * 4;
-    if (query >= a.N) return;
+    if (query >= (a.nvalid ? a.nvalid[b] : a.N)) return;
     float mmax = -INFINITY;
     for (int sp = 0; sp < a.nsplit; ++sp) {
         const size_t slot = ((size_t)b * a.nsplit + sp) * a.Npad + query;
@@ -286,8 +291,11 @@ extern "C" size_t pdsc_attention_scratch_bytes(int bs, int N, int nsplit) {
     return slots * (pdsc::ATT_C + 2) * sizeof(float);
 }
 
-extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long long ld, float* msg, void* scratch,
-                                 size_t scratch_bytes, int bs, int N, int nsplit, void* stream) {
+namespace pdsc {
+int launch_attention_fp32(const float* qkv, const float* compat, long long ld, float* msg, void* scratch, size_t scratch_bytes, int bs, int N,
+                          int nsplit, const int* nvalid, hipStream_t st_in) {
+    void* stream = (void*)st_in;
+
     PDSC_REQUIRE(qkv && compat && msg, "pdsc_sc_attention: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0, "pdsc_sc_attention: bs=%d N=%d", bs, N);
     PDSC_REQUIRE(ld >= pdsc::round_up(N, pdsc::ATT_BK) && ld % 4 == 0,
@@ -303,6 +311,7 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
     pdsc::AttArgs a{};
     a.qkv = qkv; a.compat = compat; a.ld = ld; a.msg = msg;
     a.N = N; a.Npad = pdsc::attention_npad(N); a.nsplit = nsplit; a.num_tiles = tiles;
+    a.nvalid = nvalid;
     a.part_o = (float*)scratch;
     a.part_ml = a.part_o ? a.part_o + (size_t)bs * nsplit * a.Npad * pdsc::ATT_C : nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -329,4 +338,10 @@ extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long lon
         rc = pdsc::launch_attention_combine(a, bs, st);
     }
     return rc;
+}
+}  // namespace pdsc
+
+extern "C" int pdsc_sc_attention(const float* qkv, const float* compat, long long ld, float* msg, void* scratch,
+                                 size_t scratch_bytes, int bs, int N, int nsplit, void* stream) {
+    return pdsc::launch_attention_fp32(qkv, compat, ld, msg, scratch, scratch_bytes, bs, N, nsplit, nullptr, (hipStream_t)stream);
 }

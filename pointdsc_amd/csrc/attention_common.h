@@ -12,6 +12,7 @@ struct AttArgs {
     float* part_o;           // [bs][nsplit][Npad][128]   un-normalised partial outputs
     float* part_ml;          // [bs][nsplit][Npad][2]     (running max (log2 domain), partial sum)
     int N, Npad, nsplit, num_tiles;
+    const int* nvalid;       // ragged batches (r06): [bs] correspondences per pair (<= N; strides stay those of N), or NULL
 };
 
 // arguments of the split-precision kernels (attention_split.hip)
@@ -41,5 +42,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // merge of the per-split partials (defined in attention.hip)
 int launch_attention_combine(const AttArgs& a, int bs, hipStream_t st);
+// exact-fp32 attention with an optional per-pair count array (ragged batches; pdsc_sc_attention = the same with NULL)
+int launch_attention_fp32(const float* qkv, const float* compat, long long ld, float* msg, void* scratch, size_t scratch_bytes, int bs, int N,
+                          int nsplit, const int* nvalid, hipStream_t st);
 
 }  // namespace pdsc

@@ -32,6 +32,7 @@ struct LayerArgs {
     int io_flags;            // enum pdsc_layer_io: which of part_o / res / featB_out are in point-fragment order (layer_h3.hip only)
     int stagger_cycles, stagger_mode;   // layer_h3.hip: start delay of half the first round's wavefronts (A/B knobs PDSC_LAYER_STAGGER, _MODE)
     long long* trace;        // diagnostics (pdsc_layer_trace): [workgroup][wave][16] shader-clock stamps, else NULL
+    unsigned int* range_flag; // fp16 range sentinel (pdsc_common.h): [bs] words, or NULL outside a forward
     const int* nvalid;       // ragged batches (ragged.h): [bs] correspondences per pair (<= N): tiles past a pair's own rows are
                              // skipped, its last tile is padded / zeroed from ITS count; NULL = every pair has N rows
 };

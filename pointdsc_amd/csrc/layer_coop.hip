@@ -76,6 +76,7 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
     const size_t row = (size_t)m0 + min(l31, valid - 1);
     float* Vs = Vs_all[w];
     unsigned char* patch = reinterpret_cast<unsigned char*>(Vs);
+    float rmax = 0.f;            // fp16 range sentinel (pdsc_common.h): largest |activation| this lane converts to an fp16 pair
 
     // ---- this wavefront's weight chunks in the order it uses them: sequence position k = 0..11 --------------------------------
     //   0, 1: fc1 tile w (waves 0, 1 only)   2: fc2 tile w (waves 0, 1 only)   3: fc3 tile w   4, 5: pcn tile w
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         }
         {
             u32x4 ph, pl;
-            make_kstep<true>(x0[0], x0[1], ph, pl); put(0, 2 * w, ph, pl);
-            make_kstep<true>(x0[2], x0[3], ph, pl); put(0, 2 * w + 1, ph, pl);
+            make_kstep<true>(x0[0], x0[1], ph, pl, rmax); put(0, 2 * w, ph, pl);
+            make_kstep<true>(x0[2], x0[3], ph, pl, rmax); put(0, 2 * w + 1, ph, pl);
         }
         // residual rows of this wave's fc3 tile (needed three stages on: the loads fly under fc1 / fc2)
         {
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s][e] = fmaxf(v[s][e], 0.f);
             u32x4 ph, pl;
-            make_kstep<true>(v[0], v[1], ph, pl); put(1, 2 * w, ph, pl);
-            make_kstep<true>(v[2], v[3], ph, pl); put(1, 2 * w + 1, ph, pl);
+            make_kstep<true>(v[0], v[1], ph, pl, rmax); put(1, 2 * w, ph, pl);
+            make_kstep<true>(v[2], v[3], ph, pl, rmax); put(1, 2 * w + 1, ph, pl);
         } else {
             issue(std::integral_constant<int, NB>{});                 // (waves 2, 3: positions 0..2 are empty, their slots free)
             issue(std::integral_constant<int, NB + 1>{});
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s][e] = fmaxf(v[s][e], 0.f);
             u32x4 ph, pl;
-            make_kstep<true>(v[0], v[1], ph, pl); put(0, 2 * w, ph, pl);
-            make_kstep<true>(v[2], v[3], ph, pl); put(0, 2 * w + 1, ph, pl);
+            make_kstep<true>(v[0], v[1], ph, pl, rmax); put(0, 2 * w, ph, pl);
+            make_kstep<true>(v[2], v[3], ph, pl, rmax); put(0, 2 * w + 1, ph, pl);
         } else {
             issue(std::integral_constant<int, NB + 2>{});
         }
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
     if constexpr (H) {
         {
             u32x4 ph, pl;
-            make_kstep<true>(y3[0], y3[1], ph, pl); put(1, 2 * w, ph, pl);
-            make_kstep<true>(y3[2], y3[3], ph, pl); put(1, 2 * w + 1, ph, pl);
+            make_kstep<true>(y3[0], y3[1], ph, pl, rmax); put(1, 2 * w, ph, pl);
+            make_kstep<true>(y3[2], y3[3], ph, pl, rmax); put(1, 2 * w + 1, ph, pl);
         }
         __syncthreads();
 
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         }
         {
             u32x4 ph, pl;
-            make_kstep<false>(v[0], v[1], ph, pl); put(0, 2 * w, ph, pl);
-            make_kstep<false>(v[2], v[3], ph, pl); put(0, 2 * w + 1, ph, pl);
+            make_kstep<false>(v[0], v[1], ph, pl, rmax); put(0, 2 * w, ph, pl);
+            make_kstep<false>(v[2], v[3], ph, pl, rmax); put(0, 2 * w + 1, ph, pl);
         }
         __syncthreads();
 
@@ -293,6 +294,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         run_chunk(std::integral_constant<int, 6>{}, 0, 0, true, true_type{});
         run_chunk(std::integral_constant<int, 7>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) range_note(rmax, v[s]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             unsigned hi[2], lo[2];
@@ -314,6 +317,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         run_chunk(std::integral_constant<int, 9>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);
 #pragma unroll
+        for (int s = 0; s < 4; ++s) range_note(rmax, v[s]);
+#pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x4 z = v[s];
 #pragma unroll
@@ -327,6 +332,8 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
         run_chunk(std::integral_constant<int, 10>{}, 0, 0, true, true_type{});
         run_chunk(std::integral_constant<int, 11>{}, 0, 1, false, true_type{});
         coop_finish<true>(acc, cross, v);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) range_note(rmax, v[s]);
         wave_lds_sync();                                                              // (the Q passes have read the patch)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(64 * LC_WAVES, NB <= 4 ? 2 : 1) void layer_h3_coop_
             *reinterpret_cast<u32x4*>(img + SPL_VL + off) = u32x4{clo[0], clo[1], clo[2], clo[3]};
         }
     }
+    range_report(a.range_flag, b, rmax);
 }
 
 int launch_layer_h3_coop(const LayerArgs& a, bool tail, bool head, hipStream_t st) {

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
         }
     }
     LH_STAMP(0)
+    float rmax = 0.f;            // fp16 range sentinel: largest |activation| this lane converts to an fp16 hi / lo pair
     constexpr int NCH = num_chunks<T, H>();
     WChunk w[NBUF];
     static_for<0, NBUF - 1>([&](auto jc) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
 #pragma unroll
             for (int q = 0; q < 16; ++q) x0[q] = *reinterpret_cast<const f32x4*>(a.msg + row * PDSC_CHANNELS + 8 * q + 4 * h);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) make_kstep<true>(x0[2 * kk], x0[2 * kk + 1], a0h[kk], a0l[kk]);
+            for (int kk = 0; kk < 8; ++kk) make_kstep<true>(x0[2 * kk], x0[2 * kk + 1], a0h[kk], a0l[kk], rmax);
         } else {
             // merge of the attention's key-split partials, the arithmetic of merge_partials_finish (merge_partials.h)
             auto run = [&](auto ns_tag) {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                         }                                               // to the first MFMA and keeps every batch of loads live)
                     }
 #pragma unroll
-                    for (int kk = q0 / 2; kk < (q0 + GQ) / 2; ++kk) make_kstep<true>(x0[2 * kk], x0[2 * kk + 1], a0h[kk], a0l[kk]);
+                    for (int kk = q0 / 2; kk < (q0 + GQ) / 2; ++kk) make_kstep<true>(x0[2 * kk], x0[2 * kk + 1], a0h[kk], a0l[kk], rmax);
                     __builtin_amdgcn_sched_barrier(0);               // keep the next batch's loads behind this batch's use
                 }
             };
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
 #pragma unroll
         for (int q = 0; q < 16; ++q) y3[q] = *reinterpret_cast<const f32x4*>(a.feat_in + row * PDSC_CHANNELS + 8 * q + 4 * h);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) make_kstep<true>(y3[2 * kk], y3[2 * kk + 1], ayh[kk], ayl[kk]);
+        for (int kk = 0; kk < 8; ++kk) make_kstep<true>(y3[2 * kk], y3[2 * kk + 1], ayh[kk], ayl[kk], rmax);
     }
     LH_STAMP(1)
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                 for (int e = 0; e < 4; ++e) v[s][e] = fmaxf(v[s][e], 0.f);
                 if constexpr (s & 1)
                     make_kstep<true>(v[s - 1], v[s], (d.stage == ST_FC1 ? a1h : a2h)[2 * d.tile + (s >> 1)],
-                                     (d.stage == ST_FC1 ? a1l : a2l)[2 * d.tile + (s >> 1)]);
+                                     (d.stage == ST_FC1 ? a1l : a2l)[2 * d.tile + (s >> 1)], rmax);
             }
         } else if constexpr (d.stage == ST_FC3) {
             if constexpr (s < 4) {
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                 // inputs were loaded from it), so their stores repeat that row's bytes: no predicate, no branch
                 if constexpr (!H && !(EXP & 2)) *reinterpret_cast<f32x4*>(a.feat_out + row * PDSC_CHANNELS + n0 + 8 * s + 4 * h) = y3[4 * d.tile + s];
                 if constexpr (H && (s & 1))
-                    make_kstep<true>(y3[4 * d.tile + s - 1], y3[4 * d.tile + s], ayh[2 * d.tile + (s >> 1)], ayl[2 * d.tile + (s >> 1)]);
+                    make_kstep<true>(y3[4 * d.tile + s - 1], y3[4 * d.tile + s], ayh[2 * d.tile + (s >> 1)], ayl[2 * d.tile + (s >> 1)], rmax);
             }
         } else if constexpr (d.stage == ST_PCN) {
             // featB = relu: fp32 rows leave through the patch as whole 128-byte lines; fp16 hi / lo operands of q|k|v
@@ -222,9 +223,10 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
                 }
             }
             if constexpr (s == 4 || s == 5)
-                make_kstep<false>(v[2 * (s - 4)], v[2 * (s - 4) + 1], xqh[2 * d.tile + (s - 4)], xql[2 * d.tile + (s - 4)]);
+                make_kstep<false>(v[2 * (s - 4)], v[2 * (s - 4) + 1], xqh[2 * d.tile + (s - 4)], xql[2 * d.tile + (s - 4)], rmax);
         } else {
             // q | k | v, output tile d.tile of 12: tiles 0..3 = q, 4..7 = k, 8..11 = v
+            if constexpr (s < 4) range_note(rmax, v[s]);
             {
                 if constexpr (d.tile >= 4 && d.tile < 8) {
                     // K image, chunk-major (split_layout.h): after the half swap lane (key l31, half h) holds chunk 4(t-4)+s of its
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(64 * NWV, NBUF > 2 ? 1 : 2) void layer_h3_kernel(La
     });
 
     LH_STAMP(63)
+    range_report(a.range_flag, b, rmax);
 }
 
 bool launch_layer_h3_fits(const LayerArgs& a, bool tail, bool head) {
@@ -495,6 +498,7 @@ extern "C" int pdsc_layer_fused_frag_io(const float* msg, const float* part_o, c
     a.stagger_mode = env_int("PDSC_LAYER_STAGGER_MODE", 1);
     a.trace = nullptr;
     a.nvalid = layer_nvalid_slot();
+    a.range_flag = range_flag_slot();
     PDSC_REQUIRE(launch_layer_h3_fits(a, tail, head), "pdsc_layer_fused_frag_io: output set not served by the point-fragment kernel "
                                                      "(tail + head: no feat_out; tail only: feat_out)");
     return launch_layer_h3(a, tail, head, (hipStream_t)stream);

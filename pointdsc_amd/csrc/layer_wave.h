@@ -190,6 +190,20 @@ __device__ __forceinline__ u32x4 chunk_for_store(const unsigned (&hi)[2], const 
 // `b` = channels 16kk + 8 + 4h + e of its point; the k-step wants channels 16kk + 8h .. +7 in lane-half h.  F16 selects the
 // fp16 hi / scaled-lo split (H3) instead of the unscaled fp16 hi / lo split.
 template <bool F16>
+__device__ __forceinline__ void make_kstep(const f32x4& a_in, const f32x4& b_in, u32x4& oh, u32x4& ol, float& rmax) {
+    f32x4 a = a_in, b = b_in;
+    range_note(rmax, a);
+    range_note(rmax, b);
+    unsigned ha[2], la[2], hb[2], lb[2];
+    if constexpr (F16) { split4h(a, ha, la); split4h(b, hb, lb); }
+    else { split4(a, ha, la); split4(b, hb, lb); }
+    half_swap(ha[0], hb[0]); half_swap(ha[1], hb[1]);
+    half_swap(la[0], lb[0]); half_swap(la[1], lb[1]);
+    oh = u32x4{ha[0], ha[1], hb[0], hb[1]};
+    ol = u32x4{la[0], la[1], lb[0], lb[1]};
+}
+
+template <bool F16>
 __device__ __forceinline__ void make_kstep(const f32x4& a, const f32x4& b, u32x4& oh, u32x4& ol) {
     unsigned ha[2], la[2], hb[2], lb[2];
     if constexpr (F16) { split4h(a, ha, la); split4h(b, hb, lb); }

@@ -8,6 +8,7 @@
 // convention used throughout this library: k-slot (step t = 4q+e, half h = lane>>5) <-> channel 8q+4h+e,
 // so one ds_read_b128 per lane feeds 4 MFMA steps for both A and B.
 #include "pdsc_common.h"
+#include "ragged.h"
 
 namespace pdsc {
 
@@ -120,7 +121,10 @@ constexpr int L0_LD = 16;            // floats per row of PDSC_W_LAYER0_W
 template <int KD>
 __global__ __launch_bounds__(256) void layer0_kernel(const float* __restrict__ corr, int in_dim,
                                                      const float* __restrict__ W0, const float* __restrict__ b0,
-                                                     float* __restrict__ feat, int M) {
+                                                     float* __restrict__ feat, int M, unsigned int* __restrict__ range_flag, int bs) {
+    // (r06) the forward's range sentinel starts clean: this is the first launch of the encoder
+    if (range_flag && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < bs; i += 256) range_flag[i] = 0u;
     const int c4 = (threadIdx.x & 31) * 4, rl = threadIdx.x >> 5;        // 32 channel groups x 8 row lanes, grid-stride over rows
     float w[4][KD], bias[4];
 #pragma unroll
@@ -419,16 +423,23 @@ extern "C" int pdsc_linear(const float* X, long long ldx, const float* W, const 
     return pdsc::launch_linear<1, 0>(a, 1, st);
 }
 
-extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat, int M,
-                           void* stream) {
+namespace pdsc {
+int launch_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat, int M, unsigned int* range_flag, int bs,
+                  hipStream_t st) {
     PDSC_REQUIRE(corr_pos && W0 && b0 && feat, "pdsc_layer0: null pointer");
     PDSC_REQUIRE(in_dim >= 1 && in_dim <= 16 && M > 0, "pdsc_layer0: in_dim=%d (1..16) M=%d", in_dim, M);
-    const int blocks = pdsc::ceil_div(M, 8) < pdsc::L0_MAX_BLOCKS ? pdsc::ceil_div(M, 8) : pdsc::L0_MAX_BLOCKS;
+    const int blocks = ceil_div(M, 8) < L0_MAX_BLOCKS ? ceil_div(M, 8) : L0_MAX_BLOCKS;
     if (in_dim <= 8)
-        hipLaunchKernelGGL(pdsc::layer0_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, corr_pos, in_dim, W0, b0, feat, M);
+        hipLaunchKernelGGL(layer0_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, corr_pos, in_dim, W0, b0, feat, M, range_flag, bs);
     else
-        hipLaunchKernelGGL(pdsc::layer0_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, corr_pos, in_dim, W0, b0, feat, M);
-    return pdsc::check_launch("pdsc_layer0");
+        hipLaunchKernelGGL(layer0_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, corr_pos, in_dim, W0, b0, feat, M, range_flag, bs);
+    return check_launch("pdsc_layer0");
+}
+}  // namespace pdsc
+
+extern "C" int pdsc_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat, int M,
+                           void* stream) {
+    return pdsc::launch_layer0(corr_pos, in_dim, W0, b0, feat, M, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int pdsc_classifier_hidden(const float* feat, const float* W1, const float* b1, const float* W2, const float* b2, float* h2,

@@ -44,6 +44,15 @@ int launch_copy_u32(unsigned int* dst, const unsigned int* src, size_t count, hi
 int launch_classifier_hidden(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, float* H2, int M,
                              hipStream_t st);
 
+// fp16 range sentinel (r06): the split-precision arithmetic carries activations as fp16 hi + lo pairs, so |x| must stay below 65504.
+// Every site that converts an activation notes its magnitude (range_note: one v_max3_f32 per two values); a wavefront whose maximum
+// reaches the bound sets the word of its pair in `range_flag` ([bs] u32, workspace entry "range_flag": zeroed by the forward's first
+// launch, read by its last one, which turns the pose of such a pair into NaN -- a result that is wrong is never returned silently).
+// run_forward publishes the array through this thread-local slot for the duration of a call (like layer_nvalid_slot, ragged.h);
+// stage-level calls outside a forward leave it NULL and the kernels skip the report.
+unsigned int*& range_flag_slot();
+constexpr float PDSC_F16_RANGE = 65504.0f;
+
 // opt-in event timing of the roofline kernels (api.hip); no-ops unless pdsc_profile_enable() was called
 void profile_mark_begin(int kind, hipStream_t st);
 void profile_mark_end(int kind, hipStream_t st);
@@ -86,6 +95,23 @@ __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) /
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// running maximum of |x| over the values a lane converts to fp16: ONE v_max3_f32 per two values (|abs| source modifiers; v_max ignores
+// NaN operands: a NaN input is not an overflow and propagates on its own, as it does in the reference).  The values are in/out operands
+// of the statement although it does not change them: the conversion that follows then depends on it, so the scheduler cannot sink the
+// note past the point where the fp32 values die (as plain fmaxf calls it sank them to the end of the pinned pipelines of layer_h3.hip
+// and kept every fp32 source alive: 295 spilled registers).
+__device__ __forceinline__ void range_note(float& r, float& x0, float& x1) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(r), "+v"(x0), "+v"(x1));
+}
+__device__ __forceinline__ void range_note(float& r, f32x4& v) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(r), "+v"(v[0]), "+v"(v[1]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(r), "+v"(v[2]), "+v"(v[3]));
+}
+// end of a wavefront's work: one store per wavefront and only when the bound was reached (all writers store the same value)
+__device__ __forceinline__ void range_report(unsigned int* flag, int pair, float r) {
+    if (flag && __builtin_amdgcn_ballot_w64(!(r < PDSC_F16_RANGE)) != 0ull && (threadIdx.x & 63) == 0) flag[pair] = 1u;
+}
 
 // Euclidean norm of a 3-vector with torch's CPU/GPU reduction order: sqrt(fma(z,z,fma(y,y,x*x))).
 // (oracle/pointdsc_oracle.py:pairwise_dist documents the measurement.)  sqrtf is IEEE-correct

@@ -29,7 +29,11 @@ int launch_score_hypotheses(const float* seed_trans, const float* src, const flo
 int launch_select_best(const int* counts, const float* seed_trans, const float* src, const float* tgt, float inlier_threshold, int* best,
                        float* best_trans, float* labels, int bs, int N, int S, const int* nvalid, hipStream_t st);
 int launch_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold, int max_iters,
-                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st, int* trace = nullptr);
+                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st, int* trace = nullptr,
+                           const unsigned int* range_flag = nullptr);
+// linear.hip: encoder.layer0; range_flag != NULL: its first bs words are zeroed by this launch (the forward's first encoder launch)
+int launch_layer0(const float* corr_pos, int in_dim, const float* W0, const float* b0, float* feat, int M, unsigned int* range_flag, int bs,
+                  hipStream_t st);
 constexpr int PDSC_REFINE_TRACE = 24;      // ints per pair in the workspace entry "refine_trace"
 // msg != NULL: merged output rows (key split 1, or the combine launch); msg == NULL: the key-split partials stay in `scratch`
 int launch_attention_split_ex(const void* q_split, const void* kv_tiles, const void* compat, int compat_format, long long ld,

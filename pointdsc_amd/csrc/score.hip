@@ -65,7 +65,8 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict
 __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ initial_trans, const float* __restrict__ src,
                                                       const float* __restrict__ tgt, float thr, int max_iters,
                                                       float* __restrict__ final_trans, int* __restrict__ solves, int NS,
-                                                      const int* __restrict__ nvalid, int* __restrict__ trace) {
+                                                      const int* __restrict__ nvalid, int* __restrict__ trace,
+                                                      const unsigned int* __restrict__ range_flag) {
     __shared__ float red[8 * 9];
     __shared__ float Tc[16];
     const int t = threadIdx.x, b = blockIdx.x;
@@ -123,7 +124,10 @@ __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ i
         ++solved;
         __syncthreads();
     }
-    if (t < 16) final_trans[(size_t)b * 16 + t] = Tc[t];
+    // fp16 range sentinel (pdsc_common.h): a pair whose activations left the range of the split-precision arithmetic was computed from
+    // inf / NaN operands somewhere in the encoder -- its pose is returned as NaN, never as a plausible-looking wrong motion
+    const bool poisoned = range_flag && range_flag[b] != 0u;
+    if (t < 16) final_trans[(size_t)b * 16 + t] = poisoned ? __builtin_nanf("") : Tc[t];
     if (t == 0 && solves) solves[b] = solved;
 }
 
@@ -158,10 +162,11 @@ int launch_select_best(const int* counts, const float* seed_trans, const float* 
 }
 
 int launch_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold, int max_iters,
-                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st, int* trace) {
+                           float* final_trans, int* solves, int bs, int N, const int* nvalid, hipStream_t st, int* trace,
+                           const unsigned int* range_flag) {
     PDSC_REQUIRE(initial_trans && src && tgt && final_trans, "pdsc_post_refinement: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && max_iters >= 0, "pdsc_post_refinement: bs=%d N=%d iters=%d", bs, N, max_iters);
-    hipLaunchKernelGGL(refine_kernel, dim3(bs), dim3(512), 0, st, initial_trans, src, tgt, threshold, max_iters, final_trans, solves, N, nvalid, trace);
+    hipLaunchKernelGGL(refine_kernel, dim3(bs), dim3(512), 0, st, initial_trans, src, tgt, threshold, max_iters, final_trans, solves, N, nvalid, trace, range_flag);
     return check_launch("pdsc_post_refinement");
 }
 

@@ -30,8 +30,10 @@ from . import _lib
 
 _NUM_CHANNELS = 128
 # enum pdsc_attention_precision (include/pointdsc_hip.h)
-ATTENTION_PRECISIONS = {"fp16x3": 0, "fp32": 1, "fp16x3_all": 2,
-                        "bf16x3": 0, "bf16x3_all": 2}      # (the rounds 1-4 names of the same modes: the operand pairs were bf16 then)
+ATTENTION_PRECISIONS = {"fp16x3": 0, "fp32": 1, "fp16x3_all": 2}
+# r06: "bf16x3", the rounds 1-4 name, is no longer an alias -- the operand pairs are fp16 since r05 and do NOT have bf16's
+# (= fp32's) range, so a caller who asks for the old mode by name gets an error that says so instead of silently different arithmetic
+_RETIRED_PRECISIONS = {"bf16x3": "fp16x3", "bf16x3_all": "fp16x3_all"}
 # enum pdsc_compat_format
 COMPAT_FORMATS = {"f32": 0, "u16": 1}
 # enum pdsc_layer_gemm
@@ -118,7 +120,7 @@ class PointDSC(nn.Module):
                 nn.init.constant_(m.bias, 0)
         # Not a reference constructor argument (the signature stays the reference's): arithmetic of the two
         # attention contractions.  "fp16x3" = split-precision f16 MFMA, every operand as an fp16 hi + lo pair (default; ~2^-21
-        # per product), "fp32" = exact fp32 MFMA.  "bf16x3" is accepted as the old name of "fp16x3".  (Experiments builds of the
+        # per product), "fp32" = exact fp32 MFMA.  ("bf16x3", the rounds 1-4 mode with fp32's range, is gone: asking for it raises.)  (Experiments builds of the
         # library also take "fp16x3_all": the point-wise GEMMs in split precision too -- an A/B record, rejected by the product
         # library.)
         # Module attributes only -- neither the module nor the library reads the environment.  Set before calling forward.
@@ -139,6 +141,22 @@ class PointDSC(nn.Module):
         # "per_launch" = one partial per key split of the launch plan (the r01-r04 bits: they move with the batch size, within the
         # contract; the fastest form); int 2..8: that many leaves (tuning)
         self.att_leaves = "canonical"
+        # fp16 range guard of the split-precision arithmetic (r06).  Every forward carries a device-side sentinel (workspace entry
+        # "range_flag": one word per pair, set by any activation that reaches 65504 on its way into an fp16 hi / lo pair; the library
+        # returns NaN poses for such pairs, never a plausible wrong motion).  What the MODULE does with it:
+        #   "sync" (default for the plain call): wait for the forward, read the words, and if any is set warn, switch this module to the
+        #           exact-fp32 arithmetic (kept) and re-run THIS call -- the caller gets the fp32 answer.  Costs one 4 x bs byte copy and
+        #           makes the call synchronous, which the reference's evaluation loop is anyway (it reads every result back).
+        #   "lazy": the words are copied to pinned memory behind the forward and looked at by a later call (or check_range()): the
+        #           affected call has returned NaN poses by then; the module warns and switches to fp32 for the calls that follow.
+        #           pipeline.InFlight always runs in this mode (its forwards must not synchronise).
+        #   "off" : nothing is read back (the NaN poses of the library remain).
+        self.range_guard = "sync"
+        self._guard_override = None             # set by pipeline.InFlight for the duration of its calls
+        self._range_pending = []                # lazy mode: (event, pinned words, call number)
+        self._range_pool = []                   # pinned [bs] int32 buffers, recycled
+        self._calls = 0
+        self.range_fallbacks = 0                # how many calls the guard found out of range (diagnostics / tests)
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
@@ -153,9 +171,14 @@ class PointDSC(nn.Module):
     def _config(self) -> _lib.PdscConfig:
         # reference post_refinement picks its threshold by exact equality with 0.10 (:415-418)
         refine_thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
+        if self.attention_precision in _RETIRED_PRECISIONS:
+            raise ValueError(f"attention_precision {self.attention_precision!r} was retired in library version 8: the split operands are fp16 "
+                             f"pairs now ({_RETIRED_PRECISIONS[self.attention_precision]!r}: 22 mantissa bits, but fp16's range -- |activation| "
+                             "< 65504, guarded per forward by model.range_guard); there is no mode with bf16's range any more, use "
+                             f"{_RETIRED_PRECISIONS[self.attention_precision]!r} or 'fp32'")
         if self.attention_precision not in ATTENTION_PRECISIONS:
             raise ValueError(f"attention_precision must be one of ['fp16x3', 'fp32'], got {self.attention_precision!r}")
-        if self.attention_precision in ("fp16x3_all", "bf16x3_all") and not _lib.load().pdsc_experiments_enabled():
+        if self.attention_precision == "fp16x3_all" and not _lib.load().pdsc_experiments_enabled():
             raise ValueError('attention_precision "fp16x3_all" (all-split layer GEMMs, an A/B record) exists in experiments builds of the '
                              "library only (python -m pointdsc_amd.build --experiments); the product accepts 'fp16x3' and 'fp32'")
         if self.compat_format not in COMPAT_FORMATS:
@@ -378,15 +401,13 @@ class PointDSC(nn.Module):
             out.append(g)
         return out + small
 
-    def _run(self, corr_pos, src_keypts, tgt_keypts, testing, counts=None):
+    def _run(self, corr_pos, src_keypts, tgt_keypts, testing, counts=None, _in_fallback=False):
         lib = _lib.load()
         dev = corr_pos.device
         bs, n = corr_pos.shape[0], corr_pos.shape[1]
         if counts is not None:
             if not testing:
                 raise NotImplementedError("ragged batches are supported in testing mode only (the validation forward returns an N x N matrix per pair)")
-            if self.attention_precision == "fp32":
-                raise NotImplementedError('ragged batches need a split-precision attention mode (attention_precision = "fp16x3")')
             groups = self._ragged_groups(counts)
             if len(groups) > 1 or min(counts) <= self.k:      # too heterogeneous for one launch plan (or pairs of at most k rows): one call per group
                 final_trans = torch.empty(bs, 4, 4, device=dev, dtype=torch.float32)
@@ -449,7 +470,78 @@ class PointDSC(nn.Module):
                 rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
                 what = "pdsc_forward_validation"
         _lib.check(rc, what)
-        return {"final_trans": final_trans, "final_labels": final_labels, "M": M}
+        res = {"final_trans": final_trans, "final_labels": final_labels, "M": M}
+        if wsplit is not None and not _in_fallback:
+            redo = self._guard_after_forward(ws, cfg, bs, n, num_seeds, dev)
+            if redo:
+                # exact-fp32 arithmetic from here on (kept for this module, like the range probe's fallback): same inputs, same call
+                return self._run(corr_pos, src_keypts, tgt_keypts, testing, counts, _in_fallback=True)
+        return res
+
+    # ------------------------------------------------------------------------------------------
+    def _flag_view(self, ws, cfg, bs, n, num_seeds):
+        off = int(_lib.load().pdsc_workspace_offset(C.byref(cfg), bs, n, num_seeds, b"range_flag"))
+        if off < 0:
+            raise RuntimeError("libpointdsc_hip.so has no 'range_flag' workspace entry (library older than the module)")
+        return ws[off:off + 4 * bs].view(torch.int32)
+
+    def _to_exact_fp32(self, why: str) -> None:
+        warnings.warn("pointdsc_amd: " + why + "; this module now uses attention_precision='fp32', layer_gemm='f32' (exact fp32, ~3.5x "
+                      "slower; set the attributes back after fixing the input scale or the checkpoint)", RuntimeWarning)
+        self.layer_gemm = "f32"
+        self.attention_precision = "fp32"
+
+    def _guard_after_forward(self, ws, cfg, bs, n, num_seeds, dev) -> bool:
+        """Range sentinel of the forward just enqueued (see range_guard in __init__).  True = re-run this call in exact fp32."""
+        mode = self._guard_override or self.range_guard
+        if mode not in ("sync", "lazy", "off"):
+            raise ValueError(f"range_guard must be 'sync', 'lazy' or 'off', got {mode!r}")
+        self._calls += 1
+        if mode == "off":
+            return False
+        self._poll_range(block=False)
+        flags = self._flag_view(ws, cfg, bs, n, num_seeds)
+        host = next((t for t in self._range_pool if t.numel() >= bs), None)
+        if host is not None:
+            self._range_pool.remove(host)
+        else:
+            host = torch.empty(max(bs, 32), dtype=torch.int32).pin_memory()
+        host[:bs].copy_(flags, non_blocking=True)
+        if mode == "lazy" or torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._range_pending.append((ev, host, bs, self._calls))
+            return False
+        torch.cuda.current_stream(dev).synchronize()
+        bad = host[:bs].numpy().nonzero()[0].tolist()
+        self._range_pool.append(host)
+        if not bad:
+            return False
+        self.range_fallbacks += 1
+        self._to_exact_fp32(f"activations of pair(s) {bad} of this batch reached the fp16 range (|x| >= 65504) of the split-precision "
+                            "arithmetic; re-running this call in exact fp32")
+        return True
+
+    def _poll_range(self, block: bool) -> None:
+        keep = []
+        for ev, host, bs, call in self._range_pending:
+            if block:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host, bs, call))
+                continue
+            bad = host[:bs].numpy().nonzero()[0].tolist()
+            self._range_pool.append(host)
+            if bad and self.attention_precision != "fp32":
+                self.range_fallbacks += 1
+                self._to_exact_fp32(f"forward number {call} of this module left the fp16 range (|x| >= 65504) of the split-precision arithmetic on "
+                                    f"pair(s) {bad}: the poses it returned for them are NaN")
+        self._range_pending = keep
+
+    def check_range(self) -> int:
+        """Wait for the forwards whose range words are still in flight ('lazy' guard) and apply them; returns range_fallbacks."""
+        self._poll_range(block=True)
+        return self.range_fallbacks
 
     RANGE_KINDS = ("layer0", "PointCN", "q|k|v", "message", "fc_message hidden 1", "fc_message hidden 2", "feature")
 

@@ -118,7 +118,11 @@ class InFlight:
         s = self.streams[slot]
         if s is None:                                            # depth 1: the plain synchronous-enqueue call
             with torch.no_grad():
-                res = self.model(data)
+                self.model._guard_override = "lazy" if self.model.range_guard != "off" else "off"      # (no host sync inside a pipeline)
+                try:
+                    res = self.model(data)
+                finally:
+                    self.model._guard_override = None
             if post is not None:
                 res["post"] = post(res)
             return res
@@ -133,10 +137,12 @@ class InFlight:
             res = self._replay(slot, s, data) if self.graphs else None
             if res is None:
                 self.model._ws_slot = self._slots[slot]
+                self.model._guard_override = "lazy" if self.model.range_guard != "off" else "off"
                 try:
                     res = self.model(data)
                 finally:
                     self.model._ws_slot = 0
+                    self.model._guard_override = None
             if post is not None:
                 res["post"] = post(res)
             ev = torch.cuda.Event()
@@ -162,6 +168,8 @@ class InFlight:
                 static = {k: (data[k].detach() if zc else data[k].detach().to(torch.float32).contiguous().clone()) for k in names}
                 static["testing"] = True
                 m._ws_slot = self._slots[slot]
+                # (captured forwards: the library's NaN poses are the range guard -- nothing of the module's guard can run inside a graph)
+                m._guard_override = "off"
                 try:
                     for _ in range(2):                   # workspace, packed weights, H3 range check: all before the capture
                         m(static)
@@ -171,6 +179,7 @@ class InFlight:
                         out = m(static)
                 finally:
                     m._ws_slot = 0
+                    m._guard_override = None
                 cap = (key, g, static, out)
                 if len(caps) >= 4 or any(k[:5] != key[:5] for k in caps):      # other shape / arithmetic / weights: the old graphs are dead
                     caps.clear()
@@ -193,6 +202,9 @@ class InFlight:
         for s in self.streams:
             if s is not None:
                 s.synchronize()          # (every forward ends with its main stream waiting for its tail stream)
+        if self.depth == 1:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.model._poll_range(block=False)     # the range words of the finished forwards (model.range_guard, lazy inside a pipeline)
 
     def close(self) -> None:
         """Wait for the forwards in flight and release this runner's workspaces (2.6 GB each for 32 pairs of N = 5000)."""
