@@ -393,7 +393,10 @@ int pdsc_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds
  * (models/common.py:48-69, models/PointDSC.py:250-252); only the seed rows are computed.
  *   dist[s][j] = 2 - 2 * <normed[seed_s], normed[j]>;  knn_idx[s][0:k] = ranks 1..k of ascending
  *   (dist, index) order (rank 0 dropped exactly like `[:, :, 1:]`).
- * dist_scratch: [bs][S][ldd] floats, ldd = pdsc_compat_ld(N).  knn_idx: [bs][S][k] int32. */
+ * dist_scratch: [bs][S][ldd] floats, ldd = pdsc_compat_ld(N).  knn_idx: [bs][S][k] int32.
+ * NOTE: pdsc_knn_seeds = pdsc_knn_seeds_form(form 0): for large batches (bs * ceil(S / 32) >= 384) the library takes the fused
+ * form, which never writes dist_scratch -- its contents are then UNDEFINED.  A caller that wants the S x N distances back calls
+ * pdsc_knn_seeds_form(..., form = 1). */
 int pdsc_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx,
                    int bs, int N, int S, int k, void* stream);
 /* form: 0 = the library's choice, 1 = two launches through the S x N distance matrix (Gram rows, then a selection launch),

@@ -55,14 +55,17 @@ def _hipcc() -> str:
 PER_FILE_FLAGS = {"score_slp.hip": ["-fslp-vectorize"]}
 
 
-def _sources():
-    return sorted(CSRC.glob("*.hip"))
+def _sources(experiments: bool = False):
+    """csrc/*.hip is the product library; csrc/experiments/*.hip (A/B reproducers such as the SLP-vectorised scoring kernel) joins
+    experiments builds only."""
+    return sorted(CSRC.glob("*.hip")) + (sorted((CSRC / "experiments").glob("*.hip")) if experiments else [])
 
 
 def _digest(flags=None) -> str:
     flags = FLAGS if flags is None else flags
     h = hashlib.sha256()
-    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "pointdsc_hip.h"]):
+    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list((CSRC / "experiments").glob("*.hip")) +
+                    [PKG.parent / "include" / "pointdsc_hip.h"]):
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(flags).encode())
@@ -99,7 +102,7 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False, 
         fstamp = obj_dir / (src.stem + ".sha256")
         if not force and obj.exists() and fstamp.exists() and fstamp.read_text().strip() == fd:
             return obj
-        cmd = [hipcc, *flags, *PER_FILE_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *flags, *PER_FILE_FLAGS.get(src.name, []), f"-I{CSRC}", "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[pointdsc_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -107,7 +110,7 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False, 
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, _sources()))
+        objs = list(ex.map(compile_one, _sources(experiments)))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(lib)]
     if verbose:
         print("[pointdsc_amd.build]", " ".join(cmd), flush=True)

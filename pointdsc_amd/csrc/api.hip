@@ -594,7 +594,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_TRY(pdsc_normalize_confidence(featA, h2, W(PDSC_W_CLS3_W, 0), W(PDSC_W_CLS3_B, 0), normed, conf, M, stream));
     if (mode == 0) {
         PDSC_TRY(launch_nms_keys_grid(src, conf, cfg->nms_radius, keys, ws + L.find("nms_ws"), pdsc_nms_workspace_bytes(bs, N), bs, N, nvalid, hst));
-        PDSC_TRY(launch_rank_select(keys, seeds, bs, N, S, nvalid, svalid, hst));
+        PDSC_TRY(launch_rank_select(keys, seeds, bs, N, S, nvalid, svalid, hst, conv_mask));      // (+ the solver's mask := all-ones)
     } else {
         // models/PointDSC.py:158-163 and :176
         PDSC_TRY(pdsc_feature_compat(normed, W(PDSC_W_SIGMA, 0), Mout, ldM, bs, N, stream));
@@ -611,8 +611,8 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         PDSC_TRY(pdsc_seed_transforms(src, tgt, knn_idx, eig, conv_mask, seed_trans, seed_w, bs, N, S, k,
                                       cfg->num_iterations, stream));
     } else
-        PDSC_TRY(pdsc_seed_solve(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig, conv_mask, nullptr,
-                                 seed_trans, seed_w, bs, N, S, k, cfg->num_iterations, stream));
+        PDSC_TRY(launch_seed_solve_forward(normed, src, tgt, knn_idx, W(PDSC_W_SIGMA, 0), W(PDSC_W_SIGMA_SPAT, 0), eig, conv_mask,
+                                           seed_trans, seed_w, bs, N, S, k, cfg->num_iterations, /*mask_ready=*/mode == 0, hst));
 #ifdef PDSC_EXPERIMENTS
     score_debug_slot() = env_int("PDSC_SCORE_DEBUG", 0) ? F("score_dbg") : nullptr;
 #endif
@@ -621,9 +621,10 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
     score_debug_slot() = nullptr;
 #endif
     if (mode == 0) {
-        PDSC_TRY(launch_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, initial, final_labels, bs, N, S, nvalid, hst));
-        // post refinement (:186 -> :403-438); final_labels stay those of the pre-refinement best hypothesis
-        PDSC_TRY(launch_post_refinement(initial, src, tgt, cfg->refine_threshold, cfg->refine_iters, final_trans, solves, bs, N, nvalid, hst, I("refine_trace"), range_flag));
+        // best hypothesis + its labels, then post refinement (:186 -> :403-438) in the same launch; final_labels stay those of the
+        // pre-refinement best hypothesis
+        PDSC_TRY(launch_select_and_refine(counts, seed_trans, src, tgt, cfg->inlier_threshold, cfg->refine_threshold, cfg->refine_iters, best, initial,
+                                          final_labels, final_trans, solves, bs, N, S, nvalid, hst, I("refine_trace"), range_flag));
     } else {
         // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,

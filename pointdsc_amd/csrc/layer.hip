@@ -450,6 +450,14 @@ extern "C" int pdsc_layer_fused(const float* msg, const float* res, const float*
                                 const float* b2, const float* w3, const float* b3, const float* wp, const float* bp,
                                 const float* wq, const float* bq, int M, void* stream) {
     if (featB_out) PDSC_REQUIRE(qkv_out, "pdsc_layer_fused: head needs qkv_out");
+    // this entry point sees the batch as ONE run of M independent rows (bs = 1, N = M): the per-pair counts of a ragged forward
+    // (layer_nvalid_slot) do not describe it -- with them in place the kernel took counts[0] for the row count of the whole batch
+    // (r06: the exact-fp32 path takes ragged batches now).  Padding rows are computed like any row; nothing valid reads them.
+    struct NoCounts {
+        const int* saved;
+        NoCounts() : saved(pdsc::layer_nvalid_slot()) { pdsc::layer_nvalid_slot() = nullptr; }
+        ~NoCounts() { pdsc::layer_nvalid_slot() = saved; }
+    } no_counts;
     return pdsc_layer_fused_split(msg, nullptr, nullptr, 0, 0, res, feat_in, feat_out, featB_out, qkv_out, nullptr, nullptr,
                                   w1, b1, w2, b2, w3, b3, wp, bp, wq, bq, nullptr, 1, M, stream);
 }

@@ -435,8 +435,11 @@ int launch_layer_h3(const LayerArgs& a, bool tail, bool head, hipStream_t st) {
     } else if (head && !tail && fb_pf) {
         PDSC_H3_LAUNCH(false, true, true);
     } else if (tail && head) {
+#ifdef PDSC_EXPERIMENTS       // (the shader-clock trace form: experiments builds, tools/layer_trace.py)
         if (a.trace) hipLaunchKernelGGL((layer_h3_kernel<true, true, true>), dim3(ceil_div(waves, LW_WAVES)), dim3(64 * LW_WAVES), 0, st, a);
-        else PDSC_H3_LAUNCH(true, true, false);
+        else
+#endif
+        PDSC_H3_LAUNCH(true, true, false);
     } else if (tail) {
         PDSC_H3_LAUNCH(true, false, false);
     } else {

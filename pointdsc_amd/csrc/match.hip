@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void match_nn_kernel(const float* __restrict__
                 if (MODE == 0) {
                     float d = sqrt_rn((2.0f - 2.0f * acc[r]) + 1e-6f);                                  // reference arithmetic, fp32
                     d = d != d ? -INFINITY : d;
-                    const bool take = j < j_end && d < best;                                           // strict: the first index among equal distances
+                    // strict: the first index among equal distances; the FIRST candidate of a lane is always taken (a row whose
+                    // distances are all +inf must still return np.argmin's answer, index 0 -- with `d < best` alone no lane ever wrote a key)
+                    const bool take = j < j_end && (d < best || best_j == 0x7fffffff);
                     best = take ? d : best;
                     best_j = take ? j : best_j;
                 } else {

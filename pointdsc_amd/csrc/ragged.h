@@ -12,7 +12,18 @@ namespace pdsc {
 
 int launch_nms_keys_grid(const float* src, const float* conf, float radius, float* keys, void* workspace, size_t workspace_bytes,
                          int bs, int N, const int* nvalid, hipStream_t st);
-int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st);
+// conv_mask_init != NULL: the kernel also sets conv_mask_init[b] = 0xFFFFFFFF for every pair (the start value of the seed solver's
+// convergence mask: launch_seed_solve_forward then skips its own fill launch)
+int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st,
+                       unsigned int* conv_mask_init = nullptr);
+// solver.hip: pdsc_seed_solve as the forward runs it; mask_ready: conv_mask already holds its start value (no fill launch)
+int launch_seed_solve_forward(const float* normed, const float* src, const float* tgt, const int* knn_idx, const float* sigma,
+                              const float* sigma_spat, float* eig_iters, unsigned int* conv_mask, float* seed_trans, float* seed_weights,
+                              int bs, int N, int S, int k, int num_iterations, bool mask_ready, hipStream_t st);
+// score.hip: pdsc_select_best + pdsc_post_refinement in one launch (one workgroup per pair does both; same arithmetic, same bits)
+int launch_select_and_refine(const int* counts, const float* seed_trans, const float* src, const float* tgt, float inlier_threshold,
+                             float refine_threshold, int max_iters, int* best, float* initial_trans, float* labels, float* final_trans,
+                             int* solves, int bs, int N, int S, const int* nvalid, hipStream_t st, int* trace, const unsigned int* range_flag);
 int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
                      const int* nvalid, hipStream_t st);
 // r05: the fused form (no S x N matrix) and its point-fragment operand

@@ -16,19 +16,21 @@ float*& score_debug_slot() {       // (experiments builds) where the next launch
 }
 
 // first argmax over the S counts, emit the winning transform and its inlier labels
-__global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict__ counts, const float* __restrict__ seed_trans,
+// (NT = threads of the workgroup that runs it: 1024 in select_best_kernel, 512 in select_refine_kernel -- the argmax is order
+//  independent and the labels elementwise, so the results do not depend on NT; Tb_out: the winning 4x4 stays in shared memory)
+template <int NT>
+__device__ __forceinline__ void select_best_body(const int* __restrict__ counts, const float* __restrict__ seed_trans,
                                                            const float* __restrict__ src, const float* __restrict__ tgt,
                                                            float thr, int* __restrict__ best_out,
                                                            float* __restrict__ initial_trans, float* __restrict__ labels,
-                                                           int NS, int S, const int* __restrict__ nvalid) {
-    const int N = nvalid ? nvalid[blockIdx.x] : NS;
-    __shared__ unsigned long long wbest[16];
-    __shared__ float Tb[16];
+                                                           int NS, int S, const int* __restrict__ nvalid, int b, float* __restrict__ Tb) {
+    const int N = nvalid ? nvalid[b] : NS;
+    __shared__ unsigned long long wbest[NT / 64];
     __shared__ int best_s;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // key = count << 32 | (0xFFFFFFFF - index): max key == highest count, lowest index among equals
     unsigned long long key = 0;
-    for (int s = t; s < S; s += 1024) {
+    for (int s = t; s < S; s += NT) {
         const unsigned long long kk = ((unsigned long long)(unsigned)counts[(size_t)b * S + s] << 32) | (0xFFFFFFFFu - (unsigned)s);
         key = kk > key ? kk : key;
     }
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict
     __syncthreads();
     if (t == 0) {
         unsigned long long k = wbest[0];
-        for (int w = 1; w < 16; ++w) k = wbest[w] > k ? wbest[w] : k;
+        for (int w = 1; w < NT / 64; ++w) k = wbest[w] > k ? wbest[w] : k;
         best_s = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu));
         if (best_out) best_out[b] = best_s;
     }
@@ -54,26 +56,36 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict
     __syncthreads();
     const float* srcb = src + (size_t)b * NS * 3;
     const float* tgtb = tgt + (size_t)b * NS * 3;
-    for (int i = t; i < N; i += 1024) {
+    for (int i = t; i < N; i += NT) {
         const float r = residual(Tb, srcb[i * 3], srcb[i * 3 + 1], srcb[i * 3 + 2], tgtb[i * 3], tgtb[i * 3 + 1], tgtb[i * 3 + 2]);
         labels[(size_t)b * NS + i] = r < thr ? 1.0f : 0.0f;
     }
-    for (int i = N + t; i < NS; i += 1024) labels[(size_t)b * NS + i] = 0.0f;       // padding rows of a ragged batch
+    for (int i = N + t; i < NS; i += NT) labels[(size_t)b * NS + i] = 0.0f;       // padding rows of a ragged batch
+}
+
+__global__ __launch_bounds__(1024) void select_best_kernel(const int* __restrict__ counts, const float* __restrict__ seed_trans,
+                                                           const float* __restrict__ src, const float* __restrict__ tgt,
+                                                           float thr, int* __restrict__ best_out,
+                                                           float* __restrict__ initial_trans, float* __restrict__ labels,
+                                                           int NS, int S, const int* __restrict__ nvalid) {
+    __shared__ float Tb[16];
+    select_best_body<1024>(counts, seed_trans, src, tgt, thr, best_out, initial_trans, labels, NS, S, nvalid, blockIdx.x, Tb);
 }
 
 // post_refinement: one persistent 512-thread workgroup per pair runs the whole <=max_iters loop.
-__global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ initial_trans, const float* __restrict__ src,
+// the loop of post_refinement for pair b, run by one 512-thread workgroup (shared by refine_kernel and select_refine_kernel)
+__device__ __forceinline__ void refine_body(const float* __restrict__ initial_trans, const float* __restrict__ src,
                                                       const float* __restrict__ tgt, float thr, int max_iters,
                                                       float* __restrict__ final_trans, int* __restrict__ solves, int NS,
                                                       const int* __restrict__ nvalid, int* __restrict__ trace,
-                                                      const unsigned int* __restrict__ range_flag) {
+                                                      const unsigned int* __restrict__ range_flag, int b, const float* __restrict__ T0_shared) {
     __shared__ float red[8 * 9];
     __shared__ float Tc[16];
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x;
     const int N = nvalid ? nvalid[b] : NS;
     const float* srcb = src + (size_t)b * NS * 3;
     const float* tgtb = tgt + (size_t)b * NS * 3;
-    if (t < 16) Tc[t] = initial_trans[(size_t)b * 16 + t];
+    if (t < 16) Tc[t] = T0_shared ? T0_shared[t] : initial_trans[(size_t)b * 16 + t];
     // trace (optional) [bs][PDSC_REFINE_TRACE]: the inlier count of every iteration evaluated (models/PointDSC.py:424-425), -1 after
     // the last one -- the discrete part of the loop, compared by the parity census with the reference's own sequence
     if (trace && t < PDSC_REFINE_TRACE) trace[(size_t)b * PDSC_REFINE_TRACE + t] = -1;
@@ -131,6 +143,31 @@ __global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ i
     if (t == 0 && solves) solves[b] = solved;
 }
 
+__global__ __launch_bounds__(512) void refine_kernel(const float* __restrict__ initial_trans, const float* __restrict__ src,
+                                                      const float* __restrict__ tgt, float thr, int max_iters,
+                                                      float* __restrict__ final_trans, int* __restrict__ solves, int NS,
+                                                      const int* __restrict__ nvalid, int* __restrict__ trace,
+                                                      const unsigned int* __restrict__ range_flag) {
+    refine_body(initial_trans, src, tgt, thr, max_iters, final_trans, solves, NS, nvalid, trace, range_flag, blockIdx.x, nullptr);
+}
+
+// r06: the two single-workgroup-per-pair launches at the end of the forward as one (one launch less on its chain): select the best
+// hypothesis and emit its labels (select_best_body), then refine it (refine_body) -- the same two bodies, the pose handed over in
+// shared memory instead of through initial_trans (which is still written: the parity census reads it).
+__global__ __launch_bounds__(512) void select_refine_kernel(const int* __restrict__ counts, const float* __restrict__ seed_trans,
+                                                            const float* __restrict__ src, const float* __restrict__ tgt, float thr,
+                                                            float refine_thr, int max_iters, int* __restrict__ best_out,
+                                                            float* __restrict__ initial_trans, float* __restrict__ labels,
+                                                            float* __restrict__ final_trans, int* __restrict__ solves, int NS, int S,
+                                                            const int* __restrict__ nvalid, int* __restrict__ trace,
+                                                            const unsigned int* __restrict__ range_flag) {
+    __shared__ float Tb[16];
+    const int b = blockIdx.x;
+    select_best_body<512>(counts, seed_trans, src, tgt, thr, best_out, initial_trans, labels, NS, S, nvalid, b, Tb);
+    __syncthreads();
+    refine_body(initial_trans, src, tgt, refine_thr, max_iters, final_trans, solves, NS, nvalid, trace, range_flag, b, Tb);
+}
+
 }  // namespace pdsc
 
 namespace pdsc {
@@ -159,6 +196,16 @@ int launch_select_best(const int* counts, const float* seed_trans, const float* 
     hipLaunchKernelGGL(select_best_kernel, dim3(bs), dim3(1024), 0, st, counts, seed_trans, src, tgt, thr, best, initial_trans, labels, N, S,
                        nvalid);
     return check_launch("pdsc_select_best");
+}
+
+int launch_select_and_refine(const int* counts, const float* seed_trans, const float* src, const float* tgt, float thr, float refine_thr,
+                             int max_iters, int* best, float* initial_trans, float* labels, float* final_trans, int* solves, int bs, int N,
+                             int S, const int* nvalid, hipStream_t st, int* trace, const unsigned int* range_flag) {
+    PDSC_REQUIRE(counts && seed_trans && src && tgt && initial_trans && labels && final_trans, "pdsc_select_best / pdsc_post_refinement: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0 && max_iters >= 0, "pdsc_select_best / pdsc_post_refinement: bs=%d N=%d S=%d iters=%d", bs, N, S, max_iters);
+    hipLaunchKernelGGL(select_refine_kernel, dim3(bs), dim3(512), 0, st, counts, seed_trans, src, tgt, thr, refine_thr, max_iters, best, initial_trans,
+                       labels, final_trans, solves, N, S, nvalid, trace, range_flag);
+    return check_launch("pdsc_select_best + pdsc_post_refinement");
 }
 
 int launch_post_refinement(const float* initial_trans, const float* src, const float* tgt, float threshold, int max_iters,

@@ -281,7 +281,11 @@ __device__ __forceinline__ unsigned int desc_key_bits(float f) {
 // and, sitting behind it, can never win the first-maximum argmax (models/PointDSC.py:331) -- nor change the AND of the
 // per-seed convergence flags.
 __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float* __restrict__ keys, int* __restrict__ seeds, int NS,
-                                                                  int SS, const int* __restrict__ nvalid, const int* __restrict__ svalid) {
+                                                                  int SS, const int* __restrict__ nvalid, const int* __restrict__ svalid,
+                                                                  unsigned int* __restrict__ conv_mask_init) {
+    // (r06, one launch less on the forward's chain) the per-pair convergence mask of the seed solver that follows starts at all-ones:
+    // initialised here -- this kernel is one workgroup per pair and runs before it on the same stream -- instead of by a fill launch
+    if (conv_mask_init && threadIdx.x == 0) conv_mask_init[blockIdx.x] = 0xFFFFFFFFu;
     const int N = nvalid ? nvalid[blockIdx.x] : NS, num_seeds = svalid ? svalid[blockIdx.x] : SS;
     extern __shared__ __attribute__((aligned(16))) unsigned long long surv[];     // [num_seeds]
     __shared__ int hist[256];
@@ -597,16 +601,17 @@ int launch_nms_keys_grid(const float* src, const float* conf, float radius, floa
     return check_launch("pdsc_nms_keys_grid(window)");
 }
 
-int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st) {
+int launch_rank_select(const float* keys, int* seeds, int bs, int N, int num_seeds, const int* nvalid, const int* svalid, hipStream_t st,
+                       unsigned int* conv_mask_init) {
     PDSC_REQUIRE(keys && seeds, "pdsc_rank_select: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && num_seeds >= 0 && num_seeds <= N, "pdsc_rank_select: bs=%d N=%d S=%d", bs, N, num_seeds);
-    if (num_seeds == 0) return PDSC_OK;
+    if (num_seeds == 0) return conv_mask_init ? launch_fill_u32(conv_mask_init, 0xFFFFFFFFu, (size_t)bs, st) : PDSC_OK;
     const size_t lds_bytes = (size_t)num_seeds * sizeof(unsigned long long);
     PDSC_REQUIRE(lds_bytes <= 128 * 1024, "pdsc_rank_select: num_seeds=%d exceeds the single-workgroup LDS list (16384)", num_seeds);
     const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&seed_select_kernel), lds_bytes > 65536 ? 128 * 1024 : 65536,
                                       "pdsc_rank_select(dynamic LDS)");
     if (rc != PDSC_OK) return rc;
-    hipLaunchKernelGGL(seed_select_kernel, dim3(bs), dim3(SEL_THREADS), lds_bytes, st, keys, seeds, N, num_seeds, nvalid, svalid);
+    hipLaunchKernelGGL(seed_select_kernel, dim3(bs), dim3(SEL_THREADS), lds_bytes, st, keys, seeds, N, num_seeds, nvalid, svalid, conv_mask_init);
     return check_launch("pdsc_rank_select");
 }
 

@@ -268,6 +268,44 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float* __res
     if (t == 0) kabsch_from_covariance(H, cA, cB, T + (size_t)b * 16);
 }
 
+// r06: the early-exit fix-up and the 3x3 decompositions in ONE launch (one launch less on the forward's chain).  A block = one wavefront =
+// 64 consecutive seeds.  Phase 1 (rare: only pairs whose global early exit picked an earlier iterate): the wavefront re-solves each of
+// its seeds of such a pair exactly as seed_transform_kernel does (lane = neighbour); phase 2: kabsch_batch_kernel's body, one thread
+// per seed.  Same functions on the same inputs: bit-identical to the two launches it replaces.
+__global__ __launch_bounds__(64) void fixup_kabsch_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                          const int* __restrict__ knn_idx, const float* __restrict__ eig_iters,
+                                                          const unsigned int* __restrict__ conv_mask, float* __restrict__ seed_trans,
+                                                          float* __restrict__ seed_w, int N, int S, int k, int num_iter, int count) {
+    const int lane = threadIdx.x, base = blockIdx.x * 64;
+    bool any = false;
+    for (int j = 0; j < 64 && base + j < count; ++j) {
+        const int i = base + j, b = i / S, s = i - b * S;
+        const int it = chosen_iterate(conv_mask[b], num_iter);                      // (uniform)
+        if (it == num_iter - 1) continue;
+        any = true;
+        const bool valid = lane < k;
+        const int idx = knn_idx[((size_t)b * S + s) * k + (valid ? lane : 0)];
+        const float* srcb = src + (size_t)b * N * 3;
+        const float* tgtb = tgt + (size_t)b * N * 3;
+        float v = eig_iters[(((size_t)b * S + s) * num_iter + it) * PDSC_MAX_K + lane];
+        v = valid ? v : 0.f;
+        seed_procrustes(lane, valid, v, srcb[idx * 3], srcb[idx * 3 + 1], srcb[idx * 3 + 2], tgtb[idx * 3], tgtb[idx * 3 + 1],
+                        tgtb[idx * 3 + 2], seed_trans + ((size_t)b * S + s) * 16, seed_w ? seed_w + ((size_t)b * S + s) * k : nullptr);
+    }
+    if (any) __threadfence();        // lane 0's slot stores above are read back by the slots' own threads below
+    const int i = base + lane;
+    if (i >= count) return;
+    float* slot = seed_trans + (size_t)i * 16;
+    float H[9], cA[3], cB[3], T[16];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H[e] = slot[e];          // (first read of these lines in this kernel: nothing stale can be cached)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { cA[e] = slot[9 + e]; cB[e] = slot[12 + e]; }
+    kabsch_from_covariance(H, cA, cB, T);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) slot[e] = T[e];
+}
+
 // The reference's power iteration stops ALL matrices of a call at the first iteration where every one of them passes
 // allclose (models/PointDSC.py:347-358).  In testing mode a call is one pair; the validation forward is batched, so
 // there the masks of all pairs are AND-ed.
@@ -299,6 +337,34 @@ extern "C" int pdsc_seed_power_iteration(const float* normed, const float* src, 
     return pdsc_seed_solve(normed, src, tgt, knn_idx, sigma, sigma_spat, eig_iters, conv_mask, seed_M, nullptr, nullptr, bs, N, S, k,
                            num_iterations, stream);
 }
+
+namespace pdsc {
+int launch_seed_solve_forward(const float* normed, const float* src, const float* tgt, const int* knn_idx, const float* sigma,
+                              const float* sigma_spat, float* eig_iters, unsigned int* conv_mask, float* seed_trans, float* seed_weights,
+                              int bs, int N, int S, int k, int num_iterations, bool mask_ready, hipStream_t st) {
+    PDSC_REQUIRE(normed && src && tgt && knn_idx && sigma && sigma_spat && eig_iters && conv_mask && seed_trans, "pdsc_seed_solve: null pointer");
+    PDSC_REQUIRE(bs > 0 && N > 0 && S > 0, "pdsc_seed_solve: bs=%d N=%d S=%d", bs, N, S);
+    PDSC_REQUIRE(k >= 1 && k <= PDSC_MAX_K, "pdsc_seed_solve: k=%d (max %d)", k, PDSC_MAX_K);
+    PDSC_REQUIRE(num_iterations >= 0 && num_iterations <= PDSC_MAX_POWER_ITERS, "pdsc_seed_solve: num_iterations=%d (max %d)",
+                 num_iterations, PDSC_MAX_POWER_ITERS);
+    if (!mask_ready)
+        if (const int rc = launch_fill_u32(conv_mask, 0xFFFFFFFFu, (size_t)bs, st); rc != PDSC_OK) return rc;
+    const int nb = ceil_div(k, 16);
+#define PDSC_SOLVE(NBV) launch_seed_solve<NBV>(normed, src, tgt, knn_idx, sigma, sigma_spat, eig_iters, conv_mask, nullptr, seed_trans, \
+                                               seed_weights, bs, N, S, k, num_iterations, st)
+    const int rc = nb == 1 ? PDSC_SOLVE(1) : nb == 2 ? PDSC_SOLVE(2) : nb == 3 ? PDSC_SOLVE(3) : PDSC_SOLVE(4);
+#undef PDSC_SOLVE
+    if (rc != PDSC_OK) return rc;
+    // the reference's global early exit (models/PointDSC.py:354-356) may have picked an earlier iterate for some pair (its seeds are
+    // re-solved) -- and every slot becomes its 4x4: one launch (fixup_kabsch_kernel)
+    if (num_iterations <= 0)        // (no iterate to choose: plain decompositions)
+        hipLaunchKernelGGL(kabsch_batch_kernel, dim3(ceil_div(bs * S, 64)), dim3(64), 0, st, seed_trans, bs * S);
+    else
+        hipLaunchKernelGGL(fixup_kabsch_kernel, dim3(ceil_div(bs * S, 64)), dim3(64), 0, st, src, tgt, knn_idx, eig_iters, conv_mask, seed_trans,
+                           seed_weights, N, S, k, num_iterations, bs * S);
+    return check_launch("pdsc_seed_solve(fix-up + kabsch)");
+}
+}  // namespace pdsc
 
 extern "C" int pdsc_seed_solve(const float* normed, const float* src, const float* tgt, const int* knn_idx, const float* sigma,
                                const float* sigma_spat, float* eig_iters, unsigned int* conv_mask, float* seed_M, float* seed_trans,

@@ -204,10 +204,29 @@ class PointDSC(nn.Module):
         self._wsplit = None
         self._wpack_key = None
         self._tensors = None
+        self._frozen_fp = None
+
+    def freeze_weights(self, frozen: bool = True) -> "PointDSC":
+        """Promise that no parameter or buffer is edited IN PLACE until freeze_weights(False): the per-call fingerprint below (a walk
+        over the 358 tensors' version counters, ~30 us of host time = 6 % of a one-pair N = 1000 call) is then taken once and reused.
+        Everything that goes through the nn.Module API (load_state_dict, .to() / .cuda(), train()) still invalidates the packed
+        weights; what a frozen module no longer notices is ``p.data.copy_(...)`` / an optimizer step on its tensors.  The reference's
+        evaluation loops (evaluation/test_3DMatch.py:32-54) never touch the weights between calls: bench.py --latency freezes."""
+        self._frozen = bool(frozen)
+        self._frozen_fp = None
+        return self
 
     def _weights_fingerprint(self) -> int:
         """Changes whenever a parameter or buffer is modified in place (optimizer step, ``p.data.copy_``, a sub-module's
-        ``load_state_dict``): the sum of the tensors' version counters.  ~30 us per call."""
+        ``load_state_dict``): the sum of the tensors' version counters.  ~30 us per call (freeze_weights() caches it)."""
+        if getattr(self, "_frozen", False):
+            if getattr(self, "_frozen_fp", None) is None or getattr(self, "_tensors", None) is None:
+                self._frozen = False
+                try:
+                    self._frozen_fp = self._weights_fingerprint()
+                finally:
+                    self._frozen = True
+            return self._frozen_fp
         if getattr(self, "_tensors", None) is None:
             self._tensors = list(self.parameters()) + list(self.buffers())
         return sum([t._version for t in self._tensors]) + 31 * sum([t.data_ptr() & 0xFFFF for t in self._tensors[:4]])

@@ -482,6 +482,11 @@ def knn_seeds(normed, seeds, k: int, return_dist: bool = False, form: str = "aut
     written to HBM, then a selection launch) or "fused" (one launch, no S x N matrix; the returned distances are then undefined).
     normed_pf: the rows in point-fragment order (ops.normalize_confidence_pf), the fused form's fast column operand."""
     forms = {"auto": 0, "matrix": 1, "fused": 2}
+    if return_dist:
+        # (ADVICE r05) only the matrix form writes the S x N distances: "auto" may pick the fused form for large batches
+        if form == "fused":
+            raise ValueError('knn_seeds(return_dist=True) needs form="matrix" (the fused form never writes the S x N distance matrix)')
+        form = "matrix"
     lib = _lib.load()
     normed, seeds = _chk(normed, "normed"), _chk(seeds, "seeds", torch.int32)
     bs, n = normed.shape[0], normed.shape[1]
