@@ -398,13 +398,14 @@ int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st) 
     const bool x3 = head && (a.wq_split || frag);
     const bool h3 = frag && a.gemm_format == PDSC_LAYER_GEMM_H3;
 #ifndef PDSC_EXPERIMENTS
-    // r06 prune: the product library ships the forms its own forward can reach -- the exact-fp32 path's rows +
-    // natural weights, and the fp32-GEMM fragment streams behind a split-precision attention (layer_gemm = "f32").  The generic H3
-    // variant (superseded by layer_h3.hip / layer_coop.hip, A/B knob PDSC_LAYER_H3_VARIANT), the natural-layout split-weight form and
-    // the shader-clock trace are compiled in experiments builds only (python -m pointdsc_amd.build --experiments).
-    if (h3 || a.trace || (x3 && !frag)) {
+    // r06 prune: the product library ships the forms its own forward and its stage-level parity tests reach -- the
+    // exact-fp32 path's rows + natural weights, the fp32-GEMM fragment streams behind a split-precision attention (layer_gemm = "f32")
+    // and the generic H3 variant (the stage tests compare layer_h3.hip / layer_coop.hip against it, and it serves the output sets those
+    // two do not).  The natural-layout split-weight form and the shader-clock trace are compiled in experiments builds only
+    // (python -m pointdsc_amd.build --experiments).
+    if (a.trace || (x3 && !frag)) {
         set_error("pdsc_layer_fused: this form of the wavefront-per-tile kernel (%s) exists in experiments builds of the library only",
-                  h3 ? "H3 GEMMs outside layer_h3.hip's output sets" : a.trace ? "shader-clock trace" : "split q|k|v weights in natural layout");
+                  a.trace ? "shader-clock trace" : "split q|k|v weights in natural layout");
         return PDSC_ERR_ARG;
     }
 #endif
@@ -412,28 +413,25 @@ int launch_layer_wave(const LayerArgs& a, bool tail, bool head, hipStream_t st) 
         profile_mark_begin(PDSC_PROF_LAYER, st);
 #ifdef PDSC_EXPERIMENTS
         if (h3 && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true, true>), grid, block, 0, st, a);
-        else if (h3) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, false, true>), grid, block, 0, st, a);
-        else if (frag && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true>), grid, block, 0, st, a);
+        else if (frag && !h3 && a.trace) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, true>), grid, block, 0, st, a);
         else if (x3 && !frag) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, false>), grid, block, 0, st, a);
         else
 #endif
-        if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true>), grid, block, 0, st, a);
+        if (h3) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true, false, true>), grid, block, 0, st, a);
+        else if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, true, true, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<true, true, false, false>), grid, block, 0, st, a);
         profile_mark_end(PDSC_PROF_LAYER, st);
     } else if (tail) {
-#ifdef PDSC_EXPERIMENTS
         if (h3) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true, false, true>), grid, block, 0, st, a);
-        else
-#endif
-        if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true>), grid, block, 0, st, a);
+        else if (frag) hipLaunchKernelGGL((layer_wave_kernel<true, false, false, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<true, false, false, false>), grid, block, 0, st, a);
     } else {
 #ifdef PDSC_EXPERIMENTS
-        if (h3) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true, false, true>), grid, block, 0, st, a);
-        else if (x3 && !frag) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, false>), grid, block, 0, st, a);
+        if (x3 && !frag && !h3) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, false>), grid, block, 0, st, a);
         else
 #endif
-        if (frag) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true>), grid, block, 0, st, a);
+        if (h3) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true, false, true>), grid, block, 0, st, a);
+        else if (frag) hipLaunchKernelGGL((layer_wave_kernel<false, true, true, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((layer_wave_kernel<false, true, false, false>), grid, block, 0, st, a);
     }
     return check_launch("pdsc_layer_fused(wave)");

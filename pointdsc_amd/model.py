@@ -393,31 +393,51 @@ class PointDSC(nn.Module):
         return res
 
     def _ragged_groups(self, counts):
-        """Index groups that can share a launch: the attention's key split (planned from the group's size and its longest pair)
-        must leave the group's shortest pair at least one 32-key tile per split.  Greedy over the pairs sorted by size."""
+        """Index groups that can share a launch.  Split-precision attention:
+          * att_leaves = "canonical" (r06): a pair's bits must be those of the call on that pair alone, whose attention cuts
+            its key tiles into pdsc_attention_leaf_count(N_i) leaves.  One launch has ONE leaf count (that of its longest pair), so only
+            pairs of the same leaf-count class share a launch, and a pair with fewer than two tiles per leaf -- which a ragged launch
+            would silently hand to the per-launch key split -- runs as its own (uniform) call;
+          * otherwise the key split (planned from the group's size and its longest pair) must leave the group's shortest pair at
+            least one 32-key tile per split.  Greedy over the pairs sorted by size.
+        Exact fp32 attention: its kernel takes any mix of sizes (an empty key range of a short pair merges with weight 0)."""
         lib = _lib.load()
         # a pair with no more than k correspondences takes the reference's per-pair clamp k = min(k, num_corr - 1)
         # (models/PointDSC.py:250): one launch has one k, so such a pair runs as its own (uniform) call
         small = [[i] for i in range(len(counts)) if counts[i] <= self.k]
-        order = sorted((i for i in range(len(counts)) if counts[i] > self.k), key=lambda i: -counts[i])
-        if not order:
+        rest = [i for i in range(len(counts)) if counts[i] > self.k]
+        if not rest:
             return small
-        groups, cur = [], []
-        for i in order:
-            trial = cur + [i]
-            ns = int(lib.pdsc_attention_split_default_split(len(trial), counts[trial[0]]))
-            if cur and (counts[i] + 31) // 32 < ns:
-                groups.append(cur)
-                cur = [i]
-            else:
-                cur = trial
-        groups.append(cur)
-        # a group whose plan (decided by its final size) still asks too much of its shortest pair sheds that pair
+        if self.attention_precision == "fp32":
+            return [sorted(rest, key=lambda i: -counts[i])] + small
+        classes = {}
+        if self.att_leaves == "canonical":
+            for i in rest:
+                c = int(lib.pdsc_attention_leaf_count(counts[i]))
+                if (counts[i] + 31) // 32 < 2 * c:
+                    small.append([i])
+                else:
+                    classes.setdefault(c, []).append(i)
+        else:
+            classes[0] = rest
         out = []
-        for g in groups:
-            while len(g) > 1 and (counts[g[-1]] + 31) // 32 < int(lib.pdsc_attention_split_default_split(len(g), counts[g[0]])):
-                out.append([g.pop()])
-            out.append(g)
+        for members in classes.values():
+            order = sorted(members, key=lambda i: -counts[i])
+            groups, cur = [], []
+            for i in order:
+                trial = cur + [i]
+                ns = int(lib.pdsc_attention_split_default_split(len(trial), counts[trial[0]]))
+                if cur and (counts[i] + 31) // 32 < ns:
+                    groups.append(cur)
+                    cur = [i]
+                else:
+                    cur = trial
+            groups.append(cur)
+            # a group whose plan (decided by its final size) still asks too much of its shortest pair sheds that pair
+            for g in groups:
+                while len(g) > 1 and (counts[g[-1]] + 31) // 32 < int(lib.pdsc_attention_split_default_split(len(g), counts[g[0]])):
+                    out.append([g.pop()])
+                out.append(g)
         return out + small
 
     def _run(self, corr_pos, src_keypts, tgt_keypts, testing, counts=None, _in_fallback=False):

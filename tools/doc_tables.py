@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Regenerates the result tables of DESIGN.md from the evidence bundle under profiles/ (tools/gpu_profile_run.sh <tag>):
-the text between `<!-- <tag>:<name> -->` and `<!-- /<tag>:<name> -->` is replaced.   python tools/doc_tables.py [tag, default r05]"""
+"""Writes profiles/<tag>_tables.md -- the round's full result tables -- from the evidence bundle under profiles/
+(tools/gpu_profile_run.sh <tag>).  DESIGN.md quotes the headline rows and points here (r06: the tables left DESIGN.md, which had
+grown to 119 KB).   python tools/doc_tables.py [tag, default r06]"""
 import json
 import re
 import subprocess
@@ -8,7 +9,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def L(name):
@@ -16,7 +17,7 @@ def L(name):
 
 
 def bench_table():
-    out = ["| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of the 16-bit MFMA peak | fused layer launch, frac of 8 TB/s | compat build, frac of 8 TB/s | socket power in the sustained leg (share of the cap), J per pair | reference CPU path | check: max dT vs reference / oracle |",
+    out = ["| config | pairs/s (K=20 timed steps, forwards in flight) | single stream | sustained | ms/step | attention launch, executed frac of the 16-bit MFMA peak | fused layer launch, frac of 8 TB/s on the minimal 3072 B/point (on the bytes moved) | compat build, frac of 8 TB/s | socket power in the sustained leg (share of the cap), J per pair | reference CPU path | check: max dT vs reference / oracle |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
     names = [("n5000_b32", "configs[2], headline"), ("n1000_b1", "configs[1]"), ("kitti_n5000_b16", "configs[3]"), ("lomatch_n10000_b8", "configs[4]"),
              ("kitti_n12000_b4", "the reference's KITTI evaluation size"), ("multiway_n20000_b1", "the reference's multiway size"),
@@ -30,7 +31,7 @@ def bench_table():
         pw = l.get("power")
         pws = "n/a" if not pw else f"{pw['mean_w']:.0f} W ({100 * pw['frac_of_cap']:.0f} %), {pw['joule_per_pair']:.2f} J"
         out.append(f"| `{n}` ({lab}) | **{l['value']:.0f}** ({l['in_flight']} in flight) | {l['single_stream']['value']:.0f} | {l['sustained']['value']:.0f} | "
-                   f"{l['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms, {r['executed_frac']:.3f} | {rl['avg_launch_ms']:.3f} ms, {rl['frac']:.3f} | "
+                   f"{l['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms, {r['executed_frac']:.3f} | {rl['avg_launch_ms']:.3f} ms, {rl['frac']:.3f}" + (f" (moved {rl['moved_frac']:.3f})" if rl.get('moved_frac') else "") + f" | "
                    f"{rc['avg_launch_ms']:.3f} ms, {rc['frac']:.3f} | {pws} | {cb.get('value')} ({cb.get('kind')}, {cb.get('cores')} thr) | "
                    f"{c.get('max_abs_dT_vs_reference') or float('nan'):.1e} / {c.get('max_abs_dT_vs_oracle') or float('nan'):.1e} ({'ok' if c['ok'] else 'FAIL'}) |")
     return "\n".join(out)
@@ -77,14 +78,22 @@ def latency_table():
 BLOCKS = {"bench": bench_table, "shares": share_table, "latency": latency_table, "census": lambda: census(f"{TAG}_parity_census.txt"),
           "census_fp32": lambda: census(f"{TAG}_parity_census_exact_fp32.txt")}
 
+TITLES = {"bench": "One bench line per configuration (shipped defaults, one MI355X)",
+          "shares": "Per-GPU shares of the 2- / 4- / 8-GPU strong-scaling runs, measured on one GPU (no curve has been measured on hardware)",
+          "latency": "The number an unchanged caller sees: one pair per call, pose + labels read back (bench.py --latency)",
+          "census": "Parity census, shipped arithmetic, every family at every batch size (tools/parity_census.py)",
+          "census_fp32": "Parity census, exact-fp32 arithmetic"}
+
 if __name__ == "__main__":
-    p = ROOT / "DESIGN.md"
-    s = p.read_text()
+    out = [f"# Result tables of round {TAG[1:]} (generated by tools/doc_tables.py from profiles/{TAG}_*)", ""]
     for name, fn in BLOCKS.items():
-        pat = re.compile(rf"(<!-- {TAG}:{name} -->\n).*?(\n<!-- /{TAG}:{name} -->)", re.S)
-        if not pat.search(s):
-            print("no block", name)
-            continue
-        s = pat.sub(lambda m: m.group(1) + fn() + m.group(2), s)
-    p.write_text(s)
-    print("DESIGN.md tables regenerated")
+        try:
+            body = fn()
+        except Exception as e:  # noqa: BLE001
+            body = f"(not generated: {e!r})"
+        out += [f"## {TITLES[name]}", "", body, ""]
+    st = ROOT / "profiles" / f"{TAG}_stage_census.txt"
+    if st.exists():
+        out += ["## Stage census on the trained-like checkpoints (test_trained_checkpoint_stage_decisions_follow_the_reference)", "", "```", st.read_text().strip(), "```", ""]
+    (ROOT / "profiles" / f"{TAG}_tables.md").write_text("\n".join(out))
+    print(f"profiles/{TAG}_tables.md written")
