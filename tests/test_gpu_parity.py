@@ -1996,6 +1996,16 @@ def test_build_correspondences_matches_reference_golden(name):
     assert np.abs(res["corr_pos"][0].cpu().numpy() - fx["ref_corr_pos"]).max() < 1e-5
     assert np.array_equal(res["src_keypts"][0].cpu().numpy(), skp[fx["ref_corr"][:, 0]])
     assert np.array_equal(res["tgt_keypts"][0].cpu().numpy(), tkp[fx["ref_corr"][:, 1]])
+    # r06: the fused entry (pdsc_build_correspondences: 3 / 4 launches) against the three stage entry points it replaced (5 / 8):
+    # same device code, same bits -- with and without the mutual check, both metrics
+    for mutual in (False, True):
+        for metric in ("l2", "ip"):
+            a = correspondences.build_correspondences(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), g(torch.from_numpy(skp)),
+                                                      g(torch.from_numpy(tkp)), use_mutual=mutual, metric=metric)
+            b = correspondences.build_correspondences_staged(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), g(torch.from_numpy(skp)),
+                                                             g(torch.from_numpy(tkp)), use_mutual=mutual, metric=metric)
+            for k in ("corr", "corr_pos", "src_keypts", "tgt_keypts"):
+                assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (mutual, metric, k)
 
 
 @pytest.mark.parametrize("name", ["corr_lomatch_n1000_d32", "corr_lomatch_n5000_d32"])
