@@ -138,6 +138,10 @@ enum pdsc_compat_format { PDSC_COMPAT_F32 = 0, PDSC_COMPAT_U16 = 1 };
  * carries a device-side sentinel (workspace entry "range_flag", [bs] u32, pdsc_workspace_offset): a pair any of whose activations
  * reached 65504 on its way into an fp16 pair has a non-zero word there after the call AND its final_trans is returned as NaN. */
 enum pdsc_attention_precision { PDSC_ATT_FP16X3 = 0, PDSC_ATT_FP32 = 1, PDSC_ATT_FP16X3_ALL = 2 };
+/* Optional: where the testing forwards enqueued by THIS thread from now on also leave their range words -- host_words = [bs] u32 of
+ * pinned, device-mapped host memory (hipHostMalloc; checked), written by the forward's last launch: a caller that waits for the
+ * stream anyway reads them without a device-to-host copy of its own.  NULL switches it off.  Thread-local, like pdsc_last_error. */
+int pdsc_set_range_report(unsigned int* host_words);
 
 /* ---- packed weights --------------------------------------------------------------------------
  * One flat fp32 buffer holding the model with BatchNorm (eval) folded into the preceding conv and

@@ -42,6 +42,7 @@ _cfgp = C.POINTER(PdscConfig)
 # name -> (restype, argtypes); must list every function include/pointdsc_hip.h declares
 SIGNATURES = {
     "pdsc_version": (_i, []),
+    "pdsc_set_range_report": (_i, [_vp]),
     "pdsc_last_error": (C.c_char_p, []),
     "pdsc_experiments_enabled": (_i, []),
     "pdsc_wpack_floats": (_ll, [_cfgp]),

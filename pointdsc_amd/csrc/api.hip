@@ -24,6 +24,12 @@ unsigned int*& range_flag_slot() {
     return slot;
 }
 
+// where the NEXT forward of this thread also reports its range words: pinned, device-mapped host memory ([bs] u32), or NULL
+static unsigned int*& range_report_slot() {
+    static thread_local unsigned int* slot = nullptr;
+    return slot;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -271,6 +277,21 @@ static WsLayout make_layout(const pdsc_config* c, int bs, int N, int S) {
 using namespace pdsc;
 
 extern "C" int pdsc_version(void) { return PDSC_VERSION; }
+
+extern "C" int pdsc_set_range_report(unsigned int* host_words) {
+    if (host_words) {
+        // must be host memory the device can write (hipHostMalloc / a registered range): anything else would fault inside the kernel
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, host_words) != hipSuccess || at.type != hipMemoryTypeHost || at.devicePointer == nullptr) {
+            (void)hipGetLastError();
+            set_error("pdsc_set_range_report: %p is not pinned, device-mapped host memory", (void*)host_words);
+            return PDSC_ERR_ARG;
+        }
+        host_words = (unsigned int*)at.devicePointer;
+    }
+    range_report_slot() = host_words;
+    return PDSC_OK;
+}
 extern "C" int pdsc_experiments_enabled(void) {
 #ifdef PDSC_EXPERIMENTS
     return 1;
@@ -624,7 +645,7 @@ static int run_forward(int mode, const pdsc_config* cfg, const float* wpack, con
         // best hypothesis + its labels, then post refinement (:186 -> :403-438) in the same launch; final_labels stay those of the
         // pre-refinement best hypothesis
         PDSC_TRY(launch_select_and_refine(counts, seed_trans, src, tgt, cfg->inlier_threshold, cfg->refine_threshold, cfg->refine_iters, best, initial,
-                                          final_labels, final_trans, solves, bs, N, S, nvalid, hst, I("refine_trace"), range_flag));
+                                          final_labels, final_trans, solves, bs, N, S, nvalid, hst, I("refine_trace"), range_flag, range_report_slot()));
     } else {
         // best hypothesis is the result (:186 is skipped); the labels of the call are the logits (:190-191)
         PDSC_TRY(pdsc_select_best(counts, seed_trans, src, tgt, cfg->inlier_threshold, best, final_trans, keys /* scratch */,

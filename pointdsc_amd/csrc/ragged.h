@@ -23,7 +23,8 @@ int launch_seed_solve_forward(const float* normed, const float* src, const float
 // score.hip: pdsc_select_best + pdsc_post_refinement in one launch (one workgroup per pair does both; same arithmetic, same bits)
 int launch_select_and_refine(const int* counts, const float* seed_trans, const float* src, const float* tgt, float inlier_threshold,
                              float refine_threshold, int max_iters, int* best, float* initial_trans, float* labels, float* final_trans,
-                             int* solves, int bs, int N, int S, const int* nvalid, hipStream_t st, int* trace, const unsigned int* range_flag);
+                             int* solves, int bs, int N, int S, const int* nvalid, hipStream_t st, int* trace, const unsigned int* range_flag,
+                             unsigned int* range_report = nullptr);
 int launch_knn_seeds(const float* normed, const int* seeds, float* dist_scratch, int* knn_idx, int bs, int N, int S, int k,
                      const int* nvalid, hipStream_t st);
 // r05: the fused form (no S x N matrix) and its point-fragment operand

@@ -160,9 +160,12 @@ __global__ __launch_bounds__(512) void select_refine_kernel(const int* __restric
                                                             float* __restrict__ initial_trans, float* __restrict__ labels,
                                                             float* __restrict__ final_trans, int* __restrict__ solves, int NS, int S,
                                                             const int* __restrict__ nvalid, int* __restrict__ trace,
-                                                            const unsigned int* __restrict__ range_flag) {
+                                                            const unsigned int* __restrict__ range_flag, unsigned int* __restrict__ range_report) {
     __shared__ float Tb[16];
     const int b = blockIdx.x;
+    // (pdsc_set_range_report) the pair's range word also goes to pinned host memory: the caller that waits for the stream anyway reads
+    // it there without a copy of its own
+    if (range_report && threadIdx.x == 0) range_report[b] = range_flag ? range_flag[b] : 0u;
     select_best_body<512>(counts, seed_trans, src, tgt, thr, best_out, initial_trans, labels, NS, S, nvalid, b, Tb);
     __syncthreads();
     refine_body(initial_trans, src, tgt, refine_thr, max_iters, final_trans, solves, NS, nvalid, trace, range_flag, b, Tb);
@@ -200,11 +203,11 @@ int launch_select_best(const int* counts, const float* seed_trans, const float* 
 
 int launch_select_and_refine(const int* counts, const float* seed_trans, const float* src, const float* tgt, float thr, float refine_thr,
                              int max_iters, int* best, float* initial_trans, float* labels, float* final_trans, int* solves, int bs, int N,
-                             int S, const int* nvalid, hipStream_t st, int* trace, const unsigned int* range_flag) {
+                             int S, const int* nvalid, hipStream_t st, int* trace, const unsigned int* range_flag, unsigned int* range_report) {
     PDSC_REQUIRE(counts && seed_trans && src && tgt && initial_trans && labels && final_trans, "pdsc_select_best / pdsc_post_refinement: null pointer");
     PDSC_REQUIRE(bs > 0 && N > 0 && S > 0 && max_iters >= 0, "pdsc_select_best / pdsc_post_refinement: bs=%d N=%d S=%d iters=%d", bs, N, S, max_iters);
     hipLaunchKernelGGL(select_refine_kernel, dim3(bs), dim3(512), 0, st, counts, seed_trans, src, tgt, thr, refine_thr, max_iters, best, initial_trans,
-                       labels, final_trans, solves, N, S, nvalid, trace, range_flag);
+                       labels, final_trans, solves, N, S, nvalid, trace, range_flag, range_report);
     return check_launch("pdsc_select_best + pdsc_post_refinement");
 }
 

@@ -157,6 +157,8 @@ class PointDSC(nn.Module):
         self._range_pool = []                   # pinned [bs] int32 buffers, recycled
         self._calls = 0
         self.range_fallbacks = 0                # how many calls the guard found out of range (diagnostics / tests)
+        self._report_host = None                # pinned [bs] int32 the forward's last launch writes the range words into ("sync" guard)
+        self._report_ok = True
         self._wpack: Optional[torch.Tensor] = None
         self._wsplit: Optional[torch.Tensor] = None
         self._wpack_key = None
@@ -493,6 +495,14 @@ class PointDSC(nn.Module):
                     self._last_counts = {}
                 self._last_counts[self._ws_slot] = cnt      # (keeps the device arrays alive until the slot's next call: the launches are asynchronous)
             ragged = (C.c_void_p(cnt[0].data_ptr()), C.c_void_p(cnt[1].data_ptr()), min(counts)) if cnt is not None else (None, None, 0)
+            # "sync" range guard of a testing forward: the last launch writes the pairs' range words straight into pinned host memory
+            # (pdsc_set_range_report) -- no device-to-host copy of our own, only the wait
+            report = None
+            if (testing and wsplit is not None and not _in_fallback and (self._guard_override or self.range_guard) == "sync"
+                    and self._report_ok and not torch.cuda.is_current_stream_capturing()):
+                report = self._report_buffer(bs)
+                if lib.pdsc_set_range_report(C.c_void_p(report.data_ptr())) != 0:
+                    self._report_ok, report = False, None          # (not device-mapped on this platform: the copy path below)
             if tail is not None:
                 # encoder on the current stream, the latency-bound tail on the slot's high-priority stream (pdsc_forward_testing_streams)
                 rc = lib.pdsc_forward_testing_streams(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream,
@@ -508,10 +518,12 @@ class PointDSC(nn.Module):
                 M = torch.empty(bs, n, n, device=dev, dtype=torch.float32)
                 rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
                 what = "pdsc_forward_validation"
+        if report is not None:
+            lib.pdsc_set_range_report(None)
         _lib.check(rc, what)
         res = {"final_trans": final_trans, "final_labels": final_labels, "M": M}
         if wsplit is not None and not _in_fallback:
-            redo = self._guard_after_forward(ws, cfg, bs, n, num_seeds, dev)
+            redo = self._guard_after_forward(ws, cfg, bs, n, num_seeds, dev, report)
             if redo:
                 # exact-fp32 arithmetic from here on (kept for this module, like the range probe's fallback): same inputs, same call
                 return self._run(corr_pos, src_keypts, tgt_keypts, testing, counts, _in_fallback=True)
@@ -530,7 +542,12 @@ class PointDSC(nn.Module):
         self.layer_gemm = "f32"
         self.attention_precision = "fp32"
 
-    def _guard_after_forward(self, ws, cfg, bs, n, num_seeds, dev) -> bool:
+    def _report_buffer(self, bs: int) -> torch.Tensor:
+        if self._report_host is None or self._report_host.numel() < bs:
+            self._report_host = torch.zeros(max(bs, 32), dtype=torch.int32).pin_memory()
+        return self._report_host
+
+    def _guard_after_forward(self, ws, cfg, bs, n, num_seeds, dev, report=None) -> bool:
         """Range sentinel of the forward just enqueued (see range_guard in __init__).  True = re-run this call in exact fp32."""
         mode = self._guard_override or self.range_guard
         if mode not in ("sync", "lazy", "off"):
@@ -539,6 +556,15 @@ class PointDSC(nn.Module):
         if mode == "off":
             return False
         self._poll_range(block=False)
+        if report is not None:
+            torch.cuda.current_stream(dev).synchronize()
+            bad = report[:bs].numpy().nonzero()[0].tolist()
+            if not bad:
+                return False
+            self.range_fallbacks += 1
+            self._to_exact_fp32(f"activations of pair(s) {bad} of this batch reached the fp16 range (|x| >= 65504) of the split-precision "
+                                "arithmetic; re-running this call in exact fp32")
+            return True
         flags = self._flag_view(ws, cfg, bs, n, num_seeds)
         host = next((t for t in self._range_pool if t.numel() >= bs), None)
         if host is not None:

@@ -1569,13 +1569,14 @@ def _stage_census_body(name, step, arith, model, mod, ix, w, n, S, total):
             st["seed_sets_differ"] += len(set(gs_c.tolist()) ^ set(rs_c.tolist())) // 2
             # a-6 / a-10 on the seeds both lists hold, matched by correspondence
             rpos = {int(c): j for j, c in enumerate(rs)}
+            hashes_here = mod.set_hash_rows(dec["knn"][b])
             all_equal = len(pos) == 0 and lim == S
             for j, c in enumerate(gs[:lim]):                  # (positive-key seeds: the tail of a short list is argsort's tie order)
                 r = rpos.get(int(c))
                 if r is None or r >= lim:
                     continue
                 st["knn_sets"] += 1
-                if mod.set_hash(dec["knn"][b][j]) != int(ix["knn_hash32"][i][r]):
+                if int(hashes_here[j]) != int(ix["knn_hash32"][i][r]):
                     gap = float(ix["knn_gap32"][i][r])
                     st["knn_sets_differ"] += 1
                     st["knn_max_gap_of_differing"] = max(st["knn_max_gap_of_differing"], gap)

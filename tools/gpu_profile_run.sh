@@ -7,6 +7,7 @@
 #   <tag>_kernel_stats_<config>[_<B>pairs].txt  rocprofv3 --kernel-trace summary of a short single-stream bench run
 #   <tag>_pmc_summary.txt                   PMC passes over the headline configuration (tools/gpu_pmc_run.sh)
 #   <tag>_parity_census.txt                 tools/parity_census.py: every census pair at every batch size
+#   <tag>_stage_census.txt                  seeds / neighbour sets / votes of the trained-like families against the reference's recorded decisions
 #   <tag>_match_bench.txt, <tag>_sm_bench.txt, <tag>_compat_bench.txt   micro-benches
 set -u
 TAG=${1:-prof}
@@ -19,6 +20,8 @@ cd "$ROOT"
 CONFIGS="n5000_b32 n1000_b1 kitti_n5000_b16 lomatch_n10000_b8"
 timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40 > "$OUT/${TAG}_pytest_gpu.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -5 > "$OUT/${TAG}_smoke.txt"
+# r06: the stage census on the trained-like checkpoints (default arithmetic and the exact-fp32 floor), one line per family
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -s -k stage_decisions 2>&1 | grep "STAGE-CENSUS" | sed 's/^[F.]*//' > "$OUT/${TAG}_stage_census.txt"
 if [ -z "$QUICK" ]; then
   # PMC first: the bench lines below quote the HBM traffic of THIS build (profiles/traffic.json is regenerated from the summary)
   bash "$ROOT/tools/gpu_pmc_run.sh" ${TAG}_pmc --in-flight 1 --settle-seconds 0 > /dev/null 2>&1

@@ -74,6 +74,18 @@ def set_hash(idx) -> int:
     return h
 
 
+def set_hash_rows(idx) -> np.ndarray:
+    """set_hash of every row of an [S, k] index array at once (vectorised over the rows: the byte loop runs k * 4 times, not S * k * 4)."""
+    rows = np.sort(np.asarray(idx, dtype=np.int64), axis=1).astype("<i4")
+    by = rows.view(np.uint8).reshape(rows.shape[0], -1)
+    h = np.full(rows.shape[0], 0xcbf29ce484222325, dtype=np.uint64)
+    prime = np.uint64(0x100000001b3)
+    with np.errstate(over="ignore"):
+        for c in range(by.shape[1]):
+            h = (h ^ by[:, c].astype(np.uint64)) * prime
+    return h
+
+
 # A seed's neighbour set is "decided by round-off" when the reference's own gap between the last neighbour kept and the first one
 # left out (distances 2 - 2<f_i,f_j> of unit features, models/common.py:60-68) is below this.  2e-6 = 8 quanta of that fp32
 # expression near its operand 2.0 (2^-22 each), ~3 sigma of the rounding noise of a 128-term fp32 dot product of unit vectors
