@@ -551,16 +551,6 @@ int pdsc_select_correspondences(const int* src2tgt, const int* tgt2src, int Ns, 
  * over the *count rows (in_dim = 6, ThreeDMatch.py:299-308).  Outputs have capacity for every row of corr. */
 int pdsc_build_corr_pos(const float* src_keypts, const float* tgt_keypts, const int* corr, const int* count,
                         float* corr_pos, float* src_sel, float* tgt_sel, void* stream);
-/* r06: the whole construction (datasets/ThreeDMatch.py:283-290,299-308 / demo_registration.py:101-108) in 3 launches (4 with the
- * mutual check) instead of 5 (8): one fill of the key arrays, the matcher(s) leaving their 64-bit keys un-decoded, ONE finish launch
- * that decodes, applies the mutual check, compacts in ascending source order and gathers / centres.  Same device code as the three
- * calls above, same results bit for bit.  metric: 0 = L2 arg-min (pdsc_match_descriptors), 1 = inner-product arg-max (_ip).
- * scratch: pdsc_build_correspondences_scratch_bytes(Ns, Nt) bytes.  Output capacities as above (corr [Ns][2], *count, corr_pos
- * [Ns][6], src_sel / tgt_sel [Ns][3]). */
-size_t pdsc_build_correspondences_scratch_bytes(int Ns, int Nt);
-int pdsc_build_correspondences(const float* src_desc, const float* tgt_desc, const float* src_keypts, const float* tgt_keypts,
-                               int Ns, int Nt, int D, int use_mutual, int metric, int* corr, int* count, float* corr_pos,
-                               float* src_sel, float* tgt_sel, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- spectral-matching baseline: the N x N power iteration ------------------------------
  * replaces SM() of baseline_scripts/baseline_3DMatch.py:19-53:  M = max(0, 4.5 - d^2 / 2 / sigma^2) (zero diagonal,

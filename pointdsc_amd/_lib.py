@@ -114,8 +114,6 @@ SIGNATURES = {
     "pdsc_match_descriptors_ip": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pdsc_select_correspondences": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "pdsc_build_corr_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "pdsc_build_correspondences_scratch_bytes": (_sz, [_i, _i]),
-    "pdsc_build_correspondences": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pdsc_sm_workspace_bytes": (_sz, [_i, _i]),
     "pdsc_sm_baseline": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "pdsc_sm_baseline_form": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),

@@ -61,40 +61,6 @@ def build_correspondences(src_desc: torch.Tensor, tgt_desc: torch.Tensor, src_ke
     ``use_mutual`` keeps only mutual nearest neighbours (ThreeDMatch.py:286-288); Nc is then data dependent, which costs
     the one host synchronisation that reads it.  ``metric="ip"`` matches by the largest inner product, as the 3DLoMatch caller
     does (evaluation/test_3DLoMatch.py:45-48)."""
-    if metric not in ("l2", "ip"):
-        raise ValueError(f'metric must be "l2" or "ip", got {metric!r}')
-    lib = _lib.load()
-    skp, tkp = _chk(src_keypts, "src_keypts"), _chk(tgt_keypts, "tgt_keypts")
-    s, t = _chk(src_desc, "src_desc"), _chk(tgt_desc, "tgt_desc")
-    ns, d = s.shape
-    nt = t.shape[0]
-    if t.shape[1] != d:
-        raise ValueError("descriptor lengths differ")
-    dev = s.device
-    # one allocation for the five outputs (corr | count | corr_pos | src_sel | tgt_sel) and one for the key scratch: the call is a
-    # handful of microseconds of GPU work, so host-side allocations count (r06: 3 launches instead of 5, pdsc_build_correspondences)
-    out = torch.empty(ns * 14 + 2, device=dev, dtype=torch.int32)
-    corr = out[: 2 * ns].view(ns, 2)
-    count = out[2 * ns: 2 * ns + 1]
-    corr_pos = out[2 * ns + 2: 8 * ns + 2].view(torch.float32).view(ns, 6)
-    src_sel = out[8 * ns + 2: 11 * ns + 2].view(torch.float32).view(ns, 3)
-    tgt_sel = out[11 * ns + 2: 14 * ns + 2].view(torch.float32).view(ns, 3)
-    nb = int(lib.pdsc_build_correspondences_scratch_bytes(ns, nt))
-    scratch = torch.empty(nb, device=dev, dtype=torch.uint8)
-    with torch.cuda.device(dev):
-        st = torch.cuda.current_stream().cuda_stream
-        _lib.check(lib.pdsc_build_correspondences(_p(s), _p(t), _p(skp), _p(tkp), ns, nt, d, 1 if use_mutual else 0, 0 if metric == "l2" else 1,
-                                                  _p(corr), _p(count), _p(corr_pos), _p(src_sel), _p(tgt_sel), _p(scratch), nb, st),
-                   "pdsc_build_correspondences")
-    nc = int(count.item()) if use_mutual else ns
-    return {"corr_pos": corr_pos[None, :nc], "src_keypts": src_sel[None, :nc], "tgt_keypts": tgt_sel[None, :nc],
-            "corr": corr[:nc]}
-
-
-def build_correspondences_staged(src_desc: torch.Tensor, tgt_desc: torch.Tensor, src_keypts: torch.Tensor,
-                                 tgt_keypts: torch.Tensor, use_mutual: bool = False, metric: str = "l2") -> Dict[str, torch.Tensor]:
-    """The same result through the three stage entry points (match, select, gather): what build_correspondences did before r06 and
-    what the fused entry is tested against, bit for bit."""
     lib = _lib.load()
     skp, tkp = _chk(src_keypts, "src_keypts"), _chk(tgt_keypts, "tgt_keypts")
     s2t = match_descriptors(src_desc, tgt_desc, metric=metric)

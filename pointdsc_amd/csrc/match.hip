@@ -157,26 +157,19 @@ __global__ __launch_bounds__(256) void match_decode_kernel(const unsigned long l
 
 // corr[c] = (i, src2tgt[i]) for the kept i in ascending order (np.where order); *count = number kept.
 // mutual == 0 keeps every i.  One workgroup: block-wide exclusive scan in chunks of 1024.
-// (KEYS: src2tgt / tgt2src are the matcher's raw 64-bit keys -- index in the low word -- instead of decoded index arrays: the fused
-//  finish kernel below reads them in place; same values, same order, same result)
-template <bool KEYS>
-__device__ __forceinline__ int corr_select_body(const void* __restrict__ src2tgt_v, const void* __restrict__ tgt2src_v, int Ns, int mutual,
-                                                int* __restrict__ corr, int* __restrict__ count) {
+__global__ __launch_bounds__(1024) void corr_select_kernel(const int* __restrict__ src2tgt, const int* __restrict__ tgt2src, int Ns,
+                                                           int mutual, int* __restrict__ corr, int* __restrict__ count) {
     __shared__ int wave_tot[16];
     __shared__ int base;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    auto s2t = [&](int i) { return KEYS ? (int)(unsigned int)(reinterpret_cast<const unsigned long long*>(src2tgt_v)[i] & 0xffffffffu)
-                                        : reinterpret_cast<const int*>(src2tgt_v)[i]; };
-    auto t2s = [&](int j) { return KEYS ? (int)(unsigned int)(reinterpret_cast<const unsigned long long*>(tgt2src_v)[j] & 0xffffffffu)
-                                        : reinterpret_cast<const int*>(tgt2src_v)[j]; };
     if (t == 0) base = 0;
     __syncthreads();
     for (int i0 = 0; i0 < Ns; i0 += 1024) {
         const int i = i0 + t;
         int keep = 0, j = 0;
         if (i < Ns) {
-            j = s2t(i);
-            keep = mutual ? (t2s(j) == i) : 1;
+            j = src2tgt[i];
+            keep = mutual ? (tgt2src[j] == i) : 1;
         }
         int incl = keep;
 #pragma unroll
@@ -198,24 +191,19 @@ __device__ __forceinline__ int corr_select_body(const void* __restrict__ src2tgt
         __syncthreads();
     }
     if (t == 0) *count = base;
-    return base;
-}
-
-__global__ __launch_bounds__(1024) void corr_select_kernel(const int* __restrict__ src2tgt, const int* __restrict__ tgt2src, int Ns,
-                                                           int mutual, int* __restrict__ corr, int* __restrict__ count) {
-    corr_select_body<false>(src2tgt, tgt2src, Ns, mutual, corr, count);
 }
 
 // gather + centre: src_sel[c] = src_kp[corr[c][0]], tgt_sel[c] = tgt_kp[corr[c][1]], corr_pos = concat - column mean.
 // One workgroup (the set is at most a few 10^4 rows of 6 floats); column sums in fp64 so that the mean is the
 // correctly rounded one whatever the summation order.
-__device__ __forceinline__ void corr_pos_body(const float* __restrict__ src_kp, const float* __restrict__ tgt_kp,
-                                                        const int* __restrict__ corr, int n,
+__global__ __launch_bounds__(1024) void corr_pos_kernel(const float* __restrict__ src_kp, const float* __restrict__ tgt_kp,
+                                                        const int* __restrict__ corr, const int* __restrict__ count,
                                                         float* __restrict__ corr_pos, float* __restrict__ src_sel,
                                                         float* __restrict__ tgt_sel) {
     __shared__ double red[16][6];
     __shared__ float mean[6];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = *count;
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (int c = t; c < n; c += 1024) {
         const int i = corr[2 * c], j = corr[2 * c + 1];
@@ -250,25 +238,6 @@ __device__ __forceinline__ void corr_pos_body(const float* __restrict__ src_kp, 
     }
 }
 
-__global__ __launch_bounds__(1024) void corr_pos_kernel(const float* __restrict__ src_kp, const float* __restrict__ tgt_kp,
-                                                        const int* __restrict__ corr, const int* __restrict__ count,
-                                                        float* __restrict__ corr_pos, float* __restrict__ src_sel,
-                                                        float* __restrict__ tgt_sel) {
-    corr_pos_body(src_kp, tgt_kp, corr, *count, corr_pos, src_sel, tgt_sel);
-}
-
-// r06: decode + mutual check + ordered compaction + gather / centring in ONE single-workgroup launch, straight from the matcher's keys
-// (pdsc_build_correspondences: 3 launches instead of 5 without the mutual check, 4 instead of 8 with it; same bodies, same bits)
-__global__ __launch_bounds__(1024) void corr_finish_kernel(const unsigned long long* __restrict__ keys_s2t,
-                                                           const unsigned long long* __restrict__ keys_t2s, int Ns, int mutual,
-                                                           const float* __restrict__ src_kp, const float* __restrict__ tgt_kp,
-                                                           int* __restrict__ corr, int* __restrict__ count, float* __restrict__ corr_pos,
-                                                           float* __restrict__ src_sel, float* __restrict__ tgt_sel) {
-    const int n = corr_select_body<true>(keys_s2t, keys_t2s, Ns, mutual, corr, count);
-    __syncthreads();          // corr[] of this workgroup's own stores, read back by other threads below
-    corr_pos_body(src_kp, tgt_kp, corr, n, corr_pos, src_sel, tgt_sel);
-}
-
 }  // namespace pdsc
 
 using namespace pdsc;
@@ -279,8 +248,8 @@ extern "C" size_t pdsc_match_scratch_bytes(int Ns, int Nt) {
 }
 
 static int match_launch(int mode, const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
-                        float* nn_dist, void* scratch, size_t scratch_bytes, void* stream, bool keys_ready = false) {
-    PDSC_REQUIRE(src_desc && tgt_desc && (nn_idx || keys_ready) && scratch, "pdsc_match_descriptors: null pointer");
+                        float* nn_dist, void* scratch, size_t scratch_bytes, void* stream) {
+    PDSC_REQUIRE(src_desc && tgt_desc && nn_idx && scratch, "pdsc_match_descriptors: null pointer");
     PDSC_REQUIRE(Ns > 0 && Nt > 0 && D >= 1 && D <= MT_MAXD, "pdsc_match_descriptors: Ns=%d Nt=%d D=%d (D <= %d)", Ns, Nt, D, MT_MAXD);
     if (scratch_bytes < (size_t)Ns * sizeof(unsigned long long)) {
         set_error("pdsc_match_descriptors: scratch %zu < %zu bytes", scratch_bytes, (size_t)Ns * sizeof(unsigned long long));
@@ -288,8 +257,7 @@ static int match_launch(int mode, const float* src_desc, const float* tgt_desc, 
     }
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* keys = (unsigned long long*)scratch;
-    if (!keys_ready)
-        if (const int rc = launch_fill_u32((unsigned int*)keys, 0xFFFFFFFFu, (size_t)Ns * 2, st); rc != PDSC_OK) return rc;
+    if (const int rc = launch_fill_u32((unsigned int*)keys, 0xFFFFFFFFu, (size_t)Ns * 2, st); rc != PDSC_OK) return rc;
     // split the targets so that ~1024 workgroups exist, in whole staged tiles
     const int src_blocks = ceil_div(Ns, MT_SRC);
     int splits = ceil_div(1024, src_blocks);
@@ -300,7 +268,7 @@ static int match_launch(int mode, const float* src_desc, const float* tgt_desc, 
     if (mode == 0) hipLaunchKernelGGL(match_nn_kernel<0>, dim3(src_blocks, splits), dim3(256), 0, st, src_desc, tgt_desc, Ns, Nt, D, per, keys);
     else hipLaunchKernelGGL(match_nn_kernel<1>, dim3(src_blocks, splits), dim3(256), 0, st, src_desc, tgt_desc, Ns, Nt, D, per, keys);
     int rc = check_launch("pdsc_match_descriptors");
-    if (rc != PDSC_OK || keys_ready) return rc;          // (keys_ready: the fused finish kernel reads the keys in place)
+    if (rc != PDSC_OK) return rc;
     if (mode == 0) hipLaunchKernelGGL(match_decode_kernel<0>, dim3(ceil_div(Ns, 256)), dim3(256), 0, st, keys, nn_idx, nn_dist, Ns);
     else hipLaunchKernelGGL(match_decode_kernel<1>, dim3(ceil_div(Ns, 256)), dim3(256), 0, st, keys, nn_idx, nn_dist, Ns);
     return check_launch("pdsc_match_descriptors(decode)");
@@ -315,37 +283,6 @@ extern "C" int pdsc_match_descriptors(const float* src_desc, const float* tgt_de
 extern "C" int pdsc_match_descriptors_ip(const float* src_desc, const float* tgt_desc, int Ns, int Nt, int D, int* nn_idx,
                                          float* nn_dot, void* scratch, size_t scratch_bytes, void* stream) {
     return match_launch(1, src_desc, tgt_desc, Ns, Nt, D, nn_idx, nn_dot, scratch, scratch_bytes, stream);
-}
-
-extern "C" size_t pdsc_build_correspondences_scratch_bytes(int Ns, int Nt) {
-    if (Ns <= 0 || Nt <= 0) return 0;
-    return (size_t)(Ns + Nt) * sizeof(unsigned long long);
-}
-
-extern "C" int pdsc_build_correspondences(const float* src_desc, const float* tgt_desc, const float* src_keypts, const float* tgt_keypts,
-                                          int Ns, int Nt, int D, int use_mutual, int metric, int* corr, int* count, float* corr_pos,
-                                          float* src_sel, float* tgt_sel, void* scratch, size_t scratch_bytes, void* stream) {
-    PDSC_REQUIRE(src_desc && tgt_desc && src_keypts && tgt_keypts && corr && count && corr_pos && src_sel && tgt_sel && scratch,
-                 "pdsc_build_correspondences: null pointer");
-    PDSC_REQUIRE(Ns > 0 && Nt > 0 && (metric == 0 || metric == 1), "pdsc_build_correspondences: Ns=%d Nt=%d metric=%d", Ns, Nt, metric);
-    if (scratch_bytes < pdsc_build_correspondences_scratch_bytes(Ns, Nt)) {
-        set_error("pdsc_build_correspondences: scratch %zu < %zu bytes", scratch_bytes, pdsc_build_correspondences_scratch_bytes(Ns, Nt));
-        return PDSC_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    unsigned long long* k_s2t = (unsigned long long*)scratch;
-    unsigned long long* k_t2s = k_s2t + Ns;
-    // one fill for both key arrays, the matcher(s) leave their keys un-decoded, one finish launch
-    if (const int rc = launch_fill_u32((unsigned int*)k_s2t, 0xFFFFFFFFu, (size_t)(use_mutual ? Ns + Nt : Ns) * 2, st); rc != PDSC_OK) return rc;
-    int rc = match_launch(metric, src_desc, tgt_desc, Ns, Nt, D, nullptr, nullptr, k_s2t, (size_t)Ns * 8, stream, true);
-    if (rc != PDSC_OK) return rc;
-    if (use_mutual) {
-        rc = match_launch(metric, tgt_desc, src_desc, Nt, Ns, D, nullptr, nullptr, k_t2s, (size_t)Nt * 8, stream, true);
-        if (rc != PDSC_OK) return rc;
-    }
-    hipLaunchKernelGGL(corr_finish_kernel, dim3(1), dim3(1024), 0, st, k_s2t, use_mutual ? k_t2s : nullptr, Ns, use_mutual ? 1 : 0, src_keypts,
-                       tgt_keypts, corr, count, corr_pos, src_sel, tgt_sel);
-    return check_launch("pdsc_build_correspondences(finish)");
 }
 
 extern "C" int pdsc_select_correspondences(const int* src2tgt, const int* tgt2src, int Ns, int* corr, int* count, void* stream) {

@@ -1486,13 +1486,13 @@ _STAGE_BOUNDS = {"trained_n1000_b1": (0.01, 0.01, 5e-3, 0.002), "trained_n5000_b
 
 
 @pytest.mark.parametrize("name,step,pairs,arith", [("trained_n1000_b1", 1, 64, "default"), ("trained_n1000_b1", 16, 256, "default"),
-                                                   ("trained_n5000_b32", 32, 128, "default"), ("trained_kitti_n5000_b16", 16, 128, "default"),
+                                                   ("trained_n5000_b32", 32, 64, "default"), ("trained_kitti_n5000_b16", 16, 64, "default"),
                                                    ("trained_lomatch_n10000_b8", 8, 32, "default"),
                                                    # the same census with EXACT fp32 arithmetic (fp32 MFMA everywhere, fp32 matrix): the
                                                    # shares of near-tie decisions it leaves are the summation-order floor any fp32
                                                    # implementation other than torch's CPU kernels has; the default arithmetic must not
                                                    # be held to less than that (profiles/r06_stage_census.txt prints both)
-                                                   ("trained_n1000_b1", 16, 256, "exact_fp32"), ("trained_kitti_n5000_b16", 16, 128, "exact_fp32")])
+                                                   ("trained_n1000_b1", 16, 256, "exact_fp32"), ("trained_kitti_n5000_b16", 16, 64, "exact_fp32")])
 def test_trained_checkpoint_stage_decisions_follow_the_reference(name, step, pairs, arith):
     """the stage tests on discrete work (a-5 seeds, a-6 neighbour sets, a-10 votes) tolerate a few per cent
     of near-tie differences because SEEDED weights collapse the feature space (top-k boundary gaps of 5e-7).  Here the same decisions
@@ -1997,16 +1997,6 @@ def test_build_correspondences_matches_reference_golden(name):
     assert np.abs(res["corr_pos"][0].cpu().numpy() - fx["ref_corr_pos"]).max() < 1e-5
     assert np.array_equal(res["src_keypts"][0].cpu().numpy(), skp[fx["ref_corr"][:, 0]])
     assert np.array_equal(res["tgt_keypts"][0].cpu().numpy(), tkp[fx["ref_corr"][:, 1]])
-    # r06: the fused entry (pdsc_build_correspondences: 3 / 4 launches) against the three stage entry points it replaced (5 / 8):
-    # same device code, same bits -- with and without the mutual check, both metrics
-    for mutual in (False, True):
-        for metric in ("l2", "ip"):
-            a = correspondences.build_correspondences(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), g(torch.from_numpy(skp)),
-                                                      g(torch.from_numpy(tkp)), use_mutual=mutual, metric=metric)
-            b = correspondences.build_correspondences_staged(g(torch.from_numpy(src)), g(torch.from_numpy(tgt)), g(torch.from_numpy(skp)),
-                                                             g(torch.from_numpy(tkp)), use_mutual=mutual, metric=metric)
-            for k in ("corr", "corr_pos", "src_keypts", "tgt_keypts"):
-                assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (mutual, metric, k)
 
 
 @pytest.mark.parametrize("name", ["corr_lomatch_n1000_d32", "corr_lomatch_n5000_d32"])

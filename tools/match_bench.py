@@ -30,25 +30,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             gpu_us = e0.elapsed_time(e1) / 20 * 1e3
-            # the r05 form: three stage entry points (fill, match, decode, select, gather = 5 launches; 8 with the mutual check)
-            for _ in range(3):
-                correspondences.build_correspondences_staged(ta, tb, kp, kp, use_mutual=mutual)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(20):
-                correspondences.build_correspondences_staged(ta, tb, kp, kp, use_mutual=mutual)
-            e1.record()
-            torch.cuda.synchronize()
-            staged_us = e0.elapsed_time(e1) / 20 * 1e3
             # one call at a time, waited for (what a per-pair evaluation loop sees: launch count matters here, not in the back-to-back loops)
-            lat = {}
-            for name_, fn in (("fused", correspondences.build_correspondences), ("staged", correspondences.build_correspondences_staged)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                correspondences.build_correspondences(ta, tb, kp, kp, use_mutual=mutual)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(50):
-                    fn(ta, tb, kp, kp, use_mutual=mutual)
-                    torch.cuda.synchronize()
-                lat[name_] = (time.perf_counter() - t0) / 50 * 1e6
+            lat_us = (time.perf_counter() - t0) / 50 * 1e6
             t0 = time.perf_counter()
             dist = np.sqrt(2 - 2 * (a @ b.T) + 1e-6)
             idx = np.argmin(dist, axis=1)
@@ -56,7 +44,7 @@ def main():
                 np.argmin(dist, axis=0)
             cpu_ms = (time.perf_counter() - t0) * 1e3
             flops = 2.0 * n * n * d * (2 if mutual else 1)
-            print(f"N={n} D={d} mutual={mutual}: GPU {gpu_us:8.1f} us ({flops / gpu_us / 1e6:6.2f} TFLOP/s; staged form {staged_us:8.1f} us; one call at a time, waited for: fused {lat['fused']:7.1f} / staged {lat['staged']:7.1f} us)   numpy on the host {cpu_ms:8.1f} ms")
+            print(f"N={n} D={d} mutual={mutual}: GPU {gpu_us:8.1f} us ({flops / gpu_us / 1e6:6.2f} TFLOP/s; one call at a time, waited for: {lat_us:7.1f} us)   numpy on the host {cpu_ms:8.1f} ms")
 
 
 if __name__ == "__main__":
