@@ -22,7 +22,7 @@ for pass in \
   "WRITE_SIZE" ; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace -d /tmp/pmc_$i -o p -- python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-check --sustain-seconds 0 "$@" > "$OUT/${TAG}_pass$i.log" 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace -d /tmp/pmc_$i -o p -- python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-check --sustain-seconds 0 --extra off "$@" > "$OUT/${TAG}_pass$i.log" 2>&1
   echo "## pass $i: $pass (exit $?)" >> "$SUMMARY"
   DB=$(find /tmp/pmc_$i -name '*.db' | head -1)
   if [ -n "$DB" ]; then python "$ROOT/tools/rocpd_pmc_stats.py" "$DB" $FILTER >> "$SUMMARY" 2>&1; fi

@@ -57,7 +57,7 @@ cd /tmp
 for s in n5000_b32:32 n1000_b1:1 kitti_n5000_b16:16 lomatch_n10000_b8:8 n5000_b32:4 kitti_n5000_b16:2 lomatch_n10000_b8:1; do
   c=${s%%:*}; B=${s##*:}
   rm -rf /tmp/prof_$c
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o k -- python "$ROOT/bench.py" --config $c --global-batch $B --in-flight 1 --steps 6 --warmup 1 --settle-seconds 0 --no-cpu-baseline --no-check --sustain-seconds 0 > "$OUT/${TAG}_rocprof_${c}_$B.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o k -- python "$ROOT/bench.py" --config $c --global-batch $B --in-flight 1 --steps 6 --warmup 1 --settle-seconds 0 --no-cpu-baseline --no-check --sustain-seconds 0 --extra off > "$OUT/${TAG}_rocprof_${c}_$B.log" 2>&1
   DB=$(find /tmp/prof_$c -name '*.db' | head -1)
   [ -n "$DB" ] && python "$ROOT/tools/rocpd_kernel_stats.py" "$DB" > "$OUT/${TAG}_kernel_stats_${c}_${B}pairs.txt" 2>&1
   rm -rf /tmp/prof_$c
