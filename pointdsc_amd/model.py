@@ -553,8 +553,8 @@ class PointDSC(nn.Module):
         if mode not in ("sync", "lazy", "off"):
             raise ValueError(f"range_guard must be 'sync', 'lazy' or 'off', got {mode!r}")
         self._calls += 1
-        if mode == "off":
-            return False
+        if mode == "off" or torch.cuda.is_current_stream_capturing():
+            return False          # (inside a graph capture nothing of the guard can run: the library's NaN poses remain)
         self._poll_range(block=False)
         if report is not None:
             torch.cuda.current_stream(dev).synchronize()
@@ -572,7 +572,7 @@ class PointDSC(nn.Module):
         else:
             host = torch.empty(max(bs, 32), dtype=torch.int32).pin_memory()
         host[:bs].copy_(flags, non_blocking=True)
-        if mode == "lazy" or torch.cuda.is_current_stream_capturing():
+        if mode == "lazy":
             ev = torch.cuda.Event()
             ev.record()
             self._range_pending.append((ev, host, bs, self._calls))

@@ -1076,6 +1076,53 @@ def test_seed_matrices_power_iteration_and_transforms(n):
     assert float(d.median()) < 5e-6
 
 
+_TRAINED_CASES = {}
+
+
+def trained_case(pair_index):
+    """Oracle stages of pair `pair_index` of the trained-like N = 1000 family (tests/golden/trained_3dmatch.npz weights)."""
+    if pair_index not in _TRAINED_CASES:
+        name = "trained_n1000_b1"
+        w = workloads.WORKLOADS[name]
+        kw = dict(w["model"])
+        sd = workloads.state_dict(name, PointDSC(**kw).state_dict())
+        pair = workloads.batch(name, pair_index, 1)
+        res = O.forward_testing(sd, pair["corr_pos"], pair["src_keypts"], pair["tgt_keypts"], return_stages=True,
+                                **{k: kw[k] for k in ORACLE_KEYS})
+        _TRAINED_CASES[pair_index] = dict(sd=sd, pair=pair, st=res["stages"][0], kw=kw)
+    return _TRAINED_CASES[pair_index]
+
+
+@pytest.mark.parametrize("pair_index", [2, 3, 7])            # 20 %, 40 % and 40 % inliers (inlier cycle 5 / 10 / 20 / 40 %)
+def test_discrete_stages_are_exact_on_trained_features(pair_index):
+    """the seeded-weight stage tests above tolerate 10 % of the seeds with another neighbour set and 3 % of the
+    hypotheses off by more than 1e-4, because seeded weights collapse the feature space (top-k gaps of 5e-7).  On the trained-like
+    checkpoint there is no such excuse: each stage is fed the ORACLE's own inputs (its normalised features, its seeds, its neighbour
+    lists), so only the stage's arithmetic differs, and the discrete results must be EQUAL --
+      a-6: the 40-neighbour set of every seed (100 %, no allowance);
+      a-7/8/9: every hypothesis within 1e-4 (100 %; median 5e-6), weights within 2e-6;
+      a-10: the vote count of every hypothesis and the chosen one, computed from the oracle's hypotheses: equal."""
+    c = trained_case(pair_index)
+    st, sd, pair = c["st"], c["sd"], c["pair"]
+    n = pair["corr_pos"].shape[1]
+    k = min(c["kw"]["k"], n - 1)
+    normed, seeds = st["normed"], st["seeds"]
+    idx = ops.knn_seeds(g(normed[None]), g(seeds[None].int()), k)[0].cpu().long()
+    want = st["knn_idx"]
+    differ = [s_ for s_ in range(len(seeds)) if set(idx[s_].tolist()) != set(want[s_].tolist())]
+    assert differ == [], (pair_index, "seeds whose neighbour set differs", differ[:8])
+    src, tgt = g(pair["src_keypts"]), g(pair["tgt_keypts"])
+    knn = g(want[None].int())
+    iters, mask, _ = ops.seed_power_iteration(g(normed[None]), src, tgt, knn, g(sd["sigma"]), g(sd["sigma_spat"]), 10)
+    trans, w_ = ops.seed_transforms(src, tgt, knn, iters, mask, 10)
+    assert (w_[0].cpu() - st["seed_weights"]).abs().max() < 2e-6
+    d = (trans[0].cpu() - st["seed_trans"]).abs().amax(dim=(1, 2))
+    assert float(d.max()) < 1e-4 and float(d.median()) < 5e-6, (pair_index, float(d.max()), float(d.median()))
+    counts, best, _initial, labels = ops.score_hypotheses(g(st["seed_trans"][None]), src, tgt, c["kw"]["inlier_threshold"])
+    assert torch.equal(counts[0].cpu().long(), st["counts"].long()), (pair_index, int((counts[0].cpu().long() != st["counts"].long()).sum()))
+    assert int(best[0]) == int(st["best"]) and torch.equal(labels[0].cpu(), st["final_labels"])
+
+
 def test_power_iteration_global_early_exit():
     """Rigid pair + identical features: every k x k block is c*(J-I) and converges at the 2nd iterate."""
     n, S, k = 200, 20, 40
