@@ -503,23 +503,25 @@ class PointDSC(nn.Module):
                 report = self._report_buffer(bs)
                 if lib.pdsc_set_range_report(C.c_void_p(report.data_ptr())) != 0:
                     self._report_ok, report = False, None          # (not device-mapped on this platform: the copy path below)
-            if tail is not None:
-                # encoder on the current stream, the latency-bound tail on the slot's high-priority stream (pdsc_forward_testing_streams)
-                rc = lib.pdsc_forward_testing_streams(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream,
-                                                      tail[0].cuda_stream, tail[1].cuda_event, tail[2].cuda_event)
-                what = "pdsc_forward_testing_streams"
-            elif cnt is not None:
-                rc = lib.pdsc_forward_testing_ragged(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
-                what = "pdsc_forward_testing_ragged"
-            elif testing:
-                rc = lib.pdsc_forward_testing(*common, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
-                what = "pdsc_forward_testing"
-            else:
-                M = torch.empty(bs, n, n, device=dev, dtype=torch.float32)
-                rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
-                what = "pdsc_forward_validation"
-        if report is not None:
-            lib.pdsc_set_range_report(None)
+            try:
+                if tail is not None:
+                    # encoder on the current stream, the latency-bound tail on the slot's high-priority stream (pdsc_forward_testing_streams)
+                    rc = lib.pdsc_forward_testing_streams(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream,
+                                                          tail[0].cuda_stream, tail[1].cuda_event, tail[2].cuda_event)
+                    what = "pdsc_forward_testing_streams"
+                elif cnt is not None:
+                    rc = lib.pdsc_forward_testing_ragged(*common, *ragged, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
+                    what = "pdsc_forward_testing_ragged"
+                elif testing:
+                    rc = lib.pdsc_forward_testing(*common, *outs, C.c_void_p(ws.data_ptr()), nbytes, stream)
+                    what = "pdsc_forward_testing"
+                else:
+                    M = torch.empty(bs, n, n, device=dev, dtype=torch.float32)
+                    rc = lib.pdsc_forward_validation(*common, *outs, C.c_void_p(M.data_ptr()), n, C.c_void_p(ws.data_ptr()), nbytes, stream)
+                    what = "pdsc_forward_validation"
+            finally:
+                if report is not None:
+                    lib.pdsc_set_range_report(None)          # (thread-local in the library: never left pointing at this buffer)
         _lib.check(rc, what)
         res = {"final_trans": final_trans, "final_labels": final_labels, "M": M}
         if wsplit is not None and not _in_fallback:
