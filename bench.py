@@ -356,6 +356,9 @@ def parse():
     ap.add_argument("--latency", action="store_true",
                     help="the number an UNCHANGED caller sees (evaluation/test_3DMatch.py:53-64): one forward at a time on the current stream, "
                          "its pose and labels copied to the host before the next call (forces --in-flight 1, no graphs)")
+    ap.add_argument("--range-guard", choices=["sync", "lazy", "off"], default=None,
+                    help="--latency: the module's fp16 range guard for the plain calls (default: the module's own, 'sync': the call waits for the "
+                         "forward and reads the range words the last launch left in pinned host memory; 'lazy': the call returns at once)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of this run's outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="extra measured leg after the timed region (0 = off)")
@@ -468,6 +471,8 @@ def main():
     if args.latency:
         args.in_flight, args.graphs = 1, "off"
         model.freeze_weights()          # the evaluation loop never edits the weights between calls: no per-call fingerprint walk
+        if args.range_guard:
+            model.range_guard = args.range_guard
     # each rank owns its shard of the global batch: pairs [rank*B, (rank+1)*B) of the workload's pair list
     batch = workloads.batch(args.config, args.first_pair + rank * B, B)
     data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
@@ -735,7 +740,8 @@ def main():
                    "compat_format": "f32" if fp32 else model.compat_format, "layer_gemm": model.layer_gemm,
                    "att_leaves": None if fp32 else model.att_leaves,
                    "attention_plan": None if fp32 else attention_plan(lib, B, N, model.att_leaves),
-                   "latency_mode": bool(args.latency), "gathered_poses_sha256_16": poses_sha,
+                   "latency_mode": bool(args.latency), "range_guard": model.range_guard if args.latency else "lazy (pipeline)",
+                   "gathered_poses_sha256_16": poses_sha,
                    "collective": ("none (single process, no process group)" if not (world > 1 or solo_pg) else
                                   "all_gather_into_tensor of the 64-byte poses, %s, world %d" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", world)),
                    "parallelism": "pairs sharded over %d GPU(s), %s; %d forward(s) in flight per GPU "
