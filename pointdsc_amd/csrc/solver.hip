@@ -277,12 +277,16 @@ __global__ __launch_bounds__(64) void fixup_kabsch_kernel(const float* __restric
                                                           const unsigned int* __restrict__ conv_mask, float* __restrict__ seed_trans,
                                                           float* __restrict__ seed_w, int N, int S, int k, int num_iter, int count) {
     const int lane = threadIdx.x, base = blockIdx.x * 64;
+    // the common case first: no pair this block's seeds belong to took the early exit (a handful of mask words, not one per seed)
     bool any = false;
-    for (int j = 0; j < 64 && base + j < count; ++j) {
+    {
+        const int last = min(base + 63, count - 1);
+        for (int b = base / S; b <= last / S; ++b) any |= chosen_iterate(conv_mask[b], num_iter) != num_iter - 1;
+    }
+    for (int j = 0; any && j < 64 && base + j < count; ++j) {
         const int i = base + j, b = i / S, s = i - b * S;
         const int it = chosen_iterate(conv_mask[b], num_iter);                      // (uniform)
         if (it == num_iter - 1) continue;
-        any = true;
         const bool valid = lane < k;
         const int idx = knn_idx[((size_t)b * S + s) * k + (valid ? lane : 0)];
         const float* srcb = src + (size_t)b * N * 3;
