@@ -98,6 +98,15 @@ constexpr int SPL_V_BYTES = 2 * SPL_V_PLANE;    // Vh | Vl   16 KiB
 // (Measured and dropped, profiles/r05_b_ab_leaves_in_kernel_merge.txt: merging inside this launch -- the last wave to finish a
 //  query tile, found through a ticket, loads the other partials past the caches -- puts 20-30 us of dependent memory round trips at
 //  the end of every workgroup: +14 % per launch at 32 pairs of N = 5000, against -5 % for the layer launch that then loads one message.)
+// Energy ablation (diagnostic builds only: PDSC_HIPCC_EXTRA=-DPDSC_ATT_ABLATE=<mask>, WRONG results, timing / power only;
+// tools/attention_power.py, profiles/r06_attention_energy_budget.txt): bit 0 drops the V_hi * P_lo MFMAs (1/6 of the launch's MFMAs),
+// bit 1 the two other low-order terms (K_lo * Q_hi, V_lo * P_hi: 1/3), bit 2 the last one (K_hi * Q_lo: 1/6) -- mask 7 leaves the
+// hi * hi products alone (1/3 of the MFMAs).  The product and experiments libraries are built without the macro.
+#ifndef PDSC_ATT_ABLATE
+#define PDSC_ATT_ABLATE 0
+#endif
+#define PDSC_MFMA_IF(bit, a_, b_, c_) (((PDSC_ATT_ABLATE) & (bit)) ? (c_) : PDSC_MFMA_X3(a_, b_, c_, 0, 0, 0))
+
 template <int NW, int CM = 0, bool TRACE = false, bool PS = false, bool PEEL = true, bool MG = false>
 __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplitArgs a) {
     constexpr bool C16 = CM == 1, CREG = CM == 2;
@@ -403,8 +412,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
         for (int j = 0; j < 8; ++j) {
             const sp16x8 fh = *reinterpret_cast<const sp16x8*>(K + SPL_KH + koff + 1024 * j);
             const sp16x8 fl = *reinterpret_cast<const sp16x8*>(K + SPL_KL + koff + 1024 * j);
-            sacc = PDSC_MFMA_X3(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
-            sacc = PDSC_MFMA_X3(fh, ql[j], sacc, 0, 0, 0);
+            sacc = PDSC_MFMA_IF(2, fl, qh[j], j == 0 ? zero16 : sacc);
+            sacc = PDSC_MFMA_IF(4, fh, ql[j], sacc);
             sacc = PDSC_MFMA_X3(fh, qh[j], sacc, 0, 0, 0);
         }
         if (C16) {
@@ -530,8 +539,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                         nh = *reinterpret_cast<const sp16x8*>(K + SPL_KH + koff + 1024 * (j + 1));
                         nl = *reinterpret_cast<const sp16x8*>(K + SPL_KL + koff + 1024 * (j + 1));
                     }
-                    sacc = PDSC_MFMA_X3(fl, qh[j], j == 0 ? zero16 : sacc, 0, 0, 0);
-                    sacc = PDSC_MFMA_X3(fh, ql[j], sacc, 0, 0, 0);
+                    sacc = PDSC_MFMA_IF(2, fl, qh[j], j == 0 ? zero16 : sacc);
+                    sacc = PDSC_MFMA_IF(4, fh, ql[j], sacc);
                     sacc = PDSC_MFMA_X3(fh, qh[j], sacc, 0, 0, 0);
                     if (j < DMA_SLOTS) dma_slot(kt, st, j);
                 }
@@ -572,8 +581,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sc_attention_split_kernel(AttSplit
                     nvl = *reinterpret_cast<const sp16x8*>(V + SPL_V_PLANE + vo);
                 }
                 const sp16x8 phj = __builtin_bit_cast(sp16x8, phw[j]), plj = __builtin_bit_cast(sp16x8, plw[j]);
-                o[c] = PDSC_MFMA_X3(vl, phj, o[c], 0, 0, 0);
-                o[c] = PDSC_MFMA_X3(vh, plj, o[c], 0, 0, 0);
+                o[c] = PDSC_MFMA_IF(2, vl, phj, o[c]);
+                o[c] = PDSC_MFMA_IF(1, vh, plj, o[c]);
                 o[c] = PDSC_MFMA_X3(vh, phj, o[c], 0, 0, 0);
                 if (!LAST && 8 + u < DMA_SLOTS) dma_slot(kt, st, 8 + u);
                 if (LAST) {
